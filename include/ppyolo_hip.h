@@ -1,0 +1,161 @@
+/*
+ * ppyolo_hip.h -- C ABI of libppyolo_hip.so: MI355X (gfx950) kernels for the PP-YOLO
+ * inference hot path of miemie2013/Pytorch-PPYOLO.
+ *
+ * The reference has NO FFI on this path (it is a torch.nn.Module tree); the entry points
+ * below are what a binding for this path would bind, one per reference operator that the
+ * path replaces.  Each declaration cites the reference code it stands in for
+ * (file:line inside the reference repo).  The only real FFI in the reference is the
+ * optional, CUDA-only `_ext.dcn_v2_forward` (external/DCNv2/src/dcn_v2.h:9-23); the DCN
+ * entry points mirror its argument order.
+ *
+ * Conventions (all functions):
+ *   - plain C types only; every pointer is a DEVICE pointer unless named `h_*`;
+ *   - activations are fp32 NHWC: element (n,h,w,c) of a tensor with pixel stride `ld`
+ *     (in floats, >= C, multiple of 4) lives at  base[((n*H + h)*W + w)*ld + c];
+ *     a channel slice of a wider (concat) buffer is expressed as base+offset with the
+ *     wide buffer's `ld`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
+ *     enqueue work, never synchronise, never allocate, keep no state => thread-safe per
+ *     stream and capturable into a hipGraph;
+ *   - return value: 0 = PPY_OK, negative = error (ppy_error_string()); nothing throws.
+ */
+#ifndef PPYOLO_HIP_H_
+#define PPYOLO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPY_OK 0
+#define PPY_ERR_BAD_ARG (-1)      /* shape / alignment / NULL-pointer contract violated   */
+#define PPY_ERR_UNSUPPORTED (-2)  /* valid request outside what the kernels implement     */
+#define PPY_ERR_WORKSPACE (-3)    /* workspace missing or too small                       */
+#define PPY_ERR_LAUNCH (-4)       /* hipLaunch / hipFuncSetAttribute failed               */
+
+#define PPY_ACT_NONE 0
+#define PPY_ACT_RELU 1
+#define PPY_ACT_LEAKY 2 /* LeakyReLU(0.1), reference model/custom_layers.py:133 */
+
+int ppy_version(void);
+const char *ppy_error_string(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Conv2dUnit.forward (reference model/custom_layers.py:243-253): conv(k in {1,3},
+ * pad=(k-1)/2) -> eval BatchNorm as per-channel affine -> [+ residual] -> activation.
+ * Also covers `x + shortcut; relu` of ConvBlock/IdentityBlock/BasicBlock
+ * (model/resnet_vd.py:55-56, :85-86, :265-266) through `residual`, the nearest x2
+ * upsample of the head routes (model/head.py:396-397) through `upsample2x`, and the two
+ * CoordConv channels (model/custom_layers.py:267-271) through `posbias`.
+ *
+ * Implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *   y[n,ho,wo,k] = act( (sum_{r,s,c} x[n,ho*stride+r-pad,wo*stride+s-pad,c]*w[k,r,s,c]
+ *                         + posbias[ho,wo,k]) * scale[k] + shift[k] + residual[n,ho,wo,k] )
+ * x: NHWC (ld x_ld), C % 32 == 0.   w: [K][R][S][C] ("KRSC").   scale/shift: [K].
+ * residual: NULL or NHWC [N,Ho,Wo,>=K] with ld res_ld.   posbias: NULL or [Ho*Wo][K].
+ * y: NHWC ld y_ld; with upsample2x != 0 y is [N,2Ho,2Wo,*] and every result is
+ * written to its 2x2 nearest-neighbour block.
+ * cfg: tile configuration id, -1 = built-in heuristic; splitk: 0 = heuristic, >=1 forced.
+ * ws: scratch for split-K partial sums, ppy_conv2d_workspace_bytes() bytes (may be
+ * NULL when that returns 0).
+ */
+int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
+                          const float *shift, const float *residual, int res_ld,
+                          const float *posbias, float *y, int y_ld, int N, int H, int W,
+                          int C, int K, int R, int S, int stride, int pad, int act,
+                          int upsample2x, int cfg, int splitk, void *ws, size_t ws_bytes,
+                          void *stream);
+size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
+                                  int pad, int cfg, int splitk);
+int ppy_conv2d_num_configs(void);
+/* Writes the tile configuration / split the heuristic would pick. */
+int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                    int *cfg_out, int *splitk_out);
+
+/* First backbone conv, `stage1_conv1_1` (reference model/resnet_vd.py:100, :133): 3x3
+ * stride-2 conv C_in=3 -> K (K % 4 == 0, K <= 64) + BN affine + ReLU, reading the
+ * caller's NCHW input directly and writing NHWC (fuses the layout change).
+ * x: [N,3,H,W] NCHW contiguous.  w: [K][3][3][3] in the reference's own KCRS order. */
+int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
+                                const float *shift, float *y, int y_ld, int N, int H, int W,
+                                int K, int act, void *stream);
+
+/* torch.nn.MaxPool2d(3, 2, 1) of the stem (reference model/resnet_vd.py:103, :136). */
+int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W,
+                         int C, void *stream);
+/* torch.nn.AvgPool2d(2, 2, 0) of the vd shortcut (reference model/resnet_vd.py:30, :53). */
+int ppy_avgpool2x2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C,
+                       void *stream);
+/* SPP (reference model/custom_layers.py:275-290): max-pool 5/9/13, stride 1, "same".
+ * x is channel slice [0,C) of the concat buffer; the three pooled maps are written to
+ * y5, y9, y13 (normally x+C, x+2C, x+3C of the same buffer), all with ld y_ld. */
+int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int y_ld, int N,
+                int H, int W, int C, void *stream);
+
+/* DCNv2 (reference model/custom_layers.py:551-677; arg order after
+ * external/DCNv2/src/dcn_v2.h:9-23: input, weight, bias-like, offset, mask, kernel,
+ * stride, pad).  `offset_mask`: NHWC [N,Ho,Wo,27] RAW output of conv_offset (18
+ * (y,x)-interleaved offsets then 9 mask logits; sigmoid is applied here).
+ * ppy_dcnv2_sample_f32 writes the modulated bilinear samples ("columns")
+ * cols[N*Ho*Wo][9*C] in (tap, c) order; ppy_dcnv2_f32 = sample + MFMA contraction with
+ * w [K][3][3][C] + BN affine + activation.  ws must hold N*Ho*Wo*9*C floats (+ split-K). */
+int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offset_mask, int om_ld,
+                         float *cols, int N, int H, int W, int C, int Ho, int Wo, int stride,
+                         int pad, void *stream);
+int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
+                  const float *shift, const float *offset_mask, int om_ld, float *y, int y_ld,
+                  int N, int H, int W, int C, int K, int stride, int pad, int act, int cfg,
+                  int splitk, void *ws, size_t ws_bytes, void *stream);
+size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int cfg,
+                                 int splitk);
+
+/* ------------------------------------------------------------------------------------
+ * get_iou_aware_score + yolo_box for ONE head level (reference model/head.py:21-141),
+ * fused with the `scores > score_threshold` candidate extraction of matrix_nms
+ * (reference model/matrix_nms.py:110-117).
+ * head_out: NHWC [N,S,S,A*(5+C) (+A if iou_aware)] with ld head_ld (channel layout as in
+ * the reference: [A IoU logits] then A x [tx,ty,tw,th,obj,C classes]).
+ * anchors_px: HOST pointer to A (w,h) pairs in pixels.  im_size: [N][2] = (h, w).
+ * boxes: [N][M_total][4]; this level writes rows [box_offset, box_offset + S*S*A) in
+ * (h, w, anchor) order.  Candidates with score > score_threshold are appended to
+ * cand_key/cand_idx ([N][cand_cap]; key = order-preserving uint32 image of the fp32
+ * score: bits ^ 0x80000000 for non-negative scores, ~bits for negative ones; idx =
+ * box*C + class) with the running count in cand_count[N] (zero it before the first
+ * level; it keeps counting past cand_cap, entries beyond cand_cap are dropped, so size
+ * cand_cap = M_total*C to make that impossible).  scale_x_y / iou_aware_factor are
+ * doubles because the reference derives fp32 constants from Python doubles
+ * ((scale_x_y - 1.0) * 0.5, 1 - iou_aware_factor; model/head.py:40, :125).
+ * scores_dense: optional [N][M_total][C] (reference layout) or NULL. */
+int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A, int num_classes,
+                        const float *h_anchors_px, int downsample, double scale_x_y,
+                        int iou_aware, double iou_aware_factor, int clip_bbox,
+                        const float *im_size, float *boxes, int M_total, int box_offset,
+                        float score_threshold, uint32_t *cand_key, uint32_t *cand_idx,
+                        int *cand_count, int cand_cap, float *scores_dense, void *stream);
+
+/* matrix_nms (reference model/matrix_nms.py:102-151) for a batch, from the candidate
+ * lists produced by ppy_yolo_decode_f32 / ppy_nms_candidates_f32.
+ * Order (this build's total order where the reference calls the unstable
+ * torch.argsort): score descending, ties by ascending candidate index.
+ * out_dets [N][keep_top_k][6] = (label, score, x0,y0,x1,y1), rows >= out_count[n] are
+ * -1; out_count[n] == 0 <=> the reference returns its [[-1]*6] sentinel.
+ * out_keep_idx [N][keep_top_k] = box*C + class of every kept row (-1 padding).
+ * Limits: 1 <= nms_top_k <= 1024, keep_top_k <= nms_top_k. */
+int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_classes, const uint32_t *cand_key,
+                       const uint32_t *cand_idx, const int *cand_count, int cand_cap, int N,
+                       float post_threshold, int nms_top_k, int keep_top_k, int use_gaussian,
+                       float gaussian_sigma, float *out_dets, int *out_count, int *out_keep_idx,
+                       void *stream);
+/* Candidate extraction from dense scores [N][M][C] (the reference's own input form,
+ * model/matrix_nms.py:110-117), for callers that hold yolo_box outputs. */
+int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, float score_threshold,
+                           uint32_t *cand_key, uint32_t *cand_idx, int *cand_count, int cand_cap,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPYOLO_HIP_H_ */

@@ -1,0 +1,47 @@
+"""`PPYOLO` -- drop-in for the reference's `model.ppyolo.PPYOLO` (model/ppyolo.py:14-29).
+
+Same constructor and `forward(x, im_size, eval=True, ...)` signature and return type (a list
+with one `[K, 6]` tensor per image: label, score, x0, y0, x1, y1; `[[-1]*6]` when nothing is
+detected).  The forward runs the MI355X plan (hand-written HIP kernels behind the C ABI);
+torch tensors are storage only.  There is no CPU fallback: CPU inputs raise.
+"""
+import torch
+
+from ppyolo_hip.runtime import PlanCache
+
+
+class PPYOLO(torch.nn.Module):
+    def __init__(self, backbone, head):
+        super(PPYOLO, self).__init__()
+        self.backbone = backbone
+        self.head = head
+        self._plans = PlanCache(self)
+
+    def forward(self, x, im_size, eval=True, gt_box=None, gt_label=None, gt_score=None, targets=None):
+        if not eval:
+            raise NotImplementedError('training forward (get_loss) is outside the inference hot path')
+        ex = self._plans.executor(x)
+        ex.set_inputs(x, im_size)
+        ex.run()
+        return self._plans.unpack(ex)
+
+    def forward_padded(self, x, im_size):
+        """Device-resident result without the host sync `forward` needs to build its
+        variable-length list: (dets [N,keep_top_k,6] padded with -1, count [N] int32,
+        keep_idx [N,keep_top_k] int32 = box*num_classes + class)."""
+        ex = self._plans.executor(x)
+        ex.set_inputs(x, im_size)
+        ex.run()
+        return ex.out_dets, ex.out_count, ex.out_keep
+
+    # any change of parameters / device invalidates the folded weights held by the plans
+    def load_state_dict(self, *a, **k):
+        r = super(PPYOLO, self).load_state_dict(*a, **k)
+        self._plans.clear()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super(PPYOLO, self)._apply(fn, *a, **k)
+        if hasattr(self, '_plans'):
+            self._plans.clear()
+        return r

@@ -1,0 +1,76 @@
+"""ctypes binding of libppyolo_hip.so (the C ABI declared in include/ppyolo_hip.h).
+
+`cffi` is not installed in this image, so the thin C-ABI layer is
+bound with the stdlib.  There is NO fallback: if the shared library is missing the
+import of any op raises, and every call checks the C return code.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libppyolo_hip.so')
+
+OK = 0
+ACT = {None: 0, 'relu': 1, 'leaky': 2}
+
+
+class PPYoloHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PROTOS = {
+    'ppy_version': (c_int, []),
+    'ppy_error_string': (ctypes.c_char_p, [c_int]),
+    'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_int] + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
+    'ppy_conv2d_num_configs': (c_int, []),
+    'ppy_conv2d_pick': (c_int, [c_int] * 9 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'ppy_stem_conv3x3s2_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ppy_maxpool3x3s2_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ppy_avgpool2x2_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ppy_spp_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p]),
+    'ppy_dcnv2_sample_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p]),
+    'ppy_dcnv2_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
+                      + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_dcnv2_workspace_bytes': (c_size_t, [c_int] * 9),
+    'ppy_yolo_decode_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), c_int,
+                                    c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'ppy_matrix_nms_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ppy_nms_candidates_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/ppyolo_hip.h declares."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PPYoloHipError(
+                'libppyolo_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` (hipcc, gfx950). There is no CPU / PyTorch fallback for the HIP path.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = lib().ppy_error_string(rc).decode()
+        raise PPYoloHipError('%s failed: %s (code %d)' % (what or 'libppyolo_hip call', msg, rc))

@@ -1,0 +1,232 @@
+// Stem conv (NCHW -> NHWC) and the pooling kernels of the PP-YOLO backbone / SPP.
+// All HBM/L2-bound: 16-byte coalesced NHWC accesses, no MFMA.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// stage1_conv1_1 (reference model/resnet_vd.py:100): 3x3 s2 p1 conv, 3 -> K channels, reading
+// the caller's NCHW tensor.  One thread = one output pixel x KT channels; the 27 input taps are
+// held in registers, the 27*KT weights come through the scalar cache (uniform addresses).
+// K-sum order: (c, r, s) ascending, fp32 fma chain.
+template <int KT>
+__global__ void __launch_bounds__(256) stem_conv_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ w,
+                                                        const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, float *y,
+                                                        int y_ld, int N, int H, int W, int Ho, int Wo,
+                                                        int K, int act) {
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * Ho * Wo;
+    if (pix >= total) return;
+    const int k0 = blockIdx.y * KT;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+                float v = 0.f;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v = x[(((long long)n * 3 + c) * H + hi) * W + wi];
+                in[c * 9 + r * 3 + s] = v;
+            }
+    float *o = y + pix * y_ld + k0;
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 4) {
+        floatx4 r4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + kk + u;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) acc = fmaf(in[t], w[k * 27 + t], acc);
+            r4[u] = ppy_apply_act(fmaf(acc, scale[k], shift[k]), act);
+        }
+        *reinterpret_cast<floatx4 *>(o + kk) = r4;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MaxPool2d(3, 2, 1): implicit -inf padding == skip out-of-range taps.
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x, int x_ld,
+                                                           float *y, int y_ld, int N, int H, int W,
+                                                           int C4, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long pix = i / C4;
+        const int wo = (int)(pix % Wo);
+        const int ho = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long long)Wo * Ho));
+        floatx4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = wo * 2 - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const floatx4 v = *reinterpret_cast<const floatx4 *>(
+                    x + (((long long)n * H + hi) * W + wi) * x_ld + c4 * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = fmaxf(m[u], v[u]);
+            }
+        }
+        *reinterpret_cast<floatx4 *>(y + pix * y_ld + c4 * 4) = m;
+    }
+}
+
+// AvgPool2d(2, 2, 0): ((x00 + x01) + x10 + x11) / 4 in torch's accumulation order.
+__global__ void __launch_bounds__(256) avgpool2x2_kernel(const float *__restrict__ x, int x_ld,
+                                                         float *y, int y_ld, int N, int H, int W,
+                                                         int C4, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long pix = i / C4;
+        const int wo = (int)(pix % Wo);
+        const int ho = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long long)Wo * Ho));
+        const float *p = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * x_ld + c4 * 4;
+        const floatx4 a = *reinterpret_cast<const floatx4 *>(p);
+        const floatx4 b = *reinterpret_cast<const floatx4 *>(p + x_ld);
+        const floatx4 c = *reinterpret_cast<const floatx4 *>(p + (long long)W * x_ld);
+        const floatx4 d = *reinterpret_cast<const floatx4 *>(p + (long long)(W + 1) * x_ld);
+        floatx4 r;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = (((a[u] + b[u]) + c[u]) + d[u]) * 0.25f;
+        *reinterpret_cast<floatx4 *>(y + pix * y_ld + c4 * 4) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// SPP: max-pool 5 / 9 / 13 (stride 1, "same").  pool9 = pool5(pool5), pool13 = pool5(pool9)
+// (max is associative and the -inf border makes the cascade exact), each pool5 separable.
+// One workgroup = one image x CC channels; the H*W*CC tile and one temp live in LDS.
+constexpr int SPP_CC = 8;
+
+__device__ __forceinline__ void spp_pool5(const float *src, float *tmp, float *dst, int H, int W,
+                                          int tid, int nthr) {
+    const int total = H * W * SPP_CC;
+    for (int i = tid; i < total; i += nthr) {   // horizontal
+        const int c = i % SPP_CC, w = (i / SPP_CC) % W, h = i / (SPP_CC * W);
+        float m = -INFINITY;
+        for (int d = -2; d <= 2; ++d) {
+            const int ww = w + d;
+            if ((unsigned)ww < (unsigned)W) m = fmaxf(m, src[(h * W + ww) * SPP_CC + c]);
+        }
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += nthr) {   // vertical
+        const int c = i % SPP_CC, w = (i / SPP_CC) % W, h = i / (SPP_CC * W);
+        float m = -INFINITY;
+        for (int d = -2; d <= 2; ++d) {
+            const int hh = h + d;
+            if ((unsigned)hh < (unsigned)H) m = fmaxf(m, tmp[(hh * W + w) * SPP_CC + c]);
+        }
+        dst[i] = m;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) spp_kernel(const float *__restrict__ x, int x_ld, float *y5,
+                                                  float *y9, float *y13, int y_ld, int H, int W,
+                                                  int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int total = H * W * SPP_CC;
+    float *t0 = sm, *t1 = sm + total, *t2 = sm + 2 * total;
+    const int n = blockIdx.y, c0 = blockIdx.x * SPP_CC;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const long long img = (long long)n * H * W;
+    for (int i = tid; i < total; i += nthr) {
+        const int c = i % SPP_CC, pix = i / SPP_CC;
+        t0[i] = x[(img + pix) * x_ld + c0 + c];
+    }
+    __syncthreads();
+    float *outs[3] = {y5, y9, y13};
+    float *src = t0, *dst = t2;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        spp_pool5(src, t1, dst, H, W, tid, nthr);
+        for (int i = tid; i < total; i += nthr) {
+            const int c = i % SPP_CC, pix = i / SPP_CC;
+            outs[lvl][(img + pix) * y_ld + c0 + c] = dst[i];
+        }
+        float *t = src;
+        src = dst;
+        dst = t;
+        __syncthreads();
+    }
+}
+
+int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
+                                           const float *shift, float *y, int y_ld, int N, int H, int W,
+                                           int K, int act, void *stream) {
+    PPY_CHECK_ARG(x_nchw && w_kcrs && scale && shift && y);
+    PPY_CHECK_ARG(N > 0 && H > 0 && W > 0 && K > 0 && K % 16 == 0 && y_ld >= K && y_ld % 4 == 0);
+    PPY_CHECK_ARG(((uintptr_t)y & 15) == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo;
+    dim3 grid((unsigned)((total + 255) / 256), K / 16);
+    hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, w_kcrs, scale,
+                       shift, y, y_ld, N, H, W, Ho, Wo, K, act);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C,
+                                    void *stream) {
+    PPY_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
+    PPY_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                       y, y_ld, N, H, W, C / 4, Ho, Wo);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_avgpool2x2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C,
+                                  void *stream) {
+    PPY_CHECK_ARG(x && y && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0);
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
+    PPY_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                       y_ld, N, H, W, C / 4, Ho, Wo);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int y_ld, int N, int H,
+                           int W, int C, void *stream) {
+    PPY_CHECK_ARG(x && y5 && y9 && y13 && N > 0 && H > 0 && W > 0 && C > 0 && C % SPP_CC == 0);
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= C);
+    const size_t lds = (size_t)3 * H * W * SPP_CC * sizeof(float);
+    if (lds > 160 * 1024) return PPY_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(spp_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(spp_kernel, dim3(C / SPP_CC, N), dim3(256), lds, (hipStream_t)stream, x, x_ld, y5, y9,
+                       y13, y_ld, H, W, C);
+    return ppy_launch_status();
+}

@@ -1,0 +1,374 @@
+"""Plan builder + HIP executor for the PP-YOLO inference path.
+
+The reference executes `PPYOLO.forward` as ~1000 eager ATen calls (reference
+model/ppyolo.py:19-22 down to model/custom_layers.py:243-253).  Here the module tree is
+walked ONCE per input shape into a flat plan: a list of kernel launches over pre-allocated
+NHWC buffers, with BatchNorm folded to a per-channel affine, weights re-laid to KRSC, concats
+turned into channel slices of one wide buffer (producers write their slice in place),
+CoordConv turned into a precomputed per-position bias, nearest-x2 upsample fused into the
+producing conv's store, and the residual add + ReLU fused into the conv epilogue.  The plan
+is replayed with direct C-ABI calls on the current HIP stream, or as one captured hipGraph.
+
+A plan is pure data (`Plan.ops` dicts over buffer ids), so the host logic can be checked on
+a CPU-only box by interpreting the same plan with reference ops (tests/plan_interp.py);
+the product executor below has no CPU path.
+"""
+import collections
+
+import torch
+
+from . import ops as K
+from ._lib import PPYoloHipError
+
+A = collections.namedtuple('A', 'buf coff C N H W')   # activation: channel slice of a buffer
+
+
+def fold_bn(bn, bias, K_out, device):
+    """Eval-mode BatchNorm2d as y = x*scale + shift (torch computes alpha = weight*invstd,
+    beta = bias - mean*alpha on CPU); a conv bias without BN is scale=1, shift=bias."""
+    if bn is not None:
+        invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        scale = bn.weight.detach().float() * invstd
+        shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        if bias is not None:
+            shift = shift + bias.detach().float() * scale
+    else:
+        scale = torch.ones(K_out, dtype=torch.float32, device=device)
+        shift = bias.detach().float().clone() if bias is not None else torch.zeros(K_out, dtype=torch.float32,
+                                                                                   device=device)
+    return scale.contiguous(), shift.contiguous()
+
+
+class Plan(object):
+    def __init__(self, N, H, W):
+        self.N, self.H, self.W = N, H, W
+        self.buffers = []        # (N, H, W, ld)
+        self.setup_ops = []      # run once after buffers are bound (CoordConv bias maps)
+        self.ops = []            # run every forward
+        self.consts = {}         # buffer id -> tensor to preload (coord grids)
+        self.feats = []          # backbone feature maps (A), for per-stage checks
+        self.head_outs = []      # raw head outputs (A)
+        self.decode = None       # decode / NMS parameters
+
+
+class Builder(object):
+    def __init__(self, N, H, W, device):
+        self.plan = Plan(N, H, W)
+        self.device = device
+        self._coord_cache = {}
+
+    # ---- buffers -------------------------------------------------------------------------
+    def new_buf(self, N, H, W, ld):
+        self.plan.buffers.append((N, H, W, ld))
+        return len(self.plan.buffers) - 1
+
+    def new_act(self, N, H, W, C):
+        return A(self.new_buf(N, H, W, C), 0, C, N, H, W)
+
+    def slice(self, a, coff, C):
+        return A(a.buf, a.coff + coff, C, a.N, a.H, a.W)
+
+    def _emit(self, op, setup=False):
+        (self.plan.setup_ops if setup else self.plan.ops).append(op)
+
+    # ---- ops -----------------------------------------------------------------------------
+    def stem(self, weight, scale, shift, act='relu'):
+        p = self.plan
+        Ho, Wo = K.conv_out_hw(p.H, p.W, 3, 3, 2, 1)
+        y = self.new_act(p.N, Ho, Wo, weight.shape[0])
+        self._emit(dict(op='stem', y=y, w=weight.detach().float().contiguous(), scale=scale, shift=shift, act=act))
+        return y
+
+    def conv(self, x, weight, scale, shift, stride=1, act=None, res=None, out=None, ups=False, coord=False,
+             setup=False):
+        """weight: [K, C(+2 if coord), R, S] in the reference's KCRS layout."""
+        Kout, Cin, R, S = weight.shape
+        pad = (R - 1) // 2
+        w = weight.detach().float()
+        posb = None
+        if coord:
+            assert Cin == x.C + 2
+            posb = self._coord_bias(w[:, x.C:], x.H, x.W, stride, pad)
+            w = w[:, :x.C]
+        else:
+            assert Cin == x.C, (Cin, x.C)
+        w_krsc = w.permute(0, 2, 3, 1).contiguous()
+        Ho, Wo = K.conv_out_hw(x.H, x.W, R, S, stride, pad)
+        if out is None:
+            out = self.new_act(x.N, Ho * (2 if ups else 1), Wo * (2 if ups else 1), Kout)
+        assert out.C == Kout and out.H == Ho * (2 if ups else 1) and out.W == Wo * (2 if ups else 1)
+        if res is not None:
+            assert (res.C, res.H, res.W) == (Kout, Ho, Wo)
+        self._emit(dict(op='conv', x=x, y=out, w=w_krsc, scale=scale, shift=shift, stride=stride, pad=pad, act=act,
+                        res=res, posb=posb, ups=ups, cfg=-1, splitk=0), setup)
+        return out
+
+    def _coord_bias(self, w_coord, H, W, stride, pad):
+        """Contribution of CoordConv's two appended channels (reference
+        model/custom_layers.py:261-272: x_range then y_range, each in [-1,1]) to the following
+        conv.  It does not depend on the image, so it is computed ONCE per plan by running the
+        conv kernel itself over the coordinate grid (channels padded 2 -> 32) and then added as
+        a per-position bias [Ho*Wo][K] in the epilogue of the real conv."""
+        key = (H, W)
+        if key not in self._coord_cache:
+            g = self.new_act(1, H, W, 32)
+            grid = torch.zeros((1, H, W, 32), dtype=torch.float32, device=self.device)
+            xr = torch.arange(0, W, dtype=torch.float32, device=self.device) / (W - 1) * 2.0 - 1
+            yr = torch.arange(0, H, dtype=torch.float32, device=self.device) / (H - 1) * 2.0 - 1
+            grid[0, :, :, 0] = xr.view(1, W)
+            grid[0, :, :, 1] = yr.view(H, 1)
+            self.plan.consts[g.buf] = grid
+            self._coord_cache[key] = g
+        g = self._coord_cache[key]
+        Kout, two, R, S = w_coord.shape
+        w32 = torch.zeros((Kout, 32, R, S), dtype=torch.float32, device=self.device)
+        w32[:, :2] = w_coord
+        one = torch.ones(Kout, dtype=torch.float32, device=self.device)
+        zero = torch.zeros(Kout, dtype=torch.float32, device=self.device)
+        out = self.conv(g, w32, one, zero, stride=stride, act=None, setup=True)
+        return out          # A of shape [1,Ho,Wo,K]; bound to its tensor by the executor
+
+    def maxpool(self, x):
+        Ho, Wo = K.conv_out_hw(x.H, x.W, 3, 3, 2, 1)
+        y = self.new_act(x.N, Ho, Wo, x.C)
+        self._emit(dict(op='maxpool', x=x, y=y))
+        return y
+
+    def avgpool(self, x):
+        y = self.new_act(x.N, x.H // 2, x.W // 2, x.C)
+        self._emit(dict(op='avgpool', x=x, y=y))
+        return y
+
+    def spp(self, x_slot0):
+        """x_slot0: slice [0,C) of a [N,H,W,4C] buffer; fills slices 1..3 with pool 5/9/13."""
+        C = x_slot0.C
+        ys = [self.slice(x_slot0, C * i, C) for i in (1, 2, 3)]
+        self._emit(dict(op='spp', x=x_slot0, y5=ys[0], y9=ys[1], y13=ys[2]))
+        return A(x_slot0.buf, x_slot0.coff, 4 * C, x_slot0.N, x_slot0.H, x_slot0.W)
+
+    def dcn(self, x, om, weight, scale, shift, stride, act):
+        Kout = weight.shape[0]
+        w_krsc = weight.detach().float().permute(0, 2, 3, 1).contiguous()
+        Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
+        assert (om.H, om.W, om.C) == (Ho, Wo, 27)
+        y = self.new_act(x.N, Ho, Wo, Kout)
+        self._emit(dict(op='dcn', x=x, om=om, y=y, w=w_krsc, scale=scale, shift=shift, stride=stride, pad=1, act=act,
+                        cfg=-1, splitk=0))
+        return y
+
+
+# =========================================================================================
+class HipExecutor(object):
+    """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
+
+    def __init__(self, plan, device, use_graph=True):
+        if torch.device(device).type != 'cuda':
+            raise PPYoloHipError('the HIP executor needs a ROCm device (got %s); there is no CPU path' % device)
+        self.plan = plan
+        self.device = torch.device(device)
+        self.use_graph = use_graph
+        self.graph = None
+        p = plan
+        self.bufs = []
+        for i, (N, H, W, ld) in enumerate(p.buffers):
+            if i in p.consts:
+                self.bufs.append(p.consts[i].to(self.device).contiguous())
+            else:
+                self.bufs.append(torch.empty((N, H, W, ld), dtype=torch.float32, device=self.device))
+        self.x_in = torch.zeros((p.N, 3, p.H, p.W), dtype=torch.float32, device=self.device)
+        self.im_size = torch.zeros((p.N, 2), dtype=torch.float32, device=self.device)
+        d = p.decode
+        if d is not None:
+            M, C = d['M_total'], d['num_classes']
+            self.boxes = torch.zeros((p.N, M, 4), dtype=torch.float32, device=self.device)
+            cap = M * C
+            self.cand_key = torch.zeros((p.N, cap), dtype=torch.int32, device=self.device)
+            self.cand_idx = torch.zeros((p.N, cap), dtype=torch.int32, device=self.device)
+            self.cand_count = torch.zeros((p.N,), dtype=torch.int32, device=self.device)
+            kk = d['nms']['keep_top_k']
+            self.out_dets = torch.zeros((p.N, kk, 6), dtype=torch.float32, device=self.device)
+            self.out_count = torch.zeros((p.N,), dtype=torch.int32, device=self.device)
+            self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
+        self._to_device(p.setup_ops)
+        self._to_device(p.ops)
+        self.ws = None
+        self._size_workspace()
+        with torch.cuda.device(self.device):
+            for op in p.setup_ops:
+                self._run_op(op)
+            torch.cuda.synchronize()
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _to_device(self, oplist):
+        for op in oplist:
+            for k in ('w', 'scale', 'shift'):
+                if k in op and op[k] is not None:
+                    op[k] = op[k].to(self.device).contiguous()
+
+    def view(self, a):
+        return K.View(self.bufs[a.buf], a.coff, a.C)
+
+    def _ws_need(self, op):
+        if op['op'] == 'conv':
+            x = op['x']
+            Kout, R, S, C = op['w'].shape
+            return K.conv2d_workspace_bytes(x.N, x.H, x.W, C, Kout, R, S, op['stride'], op['pad'], op['cfg'],
+                                            op['splitk'])
+        if op['op'] == 'dcn':
+            x = op['x']
+            return K.dcnv2_workspace_bytes(x.N, x.H, x.W, x.C, op['w'].shape[0], op['stride'], op['pad'], op['cfg'],
+                                           op['splitk'])
+        return 0
+
+    def _size_workspace(self):
+        need = 16
+        for op in self.plan.setup_ops + self.plan.ops:
+            need = max(need, self._ws_need(op))
+        if self.ws is None or self.ws.numel() * 4 < need:
+            self.ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+
+    def _run_op(self, op):
+        t = op['op']
+        if t == 'conv':
+            posb = op['posb']
+            K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
+                            op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
+                            None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
+                            self.ws)
+        elif t == 'stem':
+            K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
+        elif t == 'maxpool':
+            K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
+        elif t == 'avgpool':
+            K.avgpool2x2(self.view(op['x']), self.view(op['y']))
+        elif t == 'spp':
+            K.spp(self.view(op['x']), self.view(op['y5']), self.view(op['y9']), self.view(op['y13']))
+        elif t == 'dcn':
+            K.dcnv2(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['om']), self.view(op['y']),
+                    op['stride'], op['pad'], op['act'], self.ws, op['cfg'], op['splitk'])
+        else:
+            raise PPYoloHipError('unknown plan op %r' % t)
+
+    def _run_decode(self):
+        d = self.plan.decode
+        self.cand_count.zero_()
+        off = 0
+        for lvl, a in zip(d['levels'], self.plan.head_outs):
+            K.yolo_decode(self.view(a), lvl['anchors'], lvl['downsample'], d['num_classes'], d['scale_x_y'],
+                          d['iou_aware'], d['iou_aware_factor'], d['clip_bbox'], self.im_size, self.boxes, off,
+                          d['nms']['score_threshold'], self.cand_key, self.cand_idx, self.cand_count)
+            off += a.H * a.W * len(lvl['anchors'])
+        n = d['nms']
+        K.matrix_nms(self.boxes, d['num_classes'], self.cand_key, self.cand_idx, self.cand_count,
+                     n['post_threshold'], n['nms_top_k'], n['keep_top_k'], n['use_gaussian'], n['gaussian_sigma'],
+                     self.out_dets, self.out_count, self.out_keep)
+
+    def _launch_all(self):
+        for op in self.plan.ops:
+            self._run_op(op)
+        if self.plan.decode is not None:
+            self._run_decode()
+
+    # ---- public ----------------------------------------------------------------------------
+    def set_inputs(self, x, im_size=None):
+        if tuple(x.shape) != tuple(self.x_in.shape):
+            raise PPYoloHipError('plan was built for input %s, got %s' % (tuple(self.x_in.shape), tuple(x.shape)))
+        self.x_in.copy_(x)
+        if im_size is not None:
+            self.im_size.copy_(im_size.to(torch.float32))
+
+    def run(self):
+        """Enqueue one forward on the current stream (device-resident in -> device-resident out)."""
+        with torch.cuda.device(self.device):
+            if not self.use_graph:
+                self._launch_all()
+                return
+            if self.graph is None:
+                self._launch_all()                      # warm-up: module load, func attributes
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_all()
+                self.graph = g
+            self.graph.replay()
+
+    def invalidate_graph(self):
+        self.graph = None
+
+    # ---- autotune --------------------------------------------------------------------------
+    def autotune(self, iters=3, verbose=False):
+        """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
+        guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
+        from ._lib import lib
+        ncfg = lib().ppy_conv2d_num_configs()
+        splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
+        report = []
+        with torch.cuda.device(self.device):
+            big = 0
+            for op in self.plan.ops:
+                if op['op'] in ('conv', 'dcn'):
+                    for c in range(ncfg):
+                        for s in splits:
+                            o = dict(op, cfg=c, splitk=s)
+                            big = max(big, self._ws_need(o))
+            if self.ws.numel() * 4 < big:
+                self.ws = torch.empty(((big + 3) // 4,), dtype=torch.float32, device=self.device)
+            for op in self.plan.ops:
+                if op['op'] not in ('conv', 'dcn'):
+                    continue
+                Kout = op['w'].shape[0]
+                Kred = op['w'].shape[1] * op['w'].shape[2] * op['w'].shape[3]
+                chunks = Kred // 32
+                best = None
+                base_cfg, base_split = op['cfg'], op['splitk']
+                for c in range(ncfg):
+                    for s in splits:
+                        if s > 1 and chunks // s < 4:
+                            continue
+                        op['cfg'], op['splitk'] = c, s
+                        try:
+                            self._run_op(op)
+                        except PPYoloHipError:
+                            continue
+                        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        st.record()
+                        for _ in range(iters):
+                            self._run_op(op)
+                        en.record()
+                        en.synchronize()
+                        ms = st.elapsed_time(en) / iters
+                        if best is None or ms < best[0]:
+                            best = (ms, c, s)
+                if best is None:
+                    op['cfg'], op['splitk'] = base_cfg, base_split
+                    continue
+                op['cfg'], op['splitk'] = best[1], best[2]
+                report.append((op['op'], tuple(op['w'].shape), op['x'].H, best))
+                if verbose:
+                    print('autotune %s w=%s H=%d -> cfg %d split %d  %.3f ms' % (op['op'], tuple(op['w'].shape),
+                                                                               op['x'].H, best[1], best[2], best[0]))
+        self._size_workspace()
+        self.graph = None
+        return report
+
+
+def run_single(unit, x_nchw):
+    """Run ONE Conv2dUnit through the HIP kernels on an NCHW tensor (layout conversion by torch
+    is test / API glue, not part of the timed path)."""
+    if not x_nchw.is_cuda:
+        raise PPYoloHipError('HIP path needs a ROCm device tensor; there is no CPU fallback')
+    N, C, H, W = x_nchw.shape
+    b = Builder(N, H, W, x_nchw.device)
+    xin = None
+    if C == 3 and unit.stride == 2:
+        y = unit.emit(b, None)
+    else:
+        xin = b.new_act(N, H, W, C)
+        y = unit.emit(b, xin)
+    ex = HipExecutor(b.plan, x_nchw.device, use_graph=False)
+    if xin is None:
+        ex.set_inputs(x_nchw.float())
+    else:
+        ex.bufs[xin.buf].copy_(x_nchw.float().permute(0, 2, 3, 1))
+    ex.run()
+    return ex.view(y).dense().permute(0, 3, 1, 2).contiguous()

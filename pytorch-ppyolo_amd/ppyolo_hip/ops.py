@@ -1,0 +1,180 @@
+"""Tensor-level wrappers over the C ABI (include/ppyolo_hip.h).
+
+PyTorch-ROCm tensors are backing storage only: every function takes fp32 NHWC tensors
+that live on a ROCm device, passes `data_ptr()`s and the current HIP stream to
+libppyolo_hip.so and returns.  No function here computes anything with torch ops and
+none has a CPU path -- a CPU tensor raises.
+
+A "view" is (tensor, channel_offset, channels): channel slice [off, off+C) of an NHWC
+buffer whose last dimension is the pixel stride `ld`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT, check, lib
+
+
+class View(object):
+    """Channel slice [coff, coff+C) of an NHWC fp32 buffer [N,H,W,ld]."""
+    __slots__ = ('t', 'coff', 'C')
+
+    def __init__(self, t, coff=0, C=None):
+        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous()
+        self.t = t
+        self.coff = coff
+        self.C = t.shape[3] - coff if C is None else C
+        assert 0 <= coff and coff + self.C <= t.shape[3]
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    @property
+    def ld(self):
+        return self.t.shape[3]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.coff
+
+    def dense(self):
+        """Contiguous [N,H,W,C] copy of the slice (tests / API glue)."""
+        return self.t[..., self.coff:self.coff + self.C].contiguous()
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PPYoloHipError('HIP path needs ROCm device tensors; got a %s tensor (no CPU fallback)'
+                                      % t.device)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv2d_workspace_bytes(N, H, W, C, K, R, S, stride, pad, cfg=-1, splitk=0):
+    return int(lib().ppy_conv2d_workspace_bytes(N, H, W, C, K, R, S, stride, pad, cfg, splitk))
+
+
+def conv2d_pick(N, H, W, C, K, R, S, stride, pad):
+    c, s = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().ppy_conv2d_pick(N, H, W, C, K, R, S, stride, pad, ctypes.byref(c), ctypes.byref(s)), 'conv2d_pick')
+    return c.value, s.value
+
+
+def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residual=None, posbias=None,
+                  upsample2x=False, cfg=-1, splitk=0, ws=None):
+    """x, y, residual: View.  w_krsc: [K,R,S,C].  See ppy_conv2d_bn_act_f32."""
+    _dev(x.t, w_krsc, scale, shift, y.t)
+    K, R, S, C = w_krsc.shape
+    assert C == x.C and K == y.C and w_krsc.is_contiguous()
+    rc = lib().ppy_conv2d_bn_act_f32(
+        x.ptr, x.ld, w_krsc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+        None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
+        _p(posbias), y.ptr, y.ld, x.N, x.H, x.W, C, K, R, S, stride, pad, ACT[act], int(bool(upsample2x)),
+        cfg, splitk, _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream())
+    check(rc, 'ppy_conv2d_bn_act_f32')
+
+
+def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu'):
+    _dev(x_nchw, w_kcrs, scale, shift, y.t)
+    N, C, H, W = x_nchw.shape
+    assert C == 3 and x_nchw.is_contiguous() and w_kcrs.is_contiguous() and tuple(w_kcrs.shape[1:]) == (3, 3, 3)
+    check(lib().ppy_stem_conv3x3s2_nchw_f32(x_nchw.data_ptr(), w_kcrs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            y.ptr, y.ld, N, H, W, w_kcrs.shape[0], ACT[act], _stream()),
+          'ppy_stem_conv3x3s2_nchw_f32')
+
+
+def maxpool3x3s2(x, y):
+    _dev(x.t, y.t)
+    check(lib().ppy_maxpool3x3s2_f32(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_maxpool3x3s2_f32')
+
+
+def avgpool2x2(x, y):
+    _dev(x.t, y.t)
+    check(lib().ppy_avgpool2x2_f32(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_avgpool2x2_f32')
+
+
+def spp(x, y5, y9, y13):
+    _dev(x.t, y5.t)
+    assert y5.ld == y9.ld == y13.ld
+    check(lib().ppy_spp_f32(x.ptr, x.ld, y5.ptr, y9.ptr, y13.ptr, y5.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_spp_f32')
+
+
+def dcn_out_hw(H, W, stride, pad):
+    # reference model/custom_layers.py:567-568
+    return (H + 2 * pad - 2) // stride, (W + 2 * pad - 2) // stride
+
+
+def dcnv2_sample(x, offset_mask, cols, stride, pad):
+    _dev(x.t, offset_mask.t, cols)
+    Ho, Wo = offset_mask.H, offset_mask.W
+    check(lib().ppy_dcnv2_sample_f32(x.ptr, x.ld, offset_mask.ptr, offset_mask.ld, cols.data_ptr(), x.N, x.H, x.W,
+                                     x.C, Ho, Wo, stride, pad, _stream()), 'ppy_dcnv2_sample_f32')
+
+
+def dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg=-1, splitk=0):
+    return int(lib().ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
+
+
+def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1, splitk=0):
+    _dev(x.t, w_krsc, offset_mask.t, y.t, ws)
+    K = w_krsc.shape[0]
+    check(lib().ppy_dcnv2_f32(x.ptr, x.ld, w_krsc.data_ptr(), scale.data_ptr(), shift.data_ptr(), offset_mask.ptr,
+                              offset_mask.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, K, stride, pad, ACT[act], cfg, splitk,
+                              ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_f32')
+
+
+def yolo_decode(head_out, anchors_px, downsample, num_classes, scale_x_y, iou_aware, iou_aware_factor, clip_bbox,
+                im_size, boxes, box_offset, score_threshold, cand_key, cand_idx, cand_count, scores_dense=None):
+    """head_out: View [N,S,S,nch]; boxes [N,M,4]; cand_* [N,cap] int32-storage; cand_count [N] int32."""
+    _dev(head_out.t, im_size, boxes, cand_key, cand_idx, cand_count, scores_dense)
+    A = len(anchors_px)
+    flat = [float(v) for a in anchors_px for v in a]
+    arr = (ctypes.c_float * len(flat))(*flat)
+    assert head_out.H == head_out.W
+    check(lib().ppy_yolo_decode_f32(head_out.ptr, head_out.ld, head_out.N, head_out.H, A, num_classes, arr,
+                                    int(downsample), float(scale_x_y), int(bool(iou_aware)), float(iou_aware_factor),
+                                    int(bool(clip_bbox)), im_size.data_ptr(), boxes.data_ptr(), boxes.shape[1],
+                                    int(box_offset), float(score_threshold), cand_key.data_ptr(), cand_idx.data_ptr(),
+                                    cand_count.data_ptr(), cand_key.shape[1], _p(scores_dense), _stream()),
+          'ppy_yolo_decode_f32')
+
+
+def nms_candidates(scores, score_threshold, cand_key, cand_idx, cand_count):
+    _dev(scores, cand_key, cand_idx, cand_count)
+    N, M, C = scores.shape
+    assert scores.is_contiguous()
+    check(lib().ppy_nms_candidates_f32(scores.data_ptr(), N, M, C, float(score_threshold), cand_key.data_ptr(),
+                                       cand_idx.data_ptr(), cand_count.data_ptr(), cand_key.shape[1], _stream()),
+          'ppy_nms_candidates_f32')
+
+
+def matrix_nms(boxes, num_classes, cand_key, cand_idx, cand_count, post_threshold, nms_top_k, keep_top_k,
+               use_gaussian, gaussian_sigma, out_dets, out_count, out_keep):
+    _dev(boxes, cand_key, cand_idx, cand_count, out_dets, out_count, out_keep)
+    N, M, _ = boxes.shape
+    check(lib().ppy_matrix_nms_f32(boxes.data_ptr(), M, num_classes, cand_key.data_ptr(), cand_idx.data_ptr(),
+                                   cand_count.data_ptr(), cand_key.shape[1], N, float(post_threshold),
+                                   int(nms_top_k), int(keep_top_k), int(bool(use_gaussian)), float(gaussian_sigma),
+                                   out_dets.data_ptr(), out_count.data_ptr(), out_keep.data_ptr(), _stream()),
+          'ppy_matrix_nms_f32')

@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'pytorch-ppyolo_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def _load(name):
+        return np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+    return _load
+
+
+def build_model(cfg, seed=0, device='cpu'):
+    """This package's PPYOLO with the deterministic synthetic weights (same tensors the
+    goldens were generated with)."""
+    import torch
+    from config import select_backbone, select_head
+    from model.ppyolo import PPYOLO
+    from ppyolo_hip import synth
+    bb = select_backbone(cfg.backbone_type)(**cfg.backbone)
+    hd = select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=seed)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    hd.set_dropblock(is_test=True)
+    if device != 'cpu':
+        m = m.to(device)
+    return m, sd
+
+
+@pytest.fixture(scope='session')
+def model_shapes():
+    def _shapes(cfg):
+        from config import select_backbone, select_head
+        from model.ppyolo import PPYOLO
+        bb = select_backbone(cfg.backbone_type)(**cfg.backbone)
+        hd = select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
+        return {k: tuple(v.shape) for k, v in PPYOLO(bb, hd).state_dict().items()}
+    return _shapes

@@ -1,0 +1,107 @@
+"""Pin the CPU oracle (oracle/ppyolo_oracle.py) against fixtures produced by the
+reference itself (tools/make_goldens.py).  Same ATen ops in the same order -> the
+oracle is expected to be BIT-EXACT on this torch build; a tiny tolerance is allowed
+only where the oracle deliberately restructures the arithmetic (none today)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppyolo_oracle as orc
+from ppyolo_hip import synth
+from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+
+ACTS = {0: None, 1: 'relu', 2: 'leaky'}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_g1_conv_units(golden):
+    g = golden('g1_conv_units')
+    for i in range(int(g['ncases'])):
+        p = 'c%d_' % i
+        ci, co, k, s, act, bn, bias = [int(v) for v in g[p + 'meta']]
+        sd = {'u.conv.weight': T(g[p + 'w'])}
+        if bias:
+            sd['u.conv.bias'] = T(g[p + 'b'])
+        if bn:
+            b = T(g[p + 'bn'])
+            sd.update({'u.bn.weight': b[0], 'u.bn.bias': b[1], 'u.bn.running_mean': b[2],
+                       'u.bn.running_var': b[3]})
+        y = orc.conv_unit(sd, 'u', T(g[p + 'x']), s, ACTS[act])
+        assert torch.equal(y, T(g[p + 'y'])), i
+
+
+def test_g2_dcnv2(golden):
+    g = golden('g2_dcnv2')
+    for i in range(int(g['ncases'])):
+        p = 'd%d_' % i
+        ci, co, s = [int(v) for v in g[p + 'meta']]
+        sd = {'d.dcn_weight': T(g[p + 'w_dcn']), 'd.conv_offset.weight': T(g[p + 'w_off']),
+              'd.conv_offset.bias': T(g[p + 'b_off'])}
+        y = orc.dcnv2(sd, 'd', T(g[p + 'x']), stride=s)
+        assert torch.equal(y, T(g[p + 'y'])), i
+        # second oracle: explicit per-corner bounds checks (reference DCNv2_Slow)
+        assert (y - T(g[p + 'y_slow'])).abs().max() < 5e-5
+
+
+def test_g3_coord_spp(golden):
+    g = golden('g3_coord_spp')
+    assert torch.equal(orc.coord_concat(T(g['coord_x'])), T(g['coord_y']))
+    for i in range(3):
+        assert torch.equal(orc.spp(T(g['spp%d_x' % i])), T(g['spp%d_y' % i]))
+
+
+def test_g4_decode(golden):
+    g = golden('g4_decode')
+    anchors = g['anchors']
+    im_size = T(g['im_size'])
+    for i in range(3):
+        meta = [int(v) for v in g['l%d_meta' % i]]
+        S, stride, iou_aware, mask = meta[0], meta[1], meta[2], meta[3:]
+        o = T(g['l%d_out' % i])
+        if iou_aware:
+            o = orc.iou_aware_score(o, 3, 80, 0.4)
+        b, s = orc.yolo_box(o, anchors[mask], stride, 80, 1.05, im_size, True)
+        assert torch.equal(b, T(g['l%d_boxes' % i]))
+        assert torch.equal(s, T(g['l%d_scores' % i]))
+        # -0.0 from the `x0 * 0` clip is preserved
+        assert np.array_equal(np.signbit(b.numpy()), np.signbit(g['l%d_boxes' % i]))
+
+
+def test_g5_matrix_nms(golden):
+    g = golden('g5_matrix_nms')
+    for i in range(int(g['ncases'])):
+        c = g['n%d_cfg' % i]
+        pred = orc.matrix_nms(T(g['n%d_boxes' % i]), T(g['n%d_scores' % i]), float(np.float32(c[0])),
+                              float(np.float32(c[1])), int(c[2]), int(c[3]), bool(c[4]), float(c[5]))
+        ref = T(g['n%d_pred' % i])
+        assert pred.shape == ref.shape, i
+        assert torch.equal(pred, ref), i
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_64', PPYOLO_r18vd_Config), ('r50vd_96', PPYOLO_2x_Config)])
+def test_g6_backbone_head(golden, tag, cfgc, model_shapes):
+    g = golden('g6_' + tag)
+    S, N, seed, iseed = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    sd = synth.synth_state_dict(model_shapes(cfg), seed=seed)
+    feats, outs = orc.backbone_and_head(sd, cfg, synth.synth_images(N, S, seed=iseed))
+    for i, f in enumerate(feats):
+        assert torch.equal(f, T(g['feat%d' % i]))
+    for i, o in enumerate(outs):
+        assert torch.equal(o, T(g['out%d' % i]))
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_320', PPYOLO_r18vd_Config), ('r50vd_160', PPYOLO_2x_Config)])
+def test_g7_end_to_end(golden, tag, cfgc, model_shapes):
+    g = golden('g7_' + tag)
+    S, N, seed, iseed = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    sd = synth.synth_state_dict(model_shapes(cfg), seed=seed)
+    preds = orc.ppyolo_forward(sd, cfg, synth.synth_images(N, S, seed=iseed), T(g['im_size']))
+    for i, p in enumerate(preds):
+        ref = T(g['pred%d' % i])
+        assert p.shape == ref.shape
+        assert torch.equal(p, ref)

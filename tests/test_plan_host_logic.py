@@ -1,0 +1,75 @@
+"""Host-side logic of the product, checked on CPU: the plan the HIP executor replays
+(BN fold, KRSC weights, concat slices, CoordConv bias maps, fused residual / upsample, DCN
+column order, decode parameters) is interpreted with reference ops (tests/plan_interp.py) and
+must reproduce the oracle and the reference-generated goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_model
+from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+from oracle import ppyolo_oracle as orc
+from plan_interp import CpuPlanRunner
+from ppyolo_hip import synth
+from ppyolo_hip.runtime import build_plan
+
+TOL = 2e-4   # BN folded into scale/shift + coord terms summed separately -> fp32 roundoff only
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_64', PPYOLO_r18vd_Config), ('r50vd_96', PPYOLO_2x_Config)])
+def test_plan_matches_golden_features(golden, tag, cfgc):
+    g = golden('g6_' + tag)
+    S, N, seed, iseed = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    model, sd = build_model(cfg, seed)
+    plan = build_plan(model, N, S, S, 'cpu')
+    feats, outs, _ = CpuPlanRunner(plan).run(synth.synth_images(N, S, seed=iseed))
+    for i, f in enumerate(feats):
+        ref = torch.from_numpy(g['feat%d' % i])
+        assert f.shape == ref.shape
+        assert (f - ref).abs().max() <= TOL * max(1.0, ref.abs().max().item()), (tag, 'feat', i)
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(g['out%d' % i])
+        assert (o - ref).abs().max() <= TOL * max(1.0, ref.abs().max().item()), (tag, 'out', i)
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_320', PPYOLO_r18vd_Config), ('r50vd_160', PPYOLO_2x_Config)])
+def test_plan_end_to_end_matches_golden(golden, tag, cfgc):
+    g = golden('g7_' + tag)
+    S, N, seed, iseed = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    model, sd = build_model(cfg, seed)
+    plan = build_plan(model, N, S, S, 'cpu')
+    im_size = torch.from_numpy(g['im_size'])
+    _, outs, preds = CpuPlanRunner(plan).run(synth.synth_images(N, S, seed=iseed), im_size)
+    for i, p in enumerate(preds):
+        ref = torch.from_numpy(g['pred%d' % i])
+        assert p.shape == ref.shape
+        assert torch.equal(p[:, 0], ref[:, 0])                         # labels, in order
+        assert (p[:, 1] - ref[:, 1]).abs().max() <= 1e-4               # scores
+        assert (p[:, 2:] - ref[:, 2:]).abs().max() <= 1e-3             # boxes (pixels)
+
+
+def test_plan_structure_r50():
+    cfg = PPYOLO_2x_Config()
+    model, _ = build_model(cfg)
+    plan = build_plan(model, 2, 160, 160, 'cpu')
+    kinds = [o['op'] for o in plan.ops]
+    assert kinds.count('conv') == 78 and kinds.count('dcn') == 3 and kinds.count('spp') == 1
+    assert kinds.count('stem') == 1 and kinds.count('maxpool') == 1 and kinds.count('avgpool') == 3
+    assert len(plan.setup_ops) == 12                # one CoordConv bias map per coord conv
+    # every conv reads a 32-channel-aligned, 16-byte aligned slice
+    for o in plan.ops:
+        if o['op'] == 'conv':
+            assert o['x'].C % 32 == 0 and o['x'].coff % 4 == 0
+    d = plan.decode
+    assert d['M_total'] == 3 * (5 * 5 + 10 * 10 + 20 * 20)
+    assert [len(l['anchors']) for l in d['levels']] == [3, 3, 3]
+    assert d['levels'][0]['anchors'][0] == [116.0, 90.0] and d['levels'][2]['downsample'] == 8
+
+
+def test_cpu_input_raises():
+    from ppyolo_hip._lib import PPYoloHipError
+    model, _ = build_model(PPYOLO_r18vd_Config())
+    with pytest.raises(PPYoloHipError):
+        model(torch.zeros(1, 3, 64, 64), torch.tensor([[64., 64.]]))

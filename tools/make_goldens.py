@@ -1,0 +1,366 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE implementation.
+
+Build-container only: imports miemie2013/Pytorch-PPYOLO from /root/reference (which
+never travels to the GPU box) with the recipe of SURVEY.md section 8c, feeds it this
+repo's deterministic synthetic weights / inputs, and stores inputs + expected outputs
+as small fixtures.  The fixtures are DATA (tensors); no reference source is stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py [--only g5]
+
+Every fixture whose result depends on a sort asserts that the sorted keys are
+pairwise distinct (torch's CPU argsort is not stable; SURVEY.md section 7 hard part 1).
+"""
+import argparse
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+synth = _load('ppy_synth', os.path.join(ROOT, 'pytorch-ppyolo_amd', 'ppyolo_hip', 'synth.py'))
+
+# --- reference import recipe ------------------------------------
+sys.path.insert(0, REF)
+torch.Tensor.cuda = lambda self, *a, **k: self          # reference model/head.py:43 hard-codes .cuda()
+from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config, select_backbone, select_head  # noqa: E402
+from model.ppyolo import PPYOLO                                                          # noqa: E402
+from model.custom_layers import Conv2dUnit, DCNv2, DCNv2_Slow, CoordConv, SPP           # noqa: E402
+from model.head import yolo_box, get_iou_aware_score                                     # noqa: E402
+from model.matrix_nms import matrix_nms                                                  # noqa: E402
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def gen(seed):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    return g
+
+
+# ---------------------------------------------------------------------------------------
+def g1_conv_units():
+    """Conv2dUnit (reference model/custom_layers.py:65-253) at tiny shapes."""
+    cases = [  # cin, cout, k, stride, act, bn, bias, N, H, W
+        (32, 64, 1, 1, 'relu', 1, False, 2, 9, 11),
+        (32, 32, 3, 1, 'leaky', 1, False, 2, 10, 7),
+        (64, 32, 3, 2, 'relu', 1, False, 2, 11, 9),
+        (64, 96, 3, 2, None, 1, False, 1, 12, 12),
+        (32, 27, 3, 1, None, 0, True, 2, 6, 6),
+        (64, 258, 1, 1, None, 0, True, 2, 5, 5),
+        (96, 160, 1, 1, 'leaky', 1, False, 1, 19, 19),
+        (3, 32, 3, 2, 'relu', 1, False, 2, 16, 16),
+        (3, 32, 3, 2, 'relu', 1, False, 1, 15, 18),
+    ]
+    g = gen(101)
+    out = {}
+    for i, (ci, co, k, s, act, bn, bias, N, H, W) in enumerate(cases):
+        m = Conv2dUnit(ci, co, k, stride=s, bias_attr=bias, bn=bn, act=act)
+        m.eval()
+        with torch.no_grad():
+            m.conv.weight.copy_(torch.randn(m.conv.weight.shape, generator=g) * (2.0 / (ci * k * k)) ** 0.5)
+            if bias:
+                m.conv.bias.copy_(torch.randn(co, generator=g) * 0.5)
+            if bn:
+                m.bn.weight.copy_(torch.rand(co, generator=g) + 0.5)
+                m.bn.bias.copy_(torch.randn(co, generator=g) * 0.2)
+                m.bn.running_mean.copy_(torch.randn(co, generator=g) * 0.2)
+                m.bn.running_var.copy_(torch.rand(co, generator=g) + 0.5)
+            x = torch.randn(N, ci, H, W, generator=g)
+            y = m(x)
+        p = 'c%d_' % i
+        out[p + 'meta'] = np.array([ci, co, k, s, {'relu': 1, 'leaky': 2, None: 0}[act], bn, int(bias)])
+        out[p + 'x'] = x
+        out[p + 'w'] = m.conv.weight
+        if bias:
+            out[p + 'b'] = m.conv.bias
+        if bn:
+            out[p + 'bn'] = torch.stack([m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var])
+        out[p + 'y'] = y
+    out['ncases'] = np.array(len(cases))
+    save('g1_conv_units', **out)
+
+
+def g2_dcn():
+    """DCNv2 (reference model/custom_layers.py:486-677), cross-checked against the
+    python-loop DCNv2_Slow (:346-482) which has explicit per-corner bounds tests."""
+    g = gen(202)
+    out = {}
+    cases = [(32, 64, 1, 3, 9, 9), (32, 32, 2, 3, 10, 10), (64, 32, 1, 2, 7, 5)]
+    for i, (ci, co, s, N, H, W) in enumerate(cases):
+        m = DCNv2(ci, co, filter_size=3, stride=s, padding=1, bias_attr=False)
+        m.eval()
+        with torch.no_grad():
+            # offsets: std ~3 px plus a few far-out-of-range taps
+            m.conv_offset.weight.copy_(torch.randn(m.conv_offset.weight.shape, generator=g) * (3.0 / (ci * 9) ** 0.5))
+            b = torch.randn(27, generator=g) * 1.0
+            b[3] = 12.3
+            b[10] = -11.7
+            m.conv_offset.bias.copy_(b)
+            m.dcn_weight.copy_(torch.randn(m.dcn_weight.shape, generator=g) * (1.0 / (ci * 9)) ** 0.5)
+            x = torch.randn(N, ci, H, W, generator=g)
+            om = m.conv_offset(x)
+            y = m(x)
+            slow = DCNv2_Slow(ci, co, filter_size=3, stride=s, padding=1, bias_attr=False)
+            slow.load_state_dict(m.state_dict())
+            ys = slow(x)
+        err = (y - ys).abs().max().item()
+        assert err < 5e-5, err
+        p = 'd%d_' % i
+        out[p + 'meta'] = np.array([ci, co, s])
+        out[p + 'x'] = x
+        out[p + 'w_off'] = m.conv_offset.weight
+        out[p + 'b_off'] = m.conv_offset.bias
+        out[p + 'w_dcn'] = m.dcn_weight
+        out[p + 'offset_mask'] = om
+        out[p + 'y'] = y
+        out[p + 'y_slow'] = ys
+    out['ncases'] = np.array(len(cases))
+    save('g2_dcnv2', **out)
+
+
+def g3_coord_spp():
+    g = gen(303)
+    out = {}
+    x = torch.randn(2, 32, 5, 7, generator=g)
+    out['coord_x'] = x
+    out['coord_y'] = CoordConv(True)(x)
+    for i, (N, C, H, W) in enumerate([(2, 32, 19, 19), (1, 32, 10, 10), (1, 64, 13, 13)]):
+        x = torch.randn(N, C, H, W, generator=g)
+        out['spp%d_x' % i] = x
+        out['spp%d_y' % i] = SPP()(x)
+    save('g3_coord_spp', **out)
+
+
+def g4_decode():
+    """get_iou_aware_score + yolo_box (reference model/head.py:21-141)."""
+    g = gen(404)
+    cfg = PPYOLO_2x_Config()
+    anchors = np.array(cfg.head['anchors'], dtype=np.float32)
+    out = {}
+    im_size = torch.tensor([[480., 640.], [375., 500.], [1080., 1920.]])
+    for i, (S, stride, mask, iou_aware) in enumerate([(5, 32, [6, 7, 8], True), (7, 16, [3, 4, 5], True),
+                                                      (6, 8, [0, 1, 2], False)]):
+        nch = 3 * (80 + (6 if iou_aware else 5))
+        o = torch.randn(3, nch, S, S, generator=g) * 2.0
+        # push some boxes across every image border so both clips fire
+        o[:, :, 0, 0] += 1.5
+        with torch.no_grad():
+            t = get_iou_aware_score(o, 3, 80, 0.4) if iou_aware else o
+            boxes, scores = yolo_box(t, anchors[mask], stride, 80, 1.05, im_size, True, 0.01)
+        out['l%d_meta' % i] = np.array([S, stride, int(iou_aware)] + mask)
+        out['l%d_out' % i] = o
+        out['l%d_boxes' % i] = boxes
+        out['l%d_scores' % i] = scores
+    out['im_size'] = im_size
+    out['anchors'] = anchors
+    save('g4_decode', **out)
+
+
+def _nms_case(boxes, scores, **kw):
+    cfg = dict(score_threshold=0.01, post_threshold=0.01, nms_top_k=500, keep_top_k=100,
+               use_gaussian=False, gaussian_sigma=2.)
+    cfg.update(kw)
+    # tie-freeness at the first sort site
+    s = scores[scores > cfg['score_threshold']]
+    assert len(torch.unique(s)) == len(s), 'score ties in NMS fixture'
+    with torch.no_grad():
+        pred = matrix_nms(boxes, scores, **cfg)
+    if pred[0, 0] >= 0:
+        assert len(torch.unique(pred[:, 1])) == pred.shape[0], 'ties after decay'
+    return pred, cfg
+
+
+def _rand_boxes(g, n, w=640., h=480., smin=8., smax=200.):
+    cx = torch.rand(n, generator=g) * w
+    cy = torch.rand(n, generator=g) * h
+    bw = torch.rand(n, generator=g) * (smax - smin) + smin
+    bh = torch.rand(n, generator=g) * (smax - smin) + smin
+    b = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+    b[:, 0::2] = b[:, 0::2].clamp(0, w)
+    b[:, 1::2] = b[:, 1::2].clamp(0, h)
+    return b
+
+
+def _distinct_scores(g, shape, lo, hi):
+    n = int(np.prod(shape))
+    # distinct by construction: a random permutation of an arithmetic grid, float32-exact
+    grid = torch.linspace(lo, hi, n, dtype=torch.float64)
+    s = grid[torch.randperm(n, generator=g)].float().reshape(shape)
+    assert len(torch.unique(s)) == n
+    return s
+
+
+def g5_matrix_nms():
+    """matrix_nms (reference model/matrix_nms.py:102-151) on synthetic tie-free data."""
+    g = gen(505)
+    out = {}
+    cases = []
+    # 0: many candidates (>> nms_top_k), 5 classes, clustered boxes so decay matters
+    M, C = 900, 5
+    base = _rand_boxes(g, 60)
+    boxes = base[torch.randint(0, 60, (M,), generator=g)] + torch.randn(M, 4, generator=g) * 6.0
+    scores = _distinct_scores(g, (M, C), 0.0005, 0.95)
+    scores[torch.rand(M, C, generator=g) < 0.6] = 0.001
+    cases.append((boxes, scores, {}))
+    # 1: few candidates (< keep_top_k)
+    boxes = _rand_boxes(g, 40)
+    scores = _distinct_scores(g, (40, 3), 0.0, 0.03)
+    cases.append((boxes, scores, {}))
+    # 2: nothing above threshold -> sentinel
+    boxes = _rand_boxes(g, 30)
+    scores = _distinct_scores(g, (30, 4), 0.0, 0.0099)
+    cases.append((boxes, scores, {}))
+    # 3: exact duplicate boxes of the same class (1 - comp == 0 -> inf / NaN paths)
+    boxes = _rand_boxes(g, 50)
+    boxes[10] = boxes[3]
+    boxes[20] = boxes[3]
+    boxes[21] = boxes[7]
+    scores = _distinct_scores(g, (50, 2), 0.02, 0.9)
+    cases.append((boxes, scores, {}))
+    # 4: zero-area boxes (0/0 IoU -> NaN poisons every decay -> sentinel)
+    boxes = _rand_boxes(g, 30)
+    boxes[5] = torch.tensor([100., 100., 100., 150.])
+    boxes[9] = torch.tensor([300., 200., 300., 200.])
+    scores = _distinct_scores(g, (30, 2), 0.02, 0.9)
+    cases.append((boxes, scores, {}))
+    # 5: one zero-area box only (NaN only where it meets another zero-area box: none)
+    boxes = _rand_boxes(g, 30)
+    boxes[5] = torch.tensor([100., 100., 100., 150.])
+    scores = _distinct_scores(g, (30, 2), 0.02, 0.9)
+    cases.append((boxes, scores, {}))
+    # 6: gaussian kernel, smaller top-k
+    M, C = 400, 3
+    base = _rand_boxes(g, 25)
+    boxes = base[torch.randint(0, 25, (M,), generator=g)] + torch.randn(M, 4, generator=g) * 4.0
+    scores = _distinct_scores(g, (M, C), 0.001, 0.8)
+    cases.append((boxes, scores, dict(use_gaussian=True, nms_top_k=200, keep_top_k=50)))
+    # 7: heavy suppression: post_threshold removes most
+    M, C = 300, 1
+    base = _rand_boxes(g, 6)
+    boxes = base[torch.randint(0, 6, (M,), generator=g)] + torch.randn(M, 4, generator=g) * 2.0
+    scores = _distinct_scores(g, (M, C), 0.011, 0.3)
+    cases.append((boxes, scores, dict(post_threshold=0.05)))
+    # 8: 80 classes, PP-YOLO-sized box count
+    M, C = 2535, 80
+    base = _rand_boxes(g, 200)
+    boxes = base[torch.randint(0, 200, (M,), generator=g)] + torch.randn(M, 4, generator=g) * 5.0
+    scores = _distinct_scores(g, (M, C), 0.0, 0.012)
+    hot = torch.rand(M, C, generator=g) < 0.004
+    scores[hot] = _distinct_scores(g, (int(hot.sum()),), 0.02, 0.97)
+    cases.append((boxes, scores, {}))
+    for i, (b, s, kw) in enumerate(cases):
+        pred, cfg = _nms_case(b, s, **kw)
+        out['n%d_boxes' % i] = b
+        out['n%d_scores' % i] = s
+        out['n%d_pred' % i] = pred
+        out['n%d_cfg' % i] = np.array([cfg['score_threshold'], cfg['post_threshold'], cfg['nms_top_k'],
+                                       cfg['keep_top_k'], float(cfg['use_gaussian']), cfg['gaussian_sigma']],
+                                      dtype=np.float64)
+        print('   nms case %d -> %s rows (first label %.0f)' % (i, tuple(pred.shape), pred[0, 0]))
+    out['ncases'] = np.array(len(cases))
+    save('g5_matrix_nms', **out)
+
+
+def build_ref(cfg, seed=0):
+    bb = select_backbone(cfg.backbone_type)(**cfg.backbone)
+    hd = select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes, seed=seed), strict=True)
+    m.eval()
+    hd.set_dropblock(is_test=True)
+    return m, shapes
+
+
+def _assert_tie_free(model, x, im_size, cfg):
+    """Both sort sites of matrix_nms (reference model/matrix_nms.py:120, :140)."""
+    with torch.no_grad():
+        outs = model.head._get_outputs(model.backbone(x))
+        from model.head import get_iou_aware_score as gi, yolo_box as yb
+        bs, ss = [], []
+        for i, o in enumerate(outs):
+            if model.head.iou_aware:
+                o = gi(o, 3, 80, model.head.iou_aware_factor)
+            b, s = yb(o, model.head._anchors[model.head.anchor_masks[i]], model.head.downsample[i], 80,
+                      model.head.scale_x_y, im_size, True, 0.01)
+            bs.append(b)
+            ss.append(s)
+        scores = torch.cat(ss, 1)
+    for n in range(scores.shape[0]):
+        s = scores[n][scores[n] > 0.01]
+        top = torch.sort(s, descending=True)[0][:520]
+        assert len(torch.unique(top)) == len(top), 'tie among top candidates of image %d' % n
+    return int((scores > 0.01).sum())
+
+
+def g6_g7_models():
+    out_shapes = {}
+    for tag, C, S, N, seed in (('r18vd_64', PPYOLO_r18vd_Config, 64, 2, 0),
+                               ('r50vd_96', PPYOLO_2x_Config, 96, 2, 0)):
+        cfg = C()
+        m, shapes = build_ref(cfg, seed)
+        x = synth.synth_images(N, S, seed=1234)
+        with torch.no_grad():
+            feats = m.backbone(x)
+            outs = m.head._get_outputs(feats)
+        arrs = {'meta': np.array([S, N, seed, 1234])}
+        for i, f in enumerate(feats):
+            arrs['feat%d' % i] = f
+        for i, o in enumerate(outs):
+            arrs['out%d' % i] = o
+        save('g6_' + tag, **arrs)
+    for tag, C, S, N, seed in (('r18vd_320', PPYOLO_r18vd_Config, 320, 1, 0),
+                               ('r50vd_160', PPYOLO_2x_Config, 160, 2, 0)):
+        cfg = C()
+        m, shapes = build_ref(cfg, seed)
+        x = synth.synth_images(N, S, seed=1234)
+        im_size = torch.tensor([[480., 640.], [375., 500.]])[:N]
+        ncand = _assert_tie_free(m, x, im_size, cfg)
+        with torch.no_grad():
+            preds = m(x, im_size)
+            outs = m.head._get_outputs(m.backbone(x))
+        arrs = {'meta': np.array([S, N, seed, 1234]), 'im_size': im_size, 'ncand': np.array(ncand)}
+        for i, p in enumerate(preds):
+            assert len(torch.unique(p[:, 1])) == p.shape[0]
+            arrs['pred%d' % i] = p
+        for i, o in enumerate(outs):
+            arrs['out%d' % i] = o
+        save('g7_' + tag, **arrs)
+        print('   %s: %d candidates, rows %s' % (tag, ncand, [tuple(p.shape) for p in preds]))
+
+
+ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    for k, fn in ALL.items():
+        if a.only is None or a.only == k:
+            fn()
