@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Benchmark of the PP-YOLO inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (backbone + head + decode + Matrix-NMS, i.e.
+`PPYOLO.forward` minus its final host list-building) over one batch of 8 synthetic images
+per GPU that are already resident in HBM.  Metric: images/s of PPYOLO ResNet50-vd 608x608
+bs=8 (BASELINE.json `metric`, configs[2]); weak scaling (8 images per GPU, one RCCL
+all-gather of the detection records per step when N > 1).  Prints ONE JSON line on rank 0.
+
+`roofline`: the dominant kernels are the fp32-MFMA implicit-GEMM convolutions.  After the
+timed region the same plan is replayed eagerly with HIP events bracketing every conv / DCN
+launch on the launch stream; achieved = algorithmic conv FLOPs per step (2*MAC, BN/act
+excluded: 102.0 GFLOP per image at R50-608) / summed conv launch time, against
+the 157.3 TFLOP/s fp32 MFMA peak.  `cpu_baseline`: the oracle (same PyTorch-CPU ops as the
+reference) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'pytorch-ppyolo_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+WORKLOADS = {
+    'r50vd_608': dict(cfg='PPYOLO_2x_Config', size=608, model='PPYOLO ResNet50-vd (DCNv2, CoordConv, SPP)'),
+    'r18vd_416': dict(cfg='PPYOLO_r18vd_Config', size=416, model='PPYOLO_r18vd'),
+    'r18vd_320': dict(cfg='PPYOLO_r18vd_Config', size=320, model='PPYOLO_r18vd'),
+}
+
+
+def build_model(cfg_name, device):
+    import config as C
+    from model.ppyolo import PPYOLO
+    from ppyolo_hip import synth
+    cfg = getattr(C, cfg_name)()
+    bb = C.select_backbone(cfg.backbone_type)(**cfg.backbone)
+    hd = C.select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict(sd)
+    m.eval()
+    hd.set_dropblock(is_test=True)
+    return m.to(device), sd, cfg
+
+
+def conv_flops(plan):
+    """Algorithmic FLOPs (2*MAC) of every conv-shaped launch of one step."""
+    total = 0
+    per_op = []
+    for op in plan.ops:
+        f = 0
+        if op['op'] == 'conv':
+            K, R, S, C = op['w'].shape
+            y = op['y']
+            Ho, Wo = (y.H // 2, y.W // 2) if op['ups'] else (y.H, y.W)
+            f = 2 * y.N * Ho * Wo * K * R * S * C
+        elif op['op'] == 'dcn':
+            K, R, S, C = op['w'].shape
+            y = op['y']
+            f = 2 * y.N * y.H * y.W * K * R * S * C
+        elif op['op'] == 'stem':
+            y = op['y']
+            f = 2 * y.N * y.H * y.W * op['w'].shape[0] * 27
+        per_op.append(f)
+        total += f
+    return total, per_op
+
+
+def timed_conv_pass(ex, per_op_flops, reps=3):
+    """Eager replay with HIP events around every MFMA conv / DCN launch (current stream =
+    the launch stream).  Returns (sum of conv launch ms per step, flops covered)."""
+    convs = [i for i, op in enumerate(ex.plan.ops) if op['op'] in ('conv', 'dcn')]
+    best = None
+    for _ in range(reps):
+        evs = []
+        for i, op in enumerate(ex.plan.ops):
+            if i in convs:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                ex._run_op(op)
+                e.record()
+                evs.append((s, e))
+            else:
+                ex._run_op(op)
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e in evs)
+        best = ms if best is None else min(best, ms)
+    return best, sum(per_op_flops[i] for i in convs), len(convs)
+
+
+def cpu_baseline(sd, cfg, size, batch):
+    """Oracle (PyTorch-CPU restatement of the reference forward) on the host cores."""
+    from oracle import ppyolo_oracle as orc
+    from ppyolo_hip import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synth.synth_images(batch, size)
+    ims = synth.synth_im_size(batch)
+    t0 = time.perf_counter()
+    orc.ppyolo_forward(sd, cfg, x[:1], ims[:1])            # warm-up (thread pool, MKLDNN primitives)
+    warm = time.perf_counter() - t0
+    n_batches = 1 if warm * batch > 12.0 else 2
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        orc.ppyolo_forward(sd, cfg, x, ims)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_batches * batch / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d batch(es) of %d images, %dx%d, after a 1-image warm-up; oracle = same ATen ops as the '
+                       'reference forward' % (n_batches, batch, size, size))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='r50vd_608', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    from ppyolo_hip import dist as pd
+    rank, world, local = pd.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    wl = WORKLOADS[a.workload]
+    os.environ['PPYOLO_HIP_GRAPH'] = '0' if a.no_graph else '1'
+
+    import __graft_entry__ as ge
+    ge.build()
+    model, sd, cfg = build_model(wl['cfg'], dev)
+    from ppyolo_hip import synth
+    x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank).to(dev)
+    ims = synth.synth_im_size(a.batch).to(dev)
+    ex = model._plans.executor(x)
+    ex.set_inputs(x, ims)                   # inputs resident in HBM before the timed region
+    ex.use_graph = False
+    ex.run()
+    torch.cuda.synchronize()
+    if not a.no_autotune:
+        ex.autotune(iters=2)
+    ex.use_graph = not a.no_graph
+    gat = pd.DetectionGatherer(a.batch, ex.out_dets.shape[1], dev, world)
+
+    def step():
+        ex.run()
+        if world > 1:
+            gat.gather(ex.out_dets, ex.out_count)
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / a.steps * 1e3
+    value = world * a.batch * a.steps / dt
+
+    if rank == 0:
+        total_flops, per_op = conv_flops(ex.plan)
+        conv_ms, covered, nconv = timed_conv_pass(ex, per_op)
+        achieved = covered / (conv_ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    kernel='conv_igemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM), %d launches/step' % nconv,
+                    flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
+                    whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
+        out = dict(metric='images/sec PPYOLO R50-vd 608x608 bs=8' if a.workload == 'r50vd_608'
+                   else 'images/sec %s bs=%d' % (a.workload, a.batch),
+                   value=round(value, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32', data='synthetic (randn images seed 1234, deterministic random weights seed 0)',
+                   config=dict(workload='%s %dx%d, %d images per GPU, device-resident input -> padded detections'
+                                        % (wl['model'], wl['size'], wl['size'], a.batch),
+                               global_batch=world * a.batch, parallelism='batch-sharded x%d, all-gather of detections'
+                               % world if world > 1 else 'single GPU', hip_graph=not a.no_graph,
+                               autotuned=not a.no_autotune),
+                   roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sd, cfg, wl['size'], a.batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

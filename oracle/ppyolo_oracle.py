@@ -67,7 +67,7 @@ def dcnv2_sample(x, offset, mask, stride, padding, k=3):
     oW = (W + 2 * padding - (k - 1)) // stride
     oH = (H + 2 * padding - (k - 1)) // stride
     Hp, Wp = H + 2 * padding + 1, W + 2 * padding + 1
-    xp = torch.zeros((N, C, Hp, Wp), dtype=torch.float32)
+    xp = torch.zeros((N, C, Hp, Wp), dtype=x.dtype)
     xp[:, :, padding:padding + H, padding:padding + W] = x
     # window origin (in padded coordinates) + tap position inside the window
     oy = (torch.arange(oH, dtype=torch.float32) * stride + padding).view(1, oH, 1, 1)
