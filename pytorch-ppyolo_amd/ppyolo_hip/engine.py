@@ -14,6 +14,8 @@ a CPU-only box by interpreting the same plan with reference ops (tests/plan_inte
 the product executor below has no CPU path.
 """
 import collections
+import json
+import os
 
 import torch
 
@@ -37,6 +39,31 @@ def fold_bn(bn, bias, K_out, device):
         shift = bias.detach().float().clone() if bias is not None else torch.zeros(K_out, dtype=torch.float32,
                                                                                    device=device)
     return scale.contiguous(), shift.contiguous()
+
+
+_TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
+_tuned = None
+
+
+def tune_key(op):
+    """Shape key of a conv / DCN launch in the measured (tile config, split-K) table."""
+    x = op['x']
+    Kout, R, S, C = op['w'].shape
+    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (op['op'], x.N, x.H, x.W, C, Kout, R, op['stride'])
+
+
+def tuned_table():
+    """Measured per-shape choices (written by HipExecutor.autotune on an MI355X and committed
+    as tuned_gfx950.json; PPYOLO_HIP_TUNE_CACHE names an extra file).  Unknown shapes fall back
+    to the cost model inside libppyolo_hip.so."""
+    global _tuned
+    if _tuned is None:
+        _tuned = {}
+        for path in (_TUNED_PATH, os.environ.get('PPYOLO_HIP_TUNE_CACHE')):
+            if path and os.path.exists(path):
+                with open(path) as fh:
+                    _tuned.update(json.load(fh))
+    return _tuned
 
 
 class Plan(object):
@@ -191,6 +218,10 @@ class HipExecutor(object):
             self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
         self._to_device(p.setup_ops)
         self._to_device(p.ops)
+        tab = tuned_table()
+        for op in p.ops:
+            if op['op'] in ('conv', 'dcn') and op['cfg'] < 0 and tune_key(op) in tab:
+                op['cfg'], op['splitk'] = tab[tune_key(op)][:2]
         self.ws = None
         self._size_workspace()
         with torch.cuda.device(self.device):
@@ -343,13 +374,19 @@ class HipExecutor(object):
                     op['cfg'], op['splitk'] = base_cfg, base_split
                     continue
                 op['cfg'], op['splitk'] = best[1], best[2]
-                report.append((op['op'], tuple(op['w'].shape), op['x'].H, best))
+                tuned_table()[tune_key(op)] = [best[1], best[2], round(best[0], 4)]
+                report.append((tune_key(op), best))
                 if verbose:
                     print('autotune %s w=%s H=%d -> cfg %d split %d  %.3f ms' % (op['op'], tuple(op['w'].shape),
                                                                                op['x'].H, best[1], best[2], best[0]))
         self._size_workspace()
         self.graph = None
         return report
+
+    @staticmethod
+    def save_tuning(path):
+        with open(path, 'w') as fh:
+            json.dump(tuned_table(), fh, indent=0, sort_keys=True)
 
 
 def run_single(unit, x_nchw):
