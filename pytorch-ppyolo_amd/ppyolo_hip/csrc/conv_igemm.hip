@@ -24,6 +24,8 @@
 // K-slot trick: within an 8-wide k group lane-half h reads floats [4h, 4h+4); the t-th MFMA of
 // the group contracts k = {t, 4+t}.  A and B use the same permutation, so the sum is unchanged
 // and every LDS read is a b128.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -60,12 +62,124 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs &p, int m, int col
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool SPLIT>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+// Epilogue shared by both kernels.  Must be entered after a workgroup barrier that follows the
+// last MFMA read of the operand tiles (the vector path reuses the LDS as a wave-private
+// transpose patch).
+template <int TM, int TN, int WM, int WN, bool SPLIT, bool VEC>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)[TM][TN], float *smem, int m0,
+                                              int n0, int wm, int wn, int lane, int wave, int split) {
+    const int hw = p.Ho * p.Wo;
+    if constexpr (VEC) {
+        // ---- vector epilogue: each 32x32 accumulator tile goes through a wave-private LDS
+        // patch so that a lane owns 4 consecutive channels of a pixel: 16-byte residual loads
+        // and stores, 8 lanes per 128-byte row segment (the scalar form -- 4 bytes per lane --
+        // measured ~2.2 TB/s on the output-heavy 1x1 layers vs 4.3 TB/s for float4 kernels).
+        // The main loop ended with a barrier, so nobody reads the operand tiles any more.
+        float *sE = smem + wave * (32 * LDS_LD);
+        const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + ec4;
+            const bool colok = col < p.K;
+            floatx4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (!SPLIT && colok) {
+                sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
+                sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mbase = m0 + wm * WM + i * 32 + erow;
+                floatx4 rv[4];
+                if (!SPLIT && p.res) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = mbase + 8 * t;
+                        rv[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+                        if (colok && m < p.M)
+                            rv[t] = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    sE[row * LDS_LD + (lane & 31)] = acc[i][j][e];
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mbase + 8 * t;
+                    floatx4 v = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * t) * LDS_LD + ec4);
+                    if (colok && m < p.M) {
+                        if (SPLIT) {
+                            *reinterpret_cast<floatx4 *>(p.part + ((long long)split * p.M + m) * p.K + col) = v;
+                        } else {
+                            if (p.posb) {
+                                const floatx4 pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % hw) * p.K + col);
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) v[u] += pb[u];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                float o = fmaf(v[u], sc[u], sh[u]);
+                                if (p.res) o += rv[t][u];
+                                v[u] = ppy_apply_act(o, p.act);
+                            }
+                            if (!p.ups) {
+                                *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
+                            } else {
+                                const int n = m / hw, rem = m - n * hw;
+                                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                                const long long W2 = 2LL * p.Wo;
+                                float *o = p.y + (((long long)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + col;
+                                *reinterpret_cast<floatx4 *>(o) = v;
+                                *reinterpret_cast<floatx4 *>(o + p.y_ld) = v;
+                                *reinterpret_cast<floatx4 *>(o + W2 * p.y_ld) = v;
+                                *reinterpret_cast<floatx4 *>(o + (W2 + 1) * p.y_ld) = v;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    // ---- scalar epilogue: lane l holds channel (l&31) of 16 pixels per 32x32 tile ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool colok = col < p.K;
+        float sc = 1.f, sh = 0.f;
+        if (!SPLIT && colok) {
+            sc = p.scale[col];
+            sh = p.shift[col];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * WM + i * 32 + row;
+                if (colok && m < p.M) {
+                    if (SPLIT)
+                        p.part[((long long)split * p.M + m) * p.K + col] = acc[i][j][e];
+                    else
+                        epilogue_store(p, m, col, acc[i][j][e], sc, sh);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool SPLIT, bool VEC>
+__global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_kernel(const ConvArgs p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    constexpr int A_PER = BM / 32, B_PER = BN / 32;
+    constexpr int NW = (BM / WM) * (BN / WN);     // 4 waves (one per SIMD) or 8 (two per SIMD)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int RPP = NW * 8;                   // tile rows staged per pass (8 lanes x 16 B per row)
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
+    constexpr int A_PER = BM / RPP, B_PER = BN / RPP;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;                     // [2][BM][LDS_LD]
@@ -81,60 +195,72 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int kc_begin = split * p.chunks_per_split;
     const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
 
-    // ---- per-thread loader coordinates: row = (tid>>3) + 32*j, 16-byte column tid&7 ----
+    // ---- per-thread loader coordinates: row = (tid>>3) + RPP*j, 16-byte column tid&7 ----
+    // Loads are UNCONDITIONAL (straight-line code, exact vmcnt bookkeeping): a padding tap or a
+    // row beyond M reads the row's own centre pixel instead and is zeroed when it is written
+    // to LDS.
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
     long long a_base[A_PER];
     int a_hi0[A_PER], a_wi0[A_PER];
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
-        const int m = m0 + lrow + 32 * j;
-        if (m < p.M) {
-            const int n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            a_hi0[j] = ho * p.stride - p.pad;
-            a_wi0[j] = wo * p.stride - p.pad;
-            a_base[j] = (((long long)n * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.x_ld + lc4;
-        } else {
-            a_hi0[j] = -(1 << 20);   // every tap fails the bounds test -> zero rows
-            a_wi0[j] = -(1 << 20);
-            a_base[j] = 0;
-        }
+        const int mr = m0 + lrow + RPP * j;
+        const int m = min(mr, p.M - 1);
+        const int n = m / hw, rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[j] = ho * p.stride - p.pad;
+        a_wi0[j] = wo * p.stride - p.pad;
+        a_base[j] = (((long long)n * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.x_ld + lc4;
+        if (mr >= p.M) a_hi0[j] = -(1 << 20);   // every tap fails the bounds test -> zero rows
     }
     const float *b_row[B_PER];
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
-        const int k = min(n0 + lrow + 32 * j, p.K - 1);   // clamp: rows >= K are masked at store
+        const int k = min(n0 + lrow + RPP * j, p.K - 1);   // clamp: rows >= K are masked at store
         b_row[j] = p.w + (long long)k * p.Kred + lc4;
     }
 
-    floatx4 ra[A_PER], rb[B_PER];
+    // two staging register sets: loads run TWO chunks ahead of the MFMAs
+    floatx4 ra0[A_PER], rb0[B_PER], ra1[A_PER], rb1[B_PER];
+    unsigned ok0 = 0, ok1 = 0;
     const int RS = p.R * p.S;
+    // chunk cursor of the loader (chunks are fetched strictly in order): channel chunk, tap (r, s)
+    int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
+    int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
+    const long long centre_off = (long long)(p.pad * p.W + p.pad) * p.x_ld;
 
-    auto load_tiles = [&](int kc) {
-        const int cc = kc / RS, tap = kc - cc * RS;
-        const int r = tap / p.S, s = tap - r * p.S;
-        const int coff = cc * BK;
-        const long long tap_off = (long long)(r * p.W + s) * p.x_ld + coff;
+    auto load_tiles = [&](floatx4 (&ra)[A_PER], floatx4 (&rb)[B_PER], unsigned &okm) {
+        const int coff = l_cc * BK;
+        const long long tap_off = (long long)(l_r * p.W + l_s) * p.x_ld + coff;
+        const long long ctr_off = centre_off + coff;
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const int hi = a_hi0[j] + r, wi = a_wi0[j] + s;
+            const int hi = a_hi0[j] + l_r, wi = a_wi0[j] + l_s;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            floatx4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const floatx4 *>(p.x + a_base[j] + tap_off);
-            ra[j] = v;
+            m |= ok ? (1u << j) : 0u;
+            ra[j] = *reinterpret_cast<const floatx4 *>(p.x + a_base[j] + (ok ? tap_off : ctr_off));
         }
-        const int woff = tap * p.C + coff;
+        okm = m;
+        const int woff = l_tap * p.C + coff;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) rb[j] = *reinterpret_cast<const floatx4 *>(b_row[j] + woff);
+        // advance the cursor
+        ++l_tap;
+        ++l_s;
+        if (l_s == p.S) { l_s = 0; ++l_r; }
+        if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const floatx4 (&ra)[A_PER], const floatx4 (&rb)[B_PER], unsigned okm) {
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < A_PER; ++j)
-            *reinterpret_cast<floatx4 *>(sA + (buf * BM + lrow + 32 * j) * LDS_LD + lc4) = ra[j];
+            *reinterpret_cast<floatx4 *>(sA + (buf * BM + lrow + RPP * j) * LDS_LD + lc4) =
+                ((okm >> j) & 1u) ? ra[j] : zero;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j)
-            *reinterpret_cast<floatx4 *>(sB + (buf * BN + lrow + 32 * j) * LDS_LD + lc4) = rb[j];
+            *reinterpret_cast<floatx4 *>(sB + (buf * BN + lrow + RPP * j) * LDS_LD + lc4) = rb[j];
     };
 
     floatx16 acc[TM][TN];
@@ -170,45 +296,202 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 
     // ---- main loop: register-staged double buffering, one barrier per chunk ----
     if (kc_begin < kc_end) {
-        load_tiles(kc_begin);
-        store_tiles(0);
+        load_tiles(ra0, rb0, ok0);
+        if (kc_begin + 1 < kc_end) load_tiles(ra1, rb1, ok1);
+        store_tiles(0, ra0, rb0, ok0);
         __syncthreads();
-        int cur = 0;
-        for (int kc = kc_begin; kc < kc_end; ++kc) {
-            const bool more = kc + 1 < kc_end;
-            if (more) load_tiles(kc + 1);     // global loads in flight under the MFMAs
-            compute(cur);
-            if (more) store_tiles(cur ^ 1);
+        // steady state, unrolled by two so the register sets are named statically:
+        //   issue loads of chunk k+2 | MFMAs of chunk k (LDS buffer k&1) | store chunk k+1 -> LDS
+        int left = kc_end - kc_begin;          // chunks not yet computed
+        while (true) {
+            if (left > 2) load_tiles(ra0, rb0, ok0);
+            compute(0);
+            if (left == 1) break;
+            store_tiles(1, ra1, rb1, ok1);
             __syncthreads();
-            cur ^= 1;
+            --left;
+            if (left > 2) load_tiles(ra1, rb1, ok1);
+            compute(1);
+            if (left == 1) break;
+            store_tiles(0, ra0, rb0, ok0);
+            __syncthreads();
+            --left;
         }
+        __syncthreads();
     }
 
-    // ---- epilogue: lane l holds channel (l&31) of 16 pixels per 32x32 tile ----
+    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, smem, m0, n0, wm, wn, lane, wave, split);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-DMA variant: operand tiles go HBM/L2 -> LDS directly (`buffer_load_dwordx4 ... lds`), no
+// VGPR staging, no ds_write pass, and a real multi-stage pipeline with COUNTED vmcnt waits
+// (hipcc's own bookkeeping of register-staged loads drained the queue at every chunk: it waited
+// vmcnt(3) where vmcnt(7) was enough, which pinned the prefetch distance at one chunk).
+//  * The DMA writes wave-uniform base + lane*16, i.e. 8 tile rows of 128 B per wave instruction,
+//    so tiles are stored UNPADDED and bank conflicts are avoided with an XOR swizzle applied to
+//    the per-lane SOURCE column (16-byte column c of row r lives in slot c ^ ((r>>1)&7)); the MFMA
+//    fragment reads apply the same XOR.  16 rows x 16 B then cover all 64 banks once.
+//  * Addressing is a buffer descriptor rebuilt per chunk on the scalar unit (base = tensor +
+//    uniform tap/channel offset) plus a per-lane 32-bit row offset computed ONCE; padding taps and
+//    rows beyond M use an out-of-range offset, for which the hardware writes zeros into LDS
+//    (probed on MI355X: tools/probes/glds_probe.hip).  Per chunk and tile row the vector unit
+//    only executes a bit test and a select.
+//  * Pipeline (STAGES LDS buffers): wait for chunk k (counted vmcnt) -> barrier (also proves
+//    everyone finished chunk k-1, whose buffer is then refilled with chunk k+STAGES-1) -> MFMAs.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+__global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only builtins (buffer descriptor, LDS DMA)
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "8 tile rows per wave DMA instruction");
+    constexpr int A_PASS = BM / (8 * NW), B_PASS = BN / (8 * NW);
+    constexpr int G = A_PASS + B_PASS;             // DMA instructions per wave per chunk
+    constexpr int STAGE = (BM + BN) * BK;          // floats per pipeline stage
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kc_begin = split * p.chunks_per_split;
+    const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
+    const int nchunks = kc_end - kc_begin;
+
+    // ---- per-lane DMA source offsets (bytes), fixed for the whole tile ----
+    const int drow = lane >> 3, dslot = lane & 7;
+    const int hw = p.Ho * p.Wo;
+    const unsigned OOB = 0xFFFFFFF0u;
+    const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
+    unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + (lane & 31);
-        const bool colok = col < p.K;
-        float sc = 1.f, sh = 0.f;
-        if (!SPLIT && colok) {
-            sc = p.scale[col];
-            sh = p.shift[col];
+    for (int j = 0; j < A_PASS; ++j) {
+        const int row = (j * NW + wave) * 8 + drow;         // row inside the tile
+        const int scol = dslot ^ ((row >> 1) & 7);          // source 16-byte column for this slot
+        const int mr = m0 + row;
+        const int m = min(mr, p.M - 1);
+        const int n = m / hw, rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_off[j] = (unsigned)((((long long)n * p.H + hi0) * p.W + wi0) * p.x_ld * 4 + bias + scol * 16);
+        unsigned okb = 0;
+        if (mr < p.M) {
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W)
+                        okb |= 1u << (r * p.S + s2);
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int m = m0 + wm * WM + i * 32 + row;
-                if (colok && m < p.M) {
-                    if (SPLIT)
-                        p.part[((long long)split * p.M + m) * p.K + col] = acc[i][j][e];
-                    else
-                        epilogue_store(p, m, col, acc[i][j][e], sc, sh);
-                }
-            }
-        }
+        a_ok[j] = okb;
     }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+        const int row = (j * NW + wave) * 8 + drow;
+        const int scol = dslot ^ ((row >> 1) & 7);
+        const int k = min(n0 + row, p.K - 1);
+        b_off[j] = (unsigned)((long long)k * p.Kred * 4 + scol * 16);
+    }
+
+    const int RS = p.R * p.S;
+    int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
+    int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
+    const char *xb = reinterpret_cast<const char *>(p.x) - bias;
+    const char *wb = reinterpret_cast<const char *>(p.w);
+
+    auto issue = [&](int stage) {
+        const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * BK) * 4;
+        const long long b_uni = ((long long)l_tap * p.C + l_cc * BK) * 4;
+        __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + a_uni), 0, 0xFFFFFF00u, 0x00020000);
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + b_uni), 0, 0xFFFFFF00u, 0x00020000);
+        float *sA = smem + stage * STAGE;
+        float *sB = sA + BM * BK;
+#pragma unroll
+        for (int j = 0; j < A_PASS; ++j) {
+            const unsigned off = ((a_ok[j] >> l_tap) & 1u) ? a_off[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sA + (j * NW + wave) * 8 * BK), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASS; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sB + (j * NW + wave) * 8 * BK), 16, b_off[j], 0, 0, 0);
+        ++l_tap;
+        ++l_s;
+        if (l_s == p.S) { l_s = 0; ++l_r; }
+        if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read offsets: row (lane&31), 16-byte slot ((2q + lane>>5) ^ swizzle(row))
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, fkh = lane >> 5;
+    int foff[BK / 8];
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) foff[q] = frow * BK + (((2 * q + fkh) ^ fsw) << 2);
+
+    auto compute = [&](int stage) {
+        const float *a_ptr = smem + stage * STAGE + wm * WM * BK;
+        const float *b_ptr = smem + stage * STAGE + BM * BK + wn * WN * BK;
+        // all fragment reads of the chunk are issued up front (distinct registers), so the MFMA
+        // chain only waits on counted lgkmcnt instead of a read -> wait -> 4 MFMA lock-step
+        floatx4 a[BK / 8][TM], b[BK / 8][TN];
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * BK + foff[q]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const floatx4 *>(b_ptr + j * 32 * BK + foff[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b[q][j][t], acc[i][j], 0, 0, 0);
+    };
+
+    if (nchunks > 0) {
+        // prologue: STAGES-1 chunks in flight
+        issue(0);
+        if (STAGES == 3 && nchunks > 1) issue(1);
+        int stage = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            // chunks issued so far: k .. min(k + STAGES - 2, nchunks - 1); wait for chunk k only
+            if (STAGES == 3 && k + 1 < nchunks)
+                wait_vmcnt<G>();
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (k + STAGES - 1 < nchunks) {
+                int st = stage + STAGES - 1;
+                if (st >= STAGES) st -= STAGES;
+                issue(st);
+            }
+            compute(stage);
+            if (++stage == STAGES) stage = 0;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, smem, m0, n0, wm, wn, lane, wave, split);
+#endif
 }
 
 // Deterministic split-K combine (fixed z order) + the same epilogue.
@@ -235,36 +518,117 @@ constexpr TileCfg kCfgs[] = {
     {128, 32, 32, 32},   // 5
     {32, 128, 32, 32},   // 6
 };
-constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kNumTiles = sizeof(kCfgs) / sizeof(kCfgs[0]);
+// Configuration ids:
+//   [0,7)   4-wave tiles, VGPR-staged loader                      (kCfgs above)
+//   [7,14)  8-wave (512-thread) tiles, VGPR-staged loader: two waves per SIMD inside ONE
+//           workgroup share the operand tiles -> half the L2->LDS traffic and barriers per MFMA
+//           {128,128,32,64} {128,128,64,32} {128,64,32,32} {64,128,32,32} {256,64,64,32}
+//           {256,128,64,64} {128,256,64,64}
+//   [14,26) LDS-DMA loader (conv_igemm_glds_kernel), see kGlds below
+struct GldsCfg {
+    int bm, bn, wm, wn, stages;
+};
+constexpr GldsCfg kGlds[] = {
+    {64, 64, 32, 32, 3},     // 14
+    {64, 64, 32, 32, 2},     // 15
+    {128, 64, 32, 32, 3},    // 16  (8 waves)
+    {64, 128, 32, 32, 3},    // 17  (8 waves)
+    {128, 128, 32, 64, 2},   // 18  (8 waves)
+    {128, 128, 64, 32, 2},   // 19  (8 waves)
+    {128, 128, 64, 64, 2},   // 20
+    {128, 64, 64, 32, 3},    // 21
+    {64, 128, 32, 64, 3},    // 22
+    {128, 32, 32, 32, 3},    // 23
+    {32, 128, 32, 32, 3},    // 24
+    {256, 64, 64, 32, 2},    // 25  (8 waves)
+};
+constexpr int kNumGlds = sizeof(kGlds) / sizeof(kGlds[0]);
+constexpr int kNumCfgs = 14 + kNumGlds;
+
+template <int BM, int BN, int WM, int WN, bool SPLIT, bool VEC>
+int launch_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
+    auto k = conv_igemm_kernel<BM, BN, WM, WN, SPLIT, VEC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
+    return PPY_OK;
+}
+
+// 16-byte epilogue accesses need 4-channel granularity and 16-byte aligned rows everywhere.
+bool vec_epilogue_ok(const ConvArgs &p) {
+    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    if (p.K % 4 != 0 || p.y_ld % 4 != 0 || !al(p.y) || !al(p.scale) || !al(p.shift)) return false;
+    if (p.res && (p.res_ld % 4 != 0 || !al(p.res))) return false;
+    if (p.posb && !al(p.posb)) return false;
+    if (p.part && !al(p.part)) return false;
+    return true;
+}
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvArgs &p, int splits, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
-    dim3 grid(tiles, splits), block(256);
+    const bool vec = vec_epilogue_ok(p);
+    int rc;
     if (splits > 1) {
-        auto k = conv_igemm_kernel<BM, BN, WM, WN, true>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return PPY_ERR_LAUNCH;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+        rc = vec ? launch_one<BM, BN, WM, WN, true, true>(p, splits, lds, tiles, stream)
+                 : launch_one<BM, BN, WM, WN, true, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
         const long long total = (long long)p.M * p.K;
         const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, p, splits);
     } else {
-        auto k = conv_igemm_kernel<BM, BN, WM, WN, false>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return PPY_ERR_LAUNCH;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+        rc = vec ? launch_one<BM, BN, WM, WN, false, true>(p, splits, lds, tiles, stream)
+                 : launch_one<BM, BN, WM, WN, false, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+    }
+    return ppy_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+int launch_glds_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
+    auto k = conv_igemm_glds_kernel<BM, BN, WM, WN, STAGES, SPLIT, VEC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
+    return PPY_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_glds(const ConvArgs &p, int splits, hipStream_t stream) {
+    // the per-lane DMA offsets are 32-bit: tensors must stay below 4 GB (- margin)
+    const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
+    const long long wbytes = (long long)p.K * p.Kred * 4;
+    if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(float);
+    const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
+    if (lds < epi) lds = epi;
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
+    const bool vec = vec_epilogue_ok(p);
+    int rc;
+    if (splits > 1) {
+        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, true, true>(p, splits, lds, tiles, stream)
+                 : launch_glds_one<BM, BN, WM, WN, STAGES, true, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+        const long long total = (long long)p.M * p.K;
+        const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, p, splits);
+    } else {
+        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, false, true>(p, splits, lds, tiles, stream)
+                 : launch_glds_one<BM, BN, WM, WN, STAGES, false, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
 }
@@ -294,11 +658,11 @@ bool conv_geometry(int N, int H, int W, int C, int K, int R, int S, int stride, 
 // FLOP/clk); items are dealt round-robin to 256 CUs.  Small tiles pay more LDS/L1 traffic per
 // FLOP (eff), split-K pays a combine pass through HBM plus a kernel boundary.
 void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
-    static const double eff[kNumCfgs] = {1.00, 0.95, 0.95, 0.88, 0.85, 0.80, 0.80};
+    static const double eff[kNumTiles] = {1.00, 0.95, 0.95, 0.88, 0.85, 0.80, 0.80};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
     double best = 1e30;
     int bc = 3, bs = 1;
-    for (int c = 0; c < kNumCfgs; ++c) {
+    for (int c = 0; c < kNumTiles; ++c) {
         const TileCfg &t = kCfgs[c];
         // do not pick tiles much wider than the problem
         if (t.bn > 32 && t.bn / 2 >= K) continue;
@@ -395,6 +759,25 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
         case 4: return launch_cfg<256, 32, 64, 32>(p, s, st);
         case 5: return launch_cfg<128, 32, 32, 32>(p, s, st);
         case 6: return launch_cfg<32, 128, 32, 32>(p, s, st);
+        case 7: return launch_cfg<128, 128, 32, 64>(p, s, st);
+        case 8: return launch_cfg<128, 128, 64, 32>(p, s, st);
+        case 9: return launch_cfg<128, 64, 32, 32>(p, s, st);
+        case 10: return launch_cfg<64, 128, 32, 32>(p, s, st);
+        case 11: return launch_cfg<256, 64, 64, 32>(p, s, st);
+        case 12: return launch_cfg<256, 128, 64, 64>(p, s, st);
+        case 13: return launch_cfg<128, 256, 64, 64>(p, s, st);
+        case 14: return launch_glds<64, 64, 32, 32, 3>(p, s, st);
+        case 15: return launch_glds<64, 64, 32, 32, 2>(p, s, st);
+        case 16: return launch_glds<128, 64, 32, 32, 3>(p, s, st);
+        case 17: return launch_glds<64, 128, 32, 32, 3>(p, s, st);
+        case 18: return launch_glds<128, 128, 32, 64, 2>(p, s, st);
+        case 19: return launch_glds<128, 128, 64, 32, 2>(p, s, st);
+        case 20: return launch_glds<128, 128, 64, 64, 2>(p, s, st);
+        case 21: return launch_glds<128, 64, 64, 32, 3>(p, s, st);
+        case 22: return launch_glds<64, 128, 32, 64, 3>(p, s, st);
+        case 23: return launch_glds<128, 32, 32, 32, 3>(p, s, st);
+        case 24: return launch_glds<32, 128, 32, 32, 3>(p, s, st);
+        case 25: return launch_glds<256, 64, 64, 32, 2>(p, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }
