@@ -60,26 +60,74 @@ struct DecodeArgs {
     float stride_f, sxy, sxy_bias, e_obj, e_iou, thr;
 };
 
-// One wave per grid cell (n, h, w); 4 cells per workgroup.
+// 64 grid cells per 256-thread workgroup, three phases through LDS:
+//   1. the cells' channels (contiguous in NHWC) are staged with coalesced loads;
+//   2. one THREAD per (cell, anchor) does the IoU-aware objectness, the box decode and a
+//      logit-domain candidate bound: score = conf*sigmoid(cls) > thr  <=>  cls > logit(thr/conf),
+//      so the 80 class channels of a box need no exp at all unless they can pass;
+//   3. one WAVE per (cell, anchor) sweeps the class logits against that bound (minus a safety
+//      margin); only the survivors get the exact fp32 score and the exact `score > thr` test, then
+//      a wave ballot appends them to the image's candidate list.
+constexpr int DEC_CELLS = 64;
+
 __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
-    __shared__ float sh[4][272];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long cell = (long long)blockIdx.x * 4 + wv;
-    const long long ncell = (long long)p.N * p.S * p.S;
-    if (cell >= ncell) return;
-    const int w = (int)(cell % p.S), h = (int)((cell / p.S) % p.S), n = (int)(cell / ((long long)p.S * p.S));
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int per = 5 + p.C;
     const int nch = p.A * per + (p.iou_aware ? p.A : 0);
-    const float *src = p.head + cell * p.head_ld;
-    float *v = sh[wv];
-    for (int c = lane; c < nch; c += 64) v[c] = src[c];
-    __builtin_amdgcn_wave_barrier();   // LDS slice is private to this wave
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own ds_writes landed before the reads below
+    float *vals = dsm;                                  // [DEC_CELLS][nch]
+    float *s_conf = dsm + DEC_CELLS * nch;              // [DEC_CELLS * A]
+    float *s_bound = s_conf + DEC_CELLS * p.A;          // [DEC_CELLS * A]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cells_img = p.S * p.S;
+    const int cell_in_img0 = blockIdx.x * DEC_CELLS;
+    const long long cell0 = (long long)blockIdx.y * cells_img + cell_in_img0;
+    const int ncl = min(DEC_CELLS, cells_img - cell_in_img0);
 
-    const float im_h = p.im_size[n * 2 + 0], im_w = p.im_size[n * 2 + 1];
-    const float Sf = (float)p.S;
+    // ---- phase 1: stage ----
+    if (p.head_ld == nch) {
+        // contiguous block of cells: 16-byte loads from the aligned-down address, all issued before
+        // the first LDS write (a dependent 4-byte load loop here was latency-bound)
+        const float *src = p.head + cell0 * nch;
+        const int pre = (int)(((uintptr_t)src & 15) >> 2);     // floats between the 16-B line start and src
+        const float *base = src - pre;
+        const int total = ncl * nch + pre;
+        const int n4 = total >> 2;                              // whole 16-byte groups
+        constexpr int U = 8;
+        for (int i0 = 0; i0 < n4; i0 += 256 * U) {
+            floatx4 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < n4) r[u] = *reinterpret_cast<const floatx4 *>(base + 4 * i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < n4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = 4 * i + e - pre;
+                        if (idx >= 0) vals[idx] = r[u][e];
+                    }
+                }
+            }
+        }
+        for (int i = (n4 << 2) - pre + tid; i < ncl * nch; i += 256)
+            if (i >= 0) vals[i] = src[i];
+    } else {
+        for (int c = 0; c < ncl; ++c)
+            for (int i = tid; i < nch; i += 256) vals[c * nch + i] = p.head[(cell0 + c) * p.head_ld + i];
+    }
+    __syncthreads();
+
+    // ---- phase 2: one thread per (cell, anchor) ----
     const int off0 = p.iou_aware ? p.A : 0;
-    for (int a = 0; a < p.A; ++a) {
+    const float Sf = (float)p.S;
+    for (int q = tid; q < ncl * p.A; q += 256) {
+        const int c = q / p.A, a = q - c * p.A;
+        const long long cell = cell0 + c;
+        const int w = (int)(cell % p.S), h = (int)((cell / p.S) % p.S), n = (int)(cell / ((long long)p.S * p.S));
+        const float *v = vals + c * nch;
         const float *t = v + off0 + a * per;
         float obj_logit = t[4];
         if (p.iou_aware) {
@@ -93,36 +141,95 @@ __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
             obj_logit = -logf(nw);
         }
         const float conf = sigmoidf_(obj_logit);
-        const int box = p.box_offset + (h * p.S + w) * p.A + a;
-        if (lane == 0) {
-            // reference model/head.py:40-46, :61-77
-            const float bx = (p.sxy * sigmoidf_(t[0]) + (float)w - p.sxy_bias) * p.stride_f;
-            const float by = (p.sxy * sigmoidf_(t[1]) + (float)h - p.sxy_bias) * p.stride_f;
-            const float bw = expf(t[2]) * p.anchors[2 * a], bh = expf(t[3]) * p.anchors[2 * a + 1];
-            float x0 = (bx - bw / 2.0f) / Sf / p.stride_f * im_w;
-            float y0 = (by - bh / 2.0f) / Sf / p.stride_f * im_h;
-            float x1 = (bx + bw / 2.0f) / Sf / p.stride_f * im_w;
-            float y1 = (by + bh / 2.0f) / Sf / p.stride_f * im_h;
-            if (p.clip) {
-                x0 = x0 < 0.0f ? x0 * 0.0f : x0;   // keeps the reference's -0.0
-                y0 = y0 < 0.0f ? y0 * 0.0f : y0;
-                x1 = x1 > im_w ? im_w : x1;
-                y1 = y1 > im_h ? im_h : y1;
-            }
-            floatx4 b = {x0, y0, x1, y1};
-            *reinterpret_cast<floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4) = b;
+        // candidate bound in the logit domain, with a safety margin (exact test follows)
+        float bound;
+        if (p.thr <= 0.0f) {
+            bound = -INFINITY;
+        } else if (!(conf > p.thr)) {
+            bound = INFINITY;                      // conf*sigmoid(.) <= conf <= thr: nothing passes
+        } else {
+            const float tq = p.thr / conf;         // in (0, 1)
+            bound = logf(tq / (1.0f - tq)) - 0.02f;
         }
-        for (int c0 = 0; c0 < p.C; c0 += 64) {
-            const int c = c0 + lane;
-            float s = 0.f;
-            bool pass = false;
-            if (c < p.C) {
-                s = conf * sigmoidf_(t[5 + c]);
-                pass = s > p.thr;
-                if (p.scores_dense) p.scores_dense[((long long)n * p.M_total + box) * p.C + c] = s;
+        s_conf[q] = conf;
+        s_bound[q] = bound;
+        // reference model/head.py:40-46, :61-77
+        const float im_h = p.im_size[n * 2 + 0], im_w = p.im_size[n * 2 + 1];
+        const float bx = (p.sxy * sigmoidf_(t[0]) + (float)w - p.sxy_bias) * p.stride_f;
+        const float by = (p.sxy * sigmoidf_(t[1]) + (float)h - p.sxy_bias) * p.stride_f;
+        const float bw = expf(t[2]) * p.anchors[2 * a], bh = expf(t[3]) * p.anchors[2 * a + 1];
+        float x0 = (bx - bw / 2.0f) / Sf / p.stride_f * im_w;
+        float y0 = (by - bh / 2.0f) / Sf / p.stride_f * im_h;
+        float x1 = (bx + bw / 2.0f) / Sf / p.stride_f * im_w;
+        float y1 = (by + bh / 2.0f) / Sf / p.stride_f * im_h;
+        if (p.clip) {
+            x0 = x0 < 0.0f ? x0 * 0.0f : x0;   // keeps the reference's -0.0
+            y0 = y0 < 0.0f ? y0 * 0.0f : y0;
+            x1 = x1 > im_w ? im_w : x1;
+            y1 = y1 > im_h ? im_h : y1;
+        }
+        const int box = p.box_offset + (h * p.S + w) * p.A + a;
+        floatx4 bb = {x0, y0, x1, y1};
+        *reinterpret_cast<floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4) = bb;
+    }
+    __syncthreads();
+
+    // ---- phase 3: one wave per (cell, anchor) sweeps the class logits ----
+    // Two sweeps: (a) count this workgroup's candidates, ONE global atomic per workgroup reserves
+    // their slots (a returning atomic per wave on the image's single counter serialised at ~90
+    // atomics/us and dominated the kernel), (b) recompute and write.  A workgroup never spans two
+    // images (grid = N x blocks-per-image).
+    __shared__ int s_wcnt[4], s_wbase[4];
+    const int n = blockIdx.y;
+    uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
+    uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
+    int running = 0;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        if (sweep == 1) {
+            if (lane == 0) s_wcnt[wv] = running;
+            __syncthreads();
+            if (tid == 0) {
+                const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+                int base = 0;
+                if (total > 0) base = atomicAdd(p.cand_count + n, total);
+                int acc = base;
+                for (int k = 0; k < 4; ++k) { s_wbase[k] = acc; acc += s_wcnt[k]; }
             }
-            append_candidates(pass, s, (uint32_t)(box * p.C + c), p.cand_key + (long long)n * p.cand_cap,
-                              p.cand_idx + (long long)n * p.cand_cap, p.cand_count + n, p.cand_cap, lane);
+            __syncthreads();
+            running = s_wbase[wv];
+        }
+        for (int q = wv; q < ncl * p.A; q += 4) {
+            const int c = q / p.A, a = q - c * p.A;
+            const float bound = s_bound[q];
+            const bool dense = (p.scores_dense != nullptr) && sweep == 1;
+            if (!dense && bound == INFINITY) continue;      // wave-uniform
+            const int cellw = cell_in_img0 + c;
+            const int w = cellw % p.S, h = cellw / p.S;
+            const int box = p.box_offset + (h * p.S + w) * p.A + a;
+            const float conf = s_conf[q];
+            const float *cl = vals + c * nch + off0 + a * per + 5;
+            for (int c0 = 0; c0 < p.C; c0 += 64) {
+                const int k = c0 + lane;
+                float s = 0.f;
+                bool pass = false;
+                if (k < p.C) {
+                    const float lg = cl[k];
+                    if (dense || lg > bound) {
+                        s = conf * sigmoidf_(lg);
+                        pass = s > p.thr;
+                        if (dense) p.scores_dense[((long long)n * p.M_total + box) * p.C + k] = s;
+                    }
+                }
+                const unsigned long long bal = __ballot(pass);
+                if (sweep == 1 && pass) {
+                    const int pos = running + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < p.cand_cap) {
+                        ckey[pos] = score_to_key(s);
+                        cidx[pos] = (uint32_t)(box * p.C + k);
+                    }
+                }
+                running += __popcll(bal);
+            }
         }
     }
 }
@@ -203,7 +310,7 @@ struct NmsArgs {
 
 __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
     __shared__ unsigned long long skey[KMAX];
-    __shared__ float sbox[KMAX][4];
+    __shared__ __attribute__((aligned(16))) float sbox[KMAX][4];
     __shared__ float sscore[KMAX], scomp[KMAX], sdecay[KMAX], ssuf[KMAX];
     __shared__ int slabel[KMAX], sflat[KMAX];
     __shared__ unsigned int hist[1 << RBITS];
@@ -295,38 +402,35 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
     // ---- 3. Matrix-NMS decay (reference _matrix_nms :51-97) ----
     // D[i][j] = IoU(i,j) * same_class(i,j) for i < j (0 elsewhere).  Two threads per column j
     // split the i range; NaN propagates through max/min exactly like torch.max / torch.min.
-    const int part = tid & 1;
+    // Pairwise phase: one WAVE per column j (columns dealt round-robin to the 16 waves), lanes
+    // stride over the rows i < j, wave butterfly reductions.  NaN propagates through max / min
+    // exactly like torch.max / torch.min (any NaN in the column -> NaN).
+    const int lane = tid & 63, wv = tid >> 6;
     auto dval = [&](int i, int lj, float bj0, float bj1, float bj2, float bj3, float area_j) -> float {
-        const float a0 = sbox[i][0], a1 = sbox[i][1], a2 = sbox[i][2], a3 = sbox[i][3];
-        const float iw = fmaxf(fminf(a2, bj2) - fmaxf(a0, bj0), 0.0f);
-        const float ih = fmaxf(fminf(a3, bj3) - fmaxf(a1, bj1), 0.0f);
+        const floatx4 a = *reinterpret_cast<const floatx4 *>(&sbox[i][0]);
+        const float iw = fmaxf(fminf(a[2], bj2) - fmaxf(a[0], bj0), 0.0f);
+        const float ih = fmaxf(fminf(a[3], bj3) - fmaxf(a[1], bj1), 0.0f);
         const float inter = iw * ih;
-        const float area_i = (a2 - a0) * (a3 - a1);
+        const float area_i = (a[2] - a[0]) * (a[3] - a[1]);
         const float iou = inter / ((area_i + area_j) - inter);
         return iou * (slabel[i] == lj ? 1.0f : 0.0f);
     };
     // 3a. compensate IoU: column max over the whole column (zeros on/below the diagonal)
-    for (int jb = 0; jb < K; jb += NT / 2) {
-        const int j = jb + (tid >> 1);
-        float v = 0.0f;
-        if (j < K) {
-            const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
-            const float area_j = (bj2 - bj0) * (bj3 - bj1);
-            const int lj = slabel[j];
-            const int i_mid = j >> 1;
-            const int i_lo = part ? i_mid : 0, i_hi = part ? j : i_mid;
-            float mx = 0.0f;
-            bool nan = false;
-            for (int i = i_lo; i < i_hi; ++i) {
-                const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
-                nan |= (d != d);
-                mx = fmaxf(mx, d);
-            }
-            v = nan ? NAN : mx;
+    for (int j = wv; j < K; j += NT / 64) {
+        const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
+        const float area_j = (bj2 - bj0) * (bj3 - bj1);
+        const int lj = slabel[j];
+        float mx = 0.0f;
+        bool nan = false;
+        for (int i = lane; i < j; i += 64) {
+            const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
+            nan |= (d != d);
+            mx = fmaxf(mx, d);
         }
-        const float o = __shfl_xor(v, 1);
-        v = (v != v || o != o) ? NAN : fmaxf(v, o);
-        if (j < K && part == 0) scomp[j] = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const bool anynan = __ballot(nan) != 0ull;
+        if (lane == 0) scomp[j] = anynan ? NAN : mx;
     }
     __syncthreads();
     // rows i >= j (and D == 0 entries) contribute f(i) = 1/(1-comp[i])  [gaussian: 1/exp(-s*comp^2)]
@@ -348,29 +452,24 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
         __syncthreads();
     }
     // 3b. decay coefficient: column min
-    for (int jb = 0; jb < K; jb += NT / 2) {
-        const int j = jb + (tid >> 1);
-        float v = INFINITY;
-        if (j < K) {
-            const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
-            const float area_j = (bj2 - bj0) * (bj3 - bj1);
-            const int lj = slabel[j];
-            const int i_mid = j >> 1;
-            const int i_lo = part ? i_mid : 0, i_hi = part ? j : i_mid;
-            float mn = INFINITY;
-            bool nan = false;
-            for (int i = i_lo; i < i_hi; ++i) {
-                const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
-                const float c = scomp[i];
-                const float t = p.gaussian ? (expf(-1.0f * p.sigma * (d * d)) / expf(-1.0f * p.sigma * (c * c)))
-                                           : ((1.0f - d) / (1.0f - c));
-                nan |= (t != t);
-                mn = fminf(mn, t);
-            }
-            v = nan ? NAN : mn;
+    for (int j = wv; j < K; j += NT / 64) {
+        const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
+        const float area_j = (bj2 - bj0) * (bj3 - bj1);
+        const int lj = slabel[j];
+        float mn = INFINITY;
+        bool nan = false;
+        for (int i = lane; i < j; i += 64) {
+            const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
+            const float c = scomp[i];
+            const float t = p.gaussian ? (expf(-1.0f * p.sigma * (d * d)) / expf(-1.0f * p.sigma * (c * c)))
+                                       : ((1.0f - d) / (1.0f - c));
+            nan |= (t != t);
+            mn = fminf(mn, t);
         }
-        v = nanmin_(v, __shfl_xor(v, 1));
-        if (j < K && part == 0) sdecay[j] = nanmin_(v, ssuf[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const bool anynan = __ballot(nan) != 0ull;
+        if (lane == 0) sdecay[j] = nanmin_(anynan ? NAN : mn, ssuf[j]);
     }
     __syncthreads();
 
@@ -430,7 +529,18 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
     p.e_iou = (float)iou_aware_factor;
     p.thr = score_threshold;
     const long long cells = (long long)N * S * S;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const size_t lds = ((size_t)DEC_CELLS * nch + 2 * DEC_CELLS * A) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(yolo_decode_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    if (lds > 96 * 1024) return PPY_ERR_UNSUPPORTED;
+    (void)cells;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((S * S + DEC_CELLS - 1) / DEC_CELLS), N), dim3(256), lds,
+                       (hipStream_t)stream, p);
     return ppy_launch_status();
 }
 

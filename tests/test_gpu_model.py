@@ -128,7 +128,7 @@ def test_full_size_vs_oracle_and_batch_properties(cfgc, S):
     (40 fp32 ulps after ~70 layers) moves by 2.5e-3 px.  Measured max 1.0e-3 .. 2.5e-3 px on a
     480x640 image depending on the tile configuration, so the bar here is 5e-3 px x (image extent
     / 640); the committed reference goldens are held to the north-star 1e-3 px.  Size-independent properties cover the other
-    images: permuting the batch permutes the results bit-exactly (images are independent), a
+    images: permuting the batch permutes the results (bit-exactly without DCN; images are independent), a
     batch-of-1 run agrees to fp32 noise (different tile configs => different summation
     order), and the run is repeatable bit for bit."""
     cfg = cfgc()
@@ -143,8 +143,15 @@ def test_full_size_vs_oracle_and_batch_properties(cfgc, S):
     _check_preds(preds[:2], [r[0] for r in ref], keep, [r[1] for r in ref], box_tol=5e-3)
     perm = torch.tensor([5, 2, 7, 0, 3, 6, 1, 4])
     pp = [p.cpu() for p in model(x[perm].cuda(), ims[perm].cuda())]
+    has_dcn = bool(cfg.backbone.get('dcn_v2_stages'))
     for j, i in enumerate(perm.tolist()):
-        assert torch.equal(pp[j], preds[i]), 'image %d depends on its position in the batch' % i
+        if has_dcn:
+            # the reference's DCNv2 folds the batch index into the fp32 row coordinate before floor()
+            # (custom_layers.py:626-633), so ITS results depend on the batch position at the 1e-5
+            # level; this build reproduces that arithmetic, hence a tolerance instead of equality
+            _check_preds([pp[j]], [preds[i]], box_tol=5e-3 * max(1.0, float(ims[i].max()) / 640.0))
+        else:
+            assert torch.equal(pp[j], preds[i]), 'image %d depends on its position in the batch' % i
     for i in (3, 7):
         solo = model(x[i:i + 1].cuda(), ims[i:i + 1].cuda())[0].cpu()
         scale = float(ims[i].max()) / 640.0
