@@ -189,7 +189,7 @@ def main():
     ex.run()
     torch.cuda.synchronize()
     if a.autotune:
-        ex.autotune(iters=3)
+        ex.autotune(iters=5)
         if a.save_tuning and rank == 0:
             ex.save_tuning(a.save_tuning)
     ex.use_graph = not a.no_graph
