@@ -226,9 +226,19 @@ def main():
         total_flops, per_op = conv_flops(ex.plan)
         conv_ms, covered, nconv = timed_conv_pass(ex, per_op)
         achieved = covered / (conv_ms * 1e-3) / 1e12
+        # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
+        # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if a.workload == 'r50vd_608' and a.batch == 8 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)['hbm_bytes_per_step'] / nconv)
         roof = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                    kernel='conv_igemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM), %d launches/step' % nconv,
+                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    traffic_unit='bytes per launch (mean over the conv launches of a step; PMC '
+                                 '2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)',
+                    kernel='conv_igemm_glds_kernel<*> / conv_igemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM), '
+                           '%d launches/step' % nconv,
                     flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
                     whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
         out = dict(metric='images/sec PPYOLO R50-vd 608x608 bs=8' if a.workload == 'r50vd_608'
