@@ -67,9 +67,13 @@ class DetectionBlock(torch.nn.Module):
                 coord = False
         return x
 
-    def emit(self, b, x):
+    def emit(self, b, x, tip_on_side=False):
         route = self._walk(b, self.layers, x)
-        tip = self._walk(b, self.tip_layers, route)
+        if tip_on_side:
+            with b.side():
+                tip = self._walk(b, self.tip_layers, route)
+        else:
+            tip = self._walk(b, self.tip_layers, route)
         return route, tip
 
 
@@ -151,8 +155,13 @@ class YOLOv3Head(torch.nn.Module):
         outs = []
         for i, blk in enumerate(blocks):
             x = blk if i == 0 else self._concat[i]
-            route, tip = self.detection_blocks[i].emit(b, x)
-            outs.append(self.yolo_output_convs[i].emit(b, tip))
+            last = (i == n_lvl - 1)
+            route, tip = self.detection_blocks[i].emit(b, x, tip_on_side=not last)
+            if last:
+                outs.append(self.yolo_output_convs[i].emit(b, tip))
+            else:
+                with b.side():      # tip -> output conv of this level runs beside the next level's chain
+                    outs.append(self.yolo_output_convs[i].emit(b, tip))
             if i < n_lvl - 1:
                 nxt = self._concat[i + 1]
                 rc = self.route_channels(i + 1)

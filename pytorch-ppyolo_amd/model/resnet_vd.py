@@ -34,8 +34,9 @@ class ConvBlock(torch.nn.Module):
                                 name=block_name + '_branch1', **kw)
 
     def emit(self, b, x, out=None):
-        s = x if self.is_first else b.avgpool(x)
-        s = self.conv4.emit(b, s)
+        with b.side():              # projection shortcut: independent of conv1 -> conv2
+            s = x if self.is_first else b.avgpool(x)
+            s = self.conv4.emit(b, s)
         y = self.conv1.emit(b, x)
         y = self.conv2.emit(b, y)
         y = self.conv3.emit(b, y, res=s, out=out, post_act='relu')      # relu(bn(conv) + shortcut)
@@ -138,8 +139,9 @@ class BasicBlock(torch.nn.Module):
 
     def emit(self, b, x, out=None):
         if self.conv3 is not None:
-            s = x if self.is_first else b.avgpool(x)
-            s = self.conv3.emit(b, s)
+            with b.side():
+                s = x if self.is_first else b.avgpool(x)
+                s = self.conv3.emit(b, s)
         else:
             s = x
         y = self.conv1.emit(b, x)

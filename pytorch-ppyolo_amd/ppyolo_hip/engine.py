@@ -83,6 +83,7 @@ class Builder(object):
         self.plan = Plan(N, H, W)
         self.device = device
         self._coord_cache = {}
+        self._stream = 0
 
     # ---- buffers -------------------------------------------------------------------------
     def new_buf(self, N, H, W, ld):
@@ -96,7 +97,25 @@ class Builder(object):
         return A(a.buf, a.coff + coff, C, a.N, a.H, a.W)
 
     def _emit(self, op, setup=False):
+        if not setup:
+            op['stream'] = self._stream
         (self.plan.setup_ops if setup else self.plan.ops).append(op)
+
+    def side(self):
+        """Context manager: ops emitted inside form an independent branch (projection shortcut,
+        head tip/output convs) that the executor may run on a second HIP stream, concurrently with
+        the main chain -- per-layer launches at batch 8 leave CUs idle (tile quantisation, short
+        tails), a second kernel's workgroups fill them."""
+        b = self
+
+        class _Side(object):
+            def __enter__(self_inner):
+                self_inner.prev = b._stream
+                b._stream = 1
+
+            def __exit__(self_inner, *a):
+                b._stream = self_inner.prev
+        return _Side()
 
     # ---- ops -----------------------------------------------------------------------------
     def stem(self, weight, scale, shift, act='relu'):
@@ -223,7 +242,14 @@ class HipExecutor(object):
             if op['op'] in ('conv', 'dcn') and op['cfg'] < 0 and tune_key(op) in tab:
                 op['cfg'], op['splitk'] = tab[tune_key(op)][:2]
         self.ws = None
+        self.ws_side = None
         self._size_workspace()
+        # measured on MI355X: running the independent branches on a second stream is neutral-to-slightly
+        # negative (R50-608 bs8: 923 vs 932 img/s), so it is opt-in (PPYOLO_HIP_STREAMS=2)
+        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' and any(
+            op.get('stream', 0) for op in p.ops)
+        self.side_stream = torch.cuda.Stream(device=self.device) if self.multi_stream else None
+        self._build_sync_plan()
         with torch.cuda.device(self.device):
             for op in p.setup_ops:
                 self._run_op(op)
@@ -252,20 +278,66 @@ class HipExecutor(object):
         return 0
 
     def _size_workspace(self):
-        need = 16
+        need, need_side = 16, 16
         for op in self.plan.setup_ops + self.plan.ops:
-            need = max(need, self._ws_need(op))
+            if op.get('stream', 0):
+                need_side = max(need_side, self._ws_need(op))
+            else:
+                need = max(need, self._ws_need(op))
         if self.ws is None or self.ws.numel() * 4 < need:
             self.ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+        if self.ws_side is None or self.ws_side.numel() * 4 < need_side:      # concurrent branch: own scratch
+            self.ws_side = torch.empty(((need_side + 3) // 4,), dtype=torch.float32, device=self.device)
 
-    def _run_op(self, op):
+    @staticmethod
+    def _op_io(op):
+        """(input buffer ids, output buffer ids) of a plan op."""
         t = op['op']
+        if t == 'conv':
+            ins = [op['x'].buf] + ([op['res'].buf] if op['res'] is not None else [])
+            return ins, [op['y'].buf]
+        if t == 'stem':
+            return [], [op['y'].buf]
+        if t in ('maxpool', 'avgpool'):
+            return [op['x'].buf], [op['y'].buf]
+        if t == 'spp':
+            return [op['x'].buf], [op['y5'].buf]
+        if t == 'dcn':
+            return [op['x'].buf, op['om'].buf], [op['y'].buf]
+        raise PPYoloHipError('unknown plan op %r' % t)
+
+    def _build_sync_plan(self):
+        """Cross-stream dependencies, derived once: an op waits for every earlier writer of a buffer
+        it reads that ran on the other stream (buffers are never reused, concat buffers have
+        several writers of disjoint slices -> wait for all of them)."""
+        ops = self.plan.ops
+        writers = {}
+        self._waits = [[] for _ in ops]          # op index -> producer op indices on the other stream
+        self._needs_event = set()
+        for i, op in enumerate(ops):
+            ins, outs = self._op_io(op)
+            s = op.get('stream', 0) if self.multi_stream else 0
+            for bid in ins:
+                for j in writers.get(bid, []):
+                    sj = ops[j].get('stream', 0) if self.multi_stream else 0
+                    if sj != s and j not in self._waits[i]:
+                        self._waits[i].append(j)
+                        self._needs_event.add(j)
+            for bid in outs:
+                writers.setdefault(bid, []).append(i)
+        # tail of the side stream must be joined before decode / the end of the step
+        self._side_tail = max([i for i, op in enumerate(ops) if op.get('stream', 0)], default=None) \
+            if self.multi_stream else None
+
+    def _run_op(self, op, ws=None):
+        t = op['op']
+        ws = self.ws if ws is None else ws
         if t == 'conv':
             posb = op['posb']
             K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
-                            self.ws)
+                            ws)
         elif t == 'stem':
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
         elif t == 'maxpool':
@@ -276,7 +348,7 @@ class HipExecutor(object):
             K.spp(self.view(op['x']), self.view(op['y5']), self.view(op['y9']), self.view(op['y13']))
         elif t == 'dcn':
             K.dcnv2(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['om']), self.view(op['y']),
-                    op['stride'], op['pad'], op['act'], self.ws, op['cfg'], op['splitk'])
+                    op['stride'], op['pad'], op['act'], ws, op['cfg'], op['splitk'])
         else:
             raise PPYoloHipError('unknown plan op %r' % t)
 
@@ -295,8 +367,29 @@ class HipExecutor(object):
                      self.out_dets, self.out_count, self.out_keep)
 
     def _launch_all(self):
-        for op in self.plan.ops:
-            self._run_op(op)
+        if not self.multi_stream:
+            for op in self.plan.ops:
+                self._run_op(op)
+        else:
+            main = torch.cuda.current_stream()
+            side = self.side_stream
+            events = {}
+            for i, op in enumerate(self.plan.ops):
+                on_side = bool(op.get('stream', 0))
+                st = side if on_side else main
+                for j in self._waits[i]:
+                    st.wait_event(events[j])
+                if on_side:
+                    with torch.cuda.stream(side):
+                        self._run_op(op, self.ws_side)
+                else:
+                    self._run_op(op)
+                if i in self._needs_event or i == self._side_tail:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    events[i] = ev
+            if self._side_tail is not None:
+                main.wait_event(events[self._side_tail])      # join
         if self.plan.decode is not None:
             self._run_decode()
 
