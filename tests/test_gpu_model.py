@@ -196,3 +196,17 @@ def test_autotuned_plan_same_answer():
     assert len(rep) > 10
     tuned = model(x, ims)
     _check_preds([t.cpu() for t in tuned], [b.cpu() for b in base])
+
+
+@pytest.mark.parametrize('cfgc,S,N', [(PPYOLO_r18vd_Config, 352, 3), (PPYOLO_2x_Config, 224, 1), (PPYOLO_2x_Config, 288, 5)])
+def test_other_input_sizes_use_heuristic_configs(cfgc, S, N):
+    """Shapes that are NOT in the measured tile table (tuned_gfx950.json) fall back to the cost
+    model inside the library; results must still match the oracle."""
+    cfg = cfgc()
+    model, sd = build_model(cfg, 0, 'cuda')
+    x = synth.synth_images(N, S, seed=77)
+    ims = torch.tensor([[480., 640.], [375., 500.], [608., 608.], [333., 500.], [500., 375.]])[:N]
+    preds = [p.cpu() for p in model(x.cuda(), ims.cuda())]
+    dets, cnt, keep = model.forward_padded(x.cuda(), ims.cuda())
+    ref = orc.ppyolo_forward(sd, cfg, x, ims, return_index=True)
+    _check_preds(preds, [r[0] for r in ref], keep.clone(), [r[1] for r in ref], box_tol=3e-3)
