@@ -164,10 +164,17 @@ def main():
                     'committed tuned_gfx950.json table')
     ap.add_argument('--save-tuning', default=None, help='write the measured table to this JSON file')
     ap.add_argument('--layer-report', default=None, help='write per-launch timings to this JSON file')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); "gloo" '
+                    'together with --share-gpu lets the N>1 code path be smoke-tested on a 1-GPU box')
+    ap.add_argument('--share-gpu', action='store_true', help='all ranks use cuda:0 (smoke test only)')
     a = ap.parse_args()
 
     from ppyolo_hip import dist as pd
-    rank, world, local = pd.init_from_env()
+    if a.share_gpu:
+        os.environ['LOCAL_RANK_REAL'] = os.environ.get('LOCAL_RANK', '0')
+    rank, world, local = pd.init_from_env(a.backend if not a.share_gpu else (a.backend or 'gloo'))
+    if a.share_gpu:
+        local = 0
     if world != a.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     if not torch.cuda.is_available():

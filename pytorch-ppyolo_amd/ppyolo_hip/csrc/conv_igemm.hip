@@ -494,16 +494,61 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
 #endif
 }
 
-// Deterministic split-K combine (fixed z order) + the same epilogue.
+// Deterministic split-K combine (fixed z order) + the same epilogue.  VEC: one 16-byte column
+// group per thread (every load independent, 16-byte accesses); otherwise one element per thread.
+template <bool VEC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, int splits) {
+    constexpr int W = VEC ? 4 : 1;
     const long long total = (long long)p.M * p.K;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / p.K), col = (int)(i - (long long)m * p.K);
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W;
+    if (i >= total) return;
+    const int m = (int)(i / p.K), col = (int)(i - (long long)m * p.K);
+    if constexpr (VEC) {
+        floatx4 v = *reinterpret_cast<const floatx4 *>(p.part + i);
+        for (int z = 1; z < splits; ++z) {
+            const floatx4 o = *reinterpret_cast<const floatx4 *>(p.part + (long long)z * total + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += o[u];
+        }
+        const floatx4 sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
+        const floatx4 sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
+        if (p.posb) {
+            const floatx4 pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % (p.Ho * p.Wo)) * p.K + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += pb[u];
+        }
+        floatx4 r = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ppy_apply_act(fmaf(v[u], sc[u], sh[u]) + (p.res ? r[u] : 0.f), p.act);
+        if (!p.ups) {
+            *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
+        } else {
+            const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const long long W2 = 2LL * p.Wo;
+            float *o = p.y + (((long long)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + col;
+            *reinterpret_cast<floatx4 *>(o) = v;
+            *reinterpret_cast<floatx4 *>(o + p.y_ld) = v;
+            *reinterpret_cast<floatx4 *>(o + W2 * p.y_ld) = v;
+            *reinterpret_cast<floatx4 *>(o + (W2 + 1) * p.y_ld) = v;
+        }
+    } else {
         float v = p.part[i];
         for (int z = 1; z < splits; ++z) v += p.part[(long long)z * total + i];
         epilogue_store(p, m, col, v, p.scale[col], p.shift[col]);
     }
+}
+
+// launch helper shared by both conv kernels
+inline void launch_splitk_reduce(const ConvArgs &p, int splits, bool vec, hipStream_t stream) {
+    const long long total = (long long)p.M * p.K;
+    const long long threads = vec ? total / 4 : total;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (vec)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, stream, p, splits);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(grid), dim3(256), 0, stream, p, splits);
 }
 
 struct TileCfg {
@@ -580,9 +625,7 @@ int launch_cfg(const ConvArgs &p, int splits, hipStream_t stream) {
         rc = vec ? launch_one<BM, BN, WM, WN, true, true>(p, splits, lds, tiles, stream)
                  : launch_one<BM, BN, WM, WN, true, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
-        const long long total = (long long)p.M * p.K;
-        const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, p, splits);
+        launch_splitk_reduce(p, splits, vec, stream);
     } else {
         rc = vec ? launch_one<BM, BN, WM, WN, false, true>(p, splits, lds, tiles, stream)
                  : launch_one<BM, BN, WM, WN, false, false>(p, splits, lds, tiles, stream);
@@ -622,9 +665,7 @@ int launch_glds(const ConvArgs &p, int splits, hipStream_t stream) {
         rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, true, true>(p, splits, lds, tiles, stream)
                  : launch_glds_one<BM, BN, WM, WN, STAGES, true, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
-        const long long total = (long long)p.M * p.K;
-        const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, p, splits);
+        launch_splitk_reduce(p, splits, vec, stream);
     } else {
         rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, false, true>(p, splits, lds, tiles, stream)
                  : launch_glds_one<BM, BN, WM, WN, STAGES, false, false>(p, splits, lds, tiles, stream);

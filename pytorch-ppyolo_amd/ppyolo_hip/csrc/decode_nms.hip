@@ -174,62 +174,60 @@ __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
     }
     __syncthreads();
 
-    // ---- phase 3: one wave per (cell, anchor) sweeps the class logits ----
-    // Two sweeps: (a) count this workgroup's candidates, ONE global atomic per workgroup reserves
-    // their slots (a returning atomic per wave on the image's single counter serialised at ~90
-    // atomics/us and dominated the kernel), (b) recompute and write.  A workgroup never spans two
-    // images (grid = N x blocks-per-image).
-    __shared__ int s_wcnt[4], s_wbase[4];
+    // ---- phase 3: the same thread sweeps its box's class logits against the bound ----
+    // A logit above the bound is rare (it is exactly the candidate condition up to the safety
+    // margin), so the sweep is a read + compare per class; survivors get the exact fp32 score and
+    // the exact `score > thr` test and go to a workgroup-local list in LDS.  ONE global atomic
+    // per workgroup then reserves the slots (a returning atomic per wave on the image's single
+    // counter serialised at ~90 atomics/us and dominated an earlier version).  A workgroup never
+    // spans two images (grid = blocks-per-image x N).
+    constexpr int LCAP = 1536;
+    __shared__ uint32_t l_key[LCAP], l_idx[LCAP];
+    __shared__ int l_n, l_base;
+    if (tid == 0) l_n = 0;
+    __syncthreads();
     const int n = blockIdx.y;
     uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
     uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
-    int running = 0;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        if (sweep == 1) {
-            if (lane == 0) s_wcnt[wv] = running;
-            __syncthreads();
-            if (tid == 0) {
-                const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-                int base = 0;
-                if (total > 0) base = atomicAdd(p.cand_count + n, total);
-                int acc = base;
-                for (int k = 0; k < 4; ++k) { s_wbase[k] = acc; acc += s_wcnt[k]; }
+    for (int q = tid; q < ncl * p.A; q += 256) {
+        const int c = q / p.A, a = q - c * p.A;
+        const float bound = s_bound[q];
+        if (bound == INFINITY && !p.scores_dense) continue;
+        const int cellw = cell_in_img0 + c;
+        const int w = cellw % p.S, h = cellw / p.S;
+        const int box = p.box_offset + (h * p.S + w) * p.A + a;
+        const float conf = s_conf[q];
+        const float *cl = vals + c * nch + off0 + a * per + 5;
+        for (int k = 0; k < p.C; ++k) {
+            const float lg = cl[k];
+            if (p.scores_dense || lg > bound) {
+                const float sc = conf * sigmoidf_(lg);
+                if (p.scores_dense) p.scores_dense[((long long)n * p.M_total + box) * p.C + k] = sc;
+                if (sc > p.thr) {
+                    const int pos = atomicAdd(&l_n, 1);
+                    if (pos < LCAP) {
+                        l_key[pos] = score_to_key(sc);
+                        l_idx[pos] = (uint32_t)(box * p.C + k);
+                    } else {                      // dense regime: list full, append straight to global
+                        const int g = atomicAdd(p.cand_count + n, 1);
+                        if (g < p.cand_cap) {
+                            ckey[g] = score_to_key(sc);
+                            cidx[g] = (uint32_t)(box * p.C + k);
+                        }
+                    }
+                }
             }
-            __syncthreads();
-            running = s_wbase[wv];
         }
-        for (int q = wv; q < ncl * p.A; q += 4) {
-            const int c = q / p.A, a = q - c * p.A;
-            const float bound = s_bound[q];
-            const bool dense = (p.scores_dense != nullptr) && sweep == 1;
-            if (!dense && bound == INFINITY) continue;      // wave-uniform
-            const int cellw = cell_in_img0 + c;
-            const int w = cellw % p.S, h = cellw / p.S;
-            const int box = p.box_offset + (h * p.S + w) * p.A + a;
-            const float conf = s_conf[q];
-            const float *cl = vals + c * nch + off0 + a * per + 5;
-            for (int c0 = 0; c0 < p.C; c0 += 64) {
-                const int k = c0 + lane;
-                float s = 0.f;
-                bool pass = false;
-                if (k < p.C) {
-                    const float lg = cl[k];
-                    if (dense || lg > bound) {
-                        s = conf * sigmoidf_(lg);
-                        pass = s > p.thr;
-                        if (dense) p.scores_dense[((long long)n * p.M_total + box) * p.C + k] = s;
-                    }
-                }
-                const unsigned long long bal = __ballot(pass);
-                if (sweep == 1 && pass) {
-                    const int pos = running + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pos < p.cand_cap) {
-                        ckey[pos] = score_to_key(s);
-                        cidx[pos] = (uint32_t)(box * p.C + k);
-                    }
-                }
-                running += __popcll(bal);
-            }
+    }
+    __syncthreads();
+    const int nl = min(l_n, LCAP);
+    if (tid == 0 && nl > 0) l_base = atomicAdd(p.cand_count + n, nl);
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) {
+        const int g = l_base + i;
+        if (g < p.cand_cap) {
+            ckey[g] = l_key[i];
+            cidx[g] = l_idx[i];
         }
     }
 }
