@@ -37,6 +37,7 @@ struct ConvArgs {
     int x_ld, res_ld, y_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
     int M, Kred, cchunks, chunks_total, chunks_per_split;
+    unsigned long long *trace;   // debug: per-workgroup timeline (ppy_debug_set_trace), NULL in production
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs &p, int m, int col, float v,
@@ -369,6 +370,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
     const int kc_begin = split * p.chunks_per_split;
     const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
     const int nchunks = kc_end - kc_begin;
+    unsigned long long t_start = 0;
+    if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
 
     // ---- per-lane DMA source offsets (bytes), fixed for the whole tile ----
     const int drow = lane >> 3, dslot = lane & 7;
@@ -491,6 +494,16 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
         __builtin_amdgcn_s_barrier();
     }
     tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, smem, m0, n0, wm, wn, lane, wave, split);
+    if (p.trace && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        p.trace[b * 4 + 0] = t_start;
+        p.trace[b * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.trace[b * 4 + 2] = hwid | ((unsigned long long)xcc << 32);
+        p.trace[b * 4 + 3] = 0;
+    }
 #endif
 }
 
@@ -768,6 +781,11 @@ extern "C" size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st);
+static unsigned long long *g_trace = nullptr;
+// Debug hook (deliberately not in the public header): the LDS-DMA kernel writes {start, end} (100 MHz
+// real-time counter), HW_ID and XCC_ID of every workgroup of the following launches to `buf`
+// (4 x u64 per workgroup); tools/conv_trace.py turns that into a per-CU timeline.
+extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 
 extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
                                      const float *shift, const float *residual, int res_ld,
@@ -796,6 +814,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     p.stride = stride; p.pad = pad; p.act = act; p.ups = upsample2x ? 1 : 0;
     p.M = g.M; p.Kred = g.Kred; p.cchunks = C / BK; p.chunks_total = g.chunks;
     p.chunks_per_split = ceil_div(g.chunks, s);
+    p.trace = g_trace;
     hipStream_t st = (hipStream_t)stream;
     rc = dispatch_cfg(p, c, s, st);
     if (rc == PPY_ERR_UNSUPPORTED && c >= 14) {

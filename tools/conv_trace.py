@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Per-workgroup timeline of one conv launch (debug hook ppy_debug_set_trace).
+usage: conv_trace.py "N,H,W,C,K,R,stride[,res]" cfg splitk"""
+import ctypes, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'pytorch-ppyolo_amd'))
+import torch
+from ppyolo_hip import ops, _lib
+
+shp = [int(v) for v in sys.argv[1].split(',')]
+N, H, W, C, K, R, stride = shp[:7]
+cfg, splitk = int(sys.argv[2]), int(sys.argv[3])
+pad = (R - 1) // 2
+Ho, Wo = ops.conv_out_hw(H, W, R, R, stride, pad)
+x = torch.randn(N, H, W, C, device='cuda'); w = torch.randn(K, R, R, C, device='cuda') * 0.05
+sc, sh = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
+y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device='cuda')
+tr = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
+L = _lib.lib()._handle
+lib = ctypes.CDLL(_lib.LIB_PATH)
+def run():
+    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws)
+for _ in range(3): run()
+torch.cuda.synchronize()
+lib.ppy_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
+run(); torch.cuda.synchronize()
+lib.ppy_debug_set_trace(ctypes.c_void_p(0))
+t = tr.cpu().view(-1, 4)
+t = t[t[:, 1] != 0]
+nb = t.shape[0]
+t0 = int(t[:, 0].min())
+start = (t[:, 0] - t0).double() / 100.0   # readcyclecounter ticks at 100 MHz -> us
+end = (t[:, 1] - t0).double() / 100.0
+print('blocks', nb, 'span %.1f us' % end.max().item(), 'mean block duration %.1f us' % (end - start).mean().item())
+hw = t[:, 2] & 0xffffffff
+cu = (hw >> 8) & 0xf; sh_ = (hw >> 12) & 1; se = (hw >> 13) & 0x7; xcc = (t[:, 2] >> 32) & 0xf
+cuid = (xcc * 8 + se) * 32 + sh_ * 16 + cu
+per = collections.defaultdict(list)
+for i in range(nb): per[int(cuid[i])].append((start[i].item(), end[i].item()))
+print('distinct CU ids', len(per), ' blocks per CU: min %d max %d' % (min(len(v) for v in per.values()), max(len(v) for v in per.values())))
+# histogram of start times
+import numpy as np
+st = np.sort(start.numpy()); en = np.sort(end.numpy())
+print('start pct 0/25/50/75/100:', np.percentile(st, [0, 25, 50, 75, 100]).round(1))
+print('end   pct 0/25/50/75/100:', np.percentile(en, [0, 25, 50, 75, 100]).round(1))
+dur = (end - start).numpy()
+order = np.argsort(start.numpy())
+q = len(order) // 4
+for k in range(4):
+    sel = order[k * q:(k + 1) * q]
+    print('  start-quartile %d: mean duration %.1f us' % (k, dur[sel].mean()))
+# active blocks over time
+T = np.linspace(0, en.max(), 21)
+act = [(int(((start.numpy() <= tt) & (end.numpy() > tt)).sum())) for tt in T]
+print('active workgroups over time:', act)
