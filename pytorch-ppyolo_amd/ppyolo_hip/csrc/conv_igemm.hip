@@ -343,17 +343,23 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+//  * BKT = reduction depth of one pipeline stage (32 or 16 channels of one tap).  16 halves the LDS per
+//    stage (128x128 tile: 16 KB) so that 3-4 workgroups fit on a CU; a DMA instruction then covers
+//    16 rows x 64 B and the swizzle is c ^ ((r>>2)&3) over the 4 slots of a row.
+template <int BM, int BN, int WM, int WN, int STAGES, int BKT, bool SPLIT, bool VEC>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only builtins (buffer descriptor, LDS DMA)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "8 tile rows per wave DMA instruction");
-    constexpr int A_PASS = BM / (8 * NW), B_PASS = BN / (8 * NW);
+    static_assert(BKT == 32 || BKT == 16, "stage depth");
+    constexpr int SLOTS = BKT / 4;                 // 16-byte slots per tile row
+    constexpr int RPI = 64 / SLOTS;                // tile rows per wave DMA instruction (1 KB)
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "whole DMA instructions per wave");
+    constexpr int A_PASS = BM / (RPI * NW), B_PASS = BN / (RPI * NW);
     constexpr int G = A_PASS + B_PASS;             // DMA instructions per wave per chunk
-    constexpr int STAGE = (BM + BN) * BK;          // floats per pipeline stage
+    constexpr int STAGE = (BM + BN) * BKT;         // floats per pipeline stage
     static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
     typedef __attribute__((address_space(3))) void *lds_ptr;
 
@@ -374,15 +380,16 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
     if (p.trace) t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
 
     // ---- per-lane DMA source offsets (bytes), fixed for the whole tile ----
-    const int drow = lane >> 3, dslot = lane & 7;
+    const int drow = lane / SLOTS, dslot = lane % SLOTS;
+    auto swz = [](int row) { return BKT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
     const int hw = p.Ho * p.Wo;
     const unsigned OOB = 0xFFFFFFF0u;
     const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
     unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
-        const int row = (j * NW + wave) * 8 + drow;         // row inside the tile
-        const int scol = dslot ^ ((row >> 1) & 7);          // source 16-byte column for this slot
+        const int row = (j * NW + wave) * RPI + drow;       // row inside the tile
+        const int scol = dslot ^ swz(row);                  // source 16-byte column for this slot
         const int mr = m0 + row;
         const int m = min(mr, p.M - 1);
         const int n = m / hw, rem = m - n * hw;
@@ -400,8 +407,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
-        const int row = (j * NW + wave) * 8 + drow;
-        const int scol = dslot ^ ((row >> 1) & 7);
+        const int row = (j * NW + wave) * RPI + drow;
+        const int scol = dslot ^ swz(row);
         const int k = min(n0 + row, p.K - 1);
         b_off[j] = (unsigned)((long long)k * p.Kred * 4 + scol * 16);
     }
@@ -413,20 +420,20 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
     const char *wb = reinterpret_cast<const char *>(p.w);
 
     auto issue = [&](int stage) {
-        const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * BK) * 4;
-        const long long b_uni = ((long long)l_tap * p.C + l_cc * BK) * 4;
+        const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * BKT) * 4;
+        const long long b_uni = ((long long)l_tap * p.C + l_cc * BKT) * 4;
         __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + a_uni), 0, 0xFFFFFF00u, 0x00020000);
         __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + b_uni), 0, 0xFFFFFF00u, 0x00020000);
         float *sA = smem + stage * STAGE;
-        float *sB = sA + BM * BK;
+        float *sB = sA + BM * BKT;
 #pragma unroll
         for (int j = 0; j < A_PASS; ++j) {
             const unsigned off = ((a_ok[j] >> l_tap) & 1u) ? a_off[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sA + (j * NW + wave) * 8 * BK), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sA + (j * NW + wave) * RPI * BKT), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_PASS; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sB + (j * NW + wave) * 8 * BK), 16, b_off[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sB + (j * NW + wave) * RPI * BKT), 16, b_off[j], 0, 0, 0);
         ++l_tap;
         ++l_s;
         if (l_s == p.S) { l_s = 0; ++l_r; }
@@ -442,26 +449,26 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment read offsets: row (lane&31), 16-byte slot ((2q + lane>>5) ^ swizzle(row))
-    const int frow = lane & 31, fsw = (frow >> 1) & 7, fkh = lane >> 5;
-    int foff[BK / 8];
+    const int frow = lane & 31, fsw = swz(frow), fkh = lane >> 5;
+    int foff[BKT / 8];
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) foff[q] = frow * BK + (((2 * q + fkh) ^ fsw) << 2);
+    for (int q = 0; q < BKT / 8; ++q) foff[q] = frow * BKT + (((2 * q + fkh) ^ fsw) << 2);
 
     auto compute = [&](int stage) {
-        const float *a_ptr = smem + stage * STAGE + wm * WM * BK;
-        const float *b_ptr = smem + stage * STAGE + BM * BK + wn * WN * BK;
+        const float *a_ptr = smem + stage * STAGE + wm * WM * BKT;
+        const float *b_ptr = smem + stage * STAGE + BM * BKT + wn * WN * BKT;
         // all fragment reads of the chunk are issued up front (distinct registers), so the MFMA
         // chain only waits on counted lgkmcnt instead of a read -> wait -> 4 MFMA lock-step
-        floatx4 a[BK / 8][TM], b[BK / 8][TN];
+        floatx4 a[BKT / 8][TM], b[BKT / 8][TN];
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
+        for (int q = 0; q < BKT / 8; ++q) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * BK + foff[q]);
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * BKT + foff[q]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const floatx4 *>(b_ptr + j * 32 * BK + foff[q]);
+            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const floatx4 *>(b_ptr + j * 32 * BKT + foff[q]);
         }
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q)
+        for (int q = 0; q < BKT / 8; ++q)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -600,6 +607,12 @@ constexpr GldsCfg kGlds[] = {
     {128, 32, 32, 32, 3},    // 23
     {32, 128, 32, 32, 3},    // 24
     {256, 64, 64, 32, 2},    // 25  (8 waves)
+    // stage depth 16 (BKT): [26,31)
+    {128, 128, 64, 64, 2},   // 26  4 waves, 32 KB
+    {128, 128, 64, 64, 3},   // 27  4 waves, 48 KB
+    {128, 128, 64, 32, 3},   // 28  8 waves, 48 KB
+    {128, 64, 64, 32, 3},    // 29  4 waves, 36 KB
+    {64, 64, 32, 32, 3},     // 30  4 waves, 24 KB
 };
 constexpr int kNumGlds = sizeof(kGlds) / sizeof(kGlds[0]);
 constexpr int kNumCfgs = 14 + kNumGlds;
@@ -647,9 +660,9 @@ int launch_cfg(const ConvArgs &p, int splits, hipStream_t stream) {
     return ppy_launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+template <int BM, int BN, int WM, int WN, int STAGES, int BKT, bool SPLIT, bool VEC>
 int launch_glds_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = conv_igemm_glds_kernel<BM, BN, WM, WN, STAGES, SPLIT, VEC>;
+    auto k = conv_igemm_glds_kernel<BM, BN, WM, WN, STAGES, BKT, SPLIT, VEC>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -661,27 +674,31 @@ int launch_glds_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStr
     return PPY_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
-int launch_glds(const ConvArgs &p, int splits, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int STAGES, int BKT = BK>
+int launch_glds(ConvArgs p, int splits, hipStream_t stream) {
     // the per-lane DMA offsets are 32-bit: tensors must stay below 4 GB (- margin)
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
     const long long wbytes = (long long)p.K * p.Kred * 4;
     if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
     constexpr int NW = (BM / WM) * (BN / WN);
-    size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(float);
+    size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(float);
     const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
+    // chunk bookkeeping in units of this configuration's stage depth
+    p.chunks_total = p.R * p.S * (p.C / BKT);
+    p.chunks_per_split = ceil_div(p.chunks_total, splits);
+    splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
     const bool vec = vec_epilogue_ok(p);
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, true, true>(p, splits, lds, tiles, stream)
-                 : launch_glds_one<BM, BN, WM, WN, STAGES, true, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, BKT, true, true>(p, splits, lds, tiles, stream)
+                 : launch_glds_one<BM, BN, WM, WN, STAGES, BKT, true, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, false, true>(p, splits, lds, tiles, stream)
-                 : launch_glds_one<BM, BN, WM, WN, STAGES, false, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_glds_one<BM, BN, WM, WN, STAGES, BKT, false, true>(p, splits, lds, tiles, stream)
+                 : launch_glds_one<BM, BN, WM, WN, STAGES, BKT, false, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
@@ -852,6 +869,11 @@ static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 23: return launch_glds<128, 32, 32, 32, 3>(p, s, st);
         case 24: return launch_glds<32, 128, 32, 32, 3>(p, s, st);
         case 25: return launch_glds<256, 64, 64, 32, 2>(p, s, st);
+        case 26: return launch_glds<128, 128, 64, 64, 2, 16>(p, s, st);
+        case 27: return launch_glds<128, 128, 64, 64, 3, 16>(p, s, st);
+        case 28: return launch_glds<128, 128, 64, 32, 3, 16>(p, s, st);
+        case 29: return launch_glds<128, 64, 64, 32, 3, 16>(p, s, st);
+        case 30: return launch_glds<64, 64, 32, 32, 3, 16>(p, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

@@ -58,7 +58,7 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-@pytest.mark.parametrize('cfg', range(26))
+@pytest.mark.parametrize('cfg', range(31))
 @pytest.mark.parametrize('splitk', [1, 3])
 def test_conv_every_tile_config(cfg, splitk):
     """Each tile configuration / split-K path, with channel-sliced input & output buffers,
