@@ -315,3 +315,44 @@ def test_matrix_nms_ties_use_index_order():
     assert k == ref.shape[0]
     assert torch.equal(dets[0, :k], ref)
     assert np.array_equal(keep[0, :k].numpy().astype(np.int64), f)
+
+
+def test_conv_random_shapes_all_kernels():
+    """Seeded sweep over layer shapes x tile configurations x split-K (edge cases: M smaller than a
+    tile, K not a multiple of 4 -> scalar epilogue, stride 2 with odd sizes, single-chunk
+    reductions, split > chunks) against F.conv2d."""
+    import random
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import lib
+    rnd = random.Random(1234)
+    ncfg = lib().ppy_conv2d_num_configs()
+    g = torch.Generator().manual_seed(99)
+    ws = torch.empty(8 << 20).cuda()
+    for case in range(60):
+        N = rnd.choice([1, 2, 3])
+        C = rnd.choice([32, 64, 96, 160])
+        K = rnd.choice([5, 27, 32, 64, 100, 258, 300])
+        R = rnd.choice([1, 3])
+        stride = rnd.choice([1, 1, 2])
+        H, W = rnd.randint(3, 33), rnd.randint(3, 33)
+        cfg = rnd.randrange(ncfg)
+        splitk = rnd.choice([1, 1, 2, 5, 64])
+        act = rnd.choice([None, 'relu', 'leaky'])
+        pad = (R - 1) // 2
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(K, C, R, R, generator=g) * (1.0 / (C * R * R) ** 0.5)
+        sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+        ref = F.conv2d(x, w, None, stride, pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        use_res = rnd.random() < 0.5
+        res = torch.randn(ref.shape, generator=g) if use_res else None
+        if use_res:
+            ref = ref + res
+        ref = F.relu(ref) if act == 'relu' else (F.leaky_relu(ref, 0.1) if act == 'leaky' else ref)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        y = torch.full((N, Ho, Wo, K), 123.0).cuda()
+        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), w.permute(0, 2, 3, 1).contiguous().cuda(), sc.cuda(), sh.cuda(),
+                          ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
+                          cfg=cfg, splitk=splitk, ws=ws)
+        torch.cuda.synchronize()
+        close(nchw(y), ref, what='case %d: N%d C%d K%d R%d s%d %dx%d cfg%d split%d' % (case, N, C, K, R, stride, H, W, cfg,
+                                                                                 splitk))
