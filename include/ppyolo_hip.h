@@ -61,8 +61,18 @@ const char *ppy_error_string(int code);
  * cfg: tile configuration id, -1 = built-in heuristic; splitk: 0 = heuristic, >=1 forced.
  * ws: scratch for split-K partial sums, ppy_conv2d_workspace_bytes() bytes (may be
  * NULL when that returns 0).
+ * w_x3: NULL, or the same weights split into three bf16 planes by
+ * ppy_conv2d_split_weights_bf16x3 ([3][K][R][S][C] bf16, 6*K*R*S*C bytes).  With w_x3 the
+ * "bf16x3" kernels become selectable (cfg ids >= 31; the heuristic cfg = -1 then prefers
+ * them): each fp32 operand is split exactly into 3 bf16 terms and the product is evaluated as
+ * the 6 leading partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32 in,
+ * fp32 out, error vs fp64 at the level of the exact-fp32 fma chain (csrc/conv_x3.hip,
+ * profiles/r01_bf16x3_numerics.txt), 6/16 of the fp32-MFMA cost.  Without w_x3 those ids
+ * return PPY_ERR_BAD_ARG.
  */
-int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
+int ppy_conv2d_split_weights_bf16x3(const float *w_krsc, long long n_elems, void *out_planes,
+                                    void *stream);
+int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
                           const float *shift, const float *residual, int res_ld,
                           const float *posbias, float *y, int y_ld, int N, int H, int W,
                           int C, int K, int R, int S, int stride, int pad, int act,
@@ -105,7 +115,7 @@ int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int 
 int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offset_mask, int om_ld,
                          float *cols, int N, int H, int W, int C, int Ho, int Wo, int stride,
                          int pad, void *stream);
-int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
+int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
                   const float *shift, const float *offset_mask, int om_ld, float *y, int y_ld,
                   int N, int H, int W, int C, int K, int stride, int pad, int act, int cfg,
                   int splitk, void *ws, size_t ws_bytes, void *stream);

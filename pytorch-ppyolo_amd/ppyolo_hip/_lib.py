@@ -24,7 +24,8 @@ _lib = None
 _PROTOS = {
     'ppy_version': (c_int, []),
     'ppy_error_string': (ctypes.c_char_p, [c_int]),
-    'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+    'ppy_conv2d_split_weights_bf16x3': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_void_p, c_int] + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'ppy_conv2d_num_configs': (c_int, []),
@@ -36,7 +37,7 @@ _PROTOS = {
     'ppy_spp_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                             c_void_p]),
     'ppy_dcnv2_sample_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p]),
-    'ppy_dcnv2_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
+    'ppy_dcnv2_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
                       + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     'ppy_dcnv2_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_yolo_decode_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), c_int,

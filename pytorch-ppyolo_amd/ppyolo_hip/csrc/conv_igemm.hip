@@ -24,151 +24,9 @@
 // K-slot trick: within an 8-wide k group lane-half h reads floats [4h, 4h+4); the t-th MFMA of
 // the group contracts k = {t, 4+t}.  A and B use the same permutation, so the sum is unchanged
 // and every LDS read is a b128.
-#include "common.h"
+#include "conv_shared.h"
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;
-
-struct ConvArgs {
-    const float *x, *w, *scale, *shift, *res, *posb;
-    float *y, *part;
-    int x_ld, res_ld, y_ld;
-    int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
-    int M, Kred, cchunks, chunks_total, chunks_per_split;
-    unsigned long long *trace;   // debug: per-workgroup timeline (ppy_debug_set_trace), NULL in production
-};
-
-__device__ __forceinline__ void epilogue_store(const ConvArgs &p, int m, int col, float v,
-                                               float sc, float sh) {
-    const int hw = p.Ho * p.Wo;
-    if (p.posb) v += p.posb[(long long)(m % hw) * p.K + col];
-    v = fmaf(v, sc, sh);
-    if (p.res) v += p.res[(long long)m * p.res_ld + col];
-    v = ppy_apply_act(v, p.act);
-    if (!p.ups) {
-        p.y[(long long)m * p.y_ld + col] = v;
-    } else {
-        const int n = m / hw, rem = m - n * hw;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const long long W2 = 2LL * p.Wo;
-        float *o = p.y + (((long long)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + col;
-        o[0] = v;
-        o[p.y_ld] = v;
-        o[W2 * p.y_ld] = v;
-        o[(W2 + 1) * p.y_ld] = v;
-    }
-}
-
-// Epilogue shared by both kernels.  Must be entered after a workgroup barrier that follows the
-// last MFMA read of the operand tiles (the vector path reuses the LDS as a wave-private
-// transpose patch).
-template <int TM, int TN, int WM, int WN, bool SPLIT, bool VEC>
-__device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)[TM][TN], float *smem, int m0,
-                                              int n0, int wm, int wn, int lane, int wave, int split) {
-    const int hw = p.Ho * p.Wo;
-    if constexpr (VEC) {
-        // ---- vector epilogue: each 32x32 accumulator tile goes through a wave-private LDS
-        // patch so that a lane owns 4 consecutive channels of a pixel: 16-byte residual loads
-        // and stores, 8 lanes per 128-byte row segment (the scalar form -- 4 bytes per lane --
-        // measured ~2.2 TB/s on the output-heavy 1x1 layers vs 4.3 TB/s for float4 kernels).
-        // The main loop ended with a barrier, so nobody reads the operand tiles any more.
-        float *sE = smem + wave * (32 * LDS_LD);
-        const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + ec4;
-            const bool colok = col < p.K;
-            floatx4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (!SPLIT && colok) {
-                sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
-                sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mbase = m0 + wm * WM + i * 32 + erow;
-                floatx4 rv[4];
-                if (!SPLIT && p.res) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int m = mbase + 8 * t;
-                        rv[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-                        if (colok && m < p.M)
-                            rv[t] = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    sE[row * LDS_LD + (lane & 31)] = acc[i][j][e];
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mbase + 8 * t;
-                    floatx4 v = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * t) * LDS_LD + ec4);
-                    if (colok && m < p.M) {
-                        if (SPLIT) {
-                            *reinterpret_cast<floatx4 *>(p.part + ((long long)split * p.M + m) * p.K + col) = v;
-                        } else {
-                            if (p.posb) {
-                                const floatx4 pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % hw) * p.K + col);
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) v[u] += pb[u];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                float o = fmaf(v[u], sc[u], sh[u]);
-                                if (p.res) o += rv[t][u];
-                                v[u] = ppy_apply_act(o, p.act);
-                            }
-                            if (!p.ups) {
-                                *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
-                            } else {
-                                const int n = m / hw, rem = m - n * hw;
-                                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                                const long long W2 = 2LL * p.Wo;
-                                float *o = p.y + (((long long)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + col;
-                                *reinterpret_cast<floatx4 *>(o) = v;
-                                *reinterpret_cast<floatx4 *>(o + p.y_ld) = v;
-                                *reinterpret_cast<floatx4 *>(o + W2 * p.y_ld) = v;
-                                *reinterpret_cast<floatx4 *>(o + (W2 + 1) * p.y_ld) = v;
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
-    }
-    // ---- scalar epilogue: lane l holds channel (l&31) of 16 pixels per 32x32 tile ----
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + (lane & 31);
-        const bool colok = col < p.K;
-        float sc = 1.f, sh = 0.f;
-        if (!SPLIT && colok) {
-            sc = p.scale[col];
-            sh = p.shift[col];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int m = m0 + wm * WM + i * 32 + row;
-                if (colok && m < p.M) {
-                    if (SPLIT)
-                        p.part[((long long)split * p.M + m) * p.K + col] = acc[i][j][e];
-                    else
-                        epilogue_store(p, m, col, acc[i][j][e], sc, sh);
-                }
-            }
-        }
-    }
-}
 
 template <int BM, int BN, int WM, int WN, bool SPLIT, bool VEC>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_kernel(const ConvArgs p) {
@@ -338,11 +196,6 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_kernel(
 //    only executes a bit test and a select.
 //  * Pipeline (STAGES LDS buffers): wait for chunk k (counted vmcnt) -> barrier (also proves
 //    everyone finished chunk k-1, whose buffer is then refilled with chunk k+STAGES-1) -> MFMAs.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 //  * BKT = reduction depth of one pipeline stage (32 or 16 channels of one tap).  16 halves the LDS per
 //    stage (128x128 tile: 16 KB) so that 3-4 workgroups fit on a CU; a DMA instruction then covers
 //    16 rows x 64 B and the swizzle is c ^ ((r>>2)&3) over the 4 slots of a row.
@@ -514,63 +367,6 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_glds_ke
 #endif
 }
 
-// Deterministic split-K combine (fixed z order) + the same epilogue.  VEC: one 16-byte column
-// group per thread (every load independent, 16-byte accesses); otherwise one element per thread.
-template <bool VEC>
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, int splits) {
-    constexpr int W = VEC ? 4 : 1;
-    const long long total = (long long)p.M * p.K;
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W;
-    if (i >= total) return;
-    const int m = (int)(i / p.K), col = (int)(i - (long long)m * p.K);
-    if constexpr (VEC) {
-        floatx4 v = *reinterpret_cast<const floatx4 *>(p.part + i);
-        for (int z = 1; z < splits; ++z) {
-            const floatx4 o = *reinterpret_cast<const floatx4 *>(p.part + (long long)z * total + i);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] += o[u];
-        }
-        const floatx4 sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
-        const floatx4 sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
-        if (p.posb) {
-            const floatx4 pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % (p.Ho * p.Wo)) * p.K + col);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] += pb[u];
-        }
-        floatx4 r = {0.f, 0.f, 0.f, 0.f};
-        if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ppy_apply_act(fmaf(v[u], sc[u], sh[u]) + (p.res ? r[u] : 0.f), p.act);
-        if (!p.ups) {
-            *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
-        } else {
-            const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const long long W2 = 2LL * p.Wo;
-            float *o = p.y + (((long long)n * 2 * p.Ho + 2 * ho) * W2 + 2 * wo) * p.y_ld + col;
-            *reinterpret_cast<floatx4 *>(o) = v;
-            *reinterpret_cast<floatx4 *>(o + p.y_ld) = v;
-            *reinterpret_cast<floatx4 *>(o + W2 * p.y_ld) = v;
-            *reinterpret_cast<floatx4 *>(o + (W2 + 1) * p.y_ld) = v;
-        }
-    } else {
-        float v = p.part[i];
-        for (int z = 1; z < splits; ++z) v += p.part[(long long)z * total + i];
-        epilogue_store(p, m, col, v, p.scale[col], p.shift[col]);
-    }
-}
-
-// launch helper shared by both conv kernels
-inline void launch_splitk_reduce(const ConvArgs &p, int splits, bool vec, hipStream_t stream) {
-    const long long total = (long long)p.M * p.K;
-    const long long threads = vec ? total / 4 : total;
-    const unsigned grid = (unsigned)((threads + 255) / 256);
-    if (vec)
-        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, stream, p, splits);
-    else
-        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(grid), dim3(256), 0, stream, p, splits);
-}
-
 struct TileCfg {
     int bm, bn, wm, wn;
 };
@@ -629,16 +425,6 @@ int launch_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t
     }
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
     return PPY_OK;
-}
-
-// 16-byte epilogue accesses need 4-channel granularity and 16-byte aligned rows everywhere.
-bool vec_epilogue_ok(const ConvArgs &p) {
-    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
-    if (p.K % 4 != 0 || p.y_ld % 4 != 0 || !al(p.y) || !al(p.scale) || !al(p.shift)) return false;
-    if (p.res && (p.res_ld % 4 != 0 || !al(p.res))) return false;
-    if (p.posb && !al(p.posb)) return false;
-    if (p.part && !al(p.part)) return false;
-    return true;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -704,25 +490,6 @@ int launch_glds(ConvArgs p, int splits, hipStream_t stream) {
     return ppy_launch_status();
 }
 
-struct Geometry {
-    int Ho, Wo, M, Kred, chunks;
-};
-
-bool conv_geometry(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, Geometry *g) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
-        return false;
-    if (C % BK != 0) return false;
-    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-    if (Ho <= 0 || Wo <= 0) return false;
-    const long long M = (long long)N * Ho * Wo;
-    if (M > 0x7fffffffLL / 4) return false;
-    g->Ho = Ho;
-    g->Wo = Wo;
-    g->M = (int)M;
-    g->Kred = R * S * C;
-    g->chunks = R * S * (C / BK);
-    return true;
-}
 
 // Cost model (cycles on one CU) used when the caller does not force a configuration.
 // A work item (tile x split) costs BM*BN/4 MFMA-cycles per chunk on a CU (4 SIMDs x 64
@@ -762,7 +529,8 @@ void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
 
 }  // namespace
 
-extern "C" int ppy_conv2d_num_configs(void) { return kNumCfgs; }
+// configuration ids [kNumCfgs, kNumCfgs + ppy_x3_num_configs()) select the split-bf16 kernels of conv_x3.hip
+extern "C" int ppy_conv2d_num_configs(void) { return kNumCfgs + ppy_x3_num_configs(); }
 
 extern "C" int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                int *cfg_out, int *splitk_out) {
@@ -776,7 +544,7 @@ extern "C" int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, 
 }
 
 static int resolve(const Geometry &g, int K, int cfg, int splitk, int *c, int *s) {
-    if (cfg >= kNumCfgs) return PPY_ERR_BAD_ARG;
+    if (cfg >= kNumCfgs + ppy_x3_num_configs()) return PPY_ERR_BAD_ARG;
     int hc, hs;
     pick_config(g, K, &hc, &hs);
     *c = cfg < 0 ? hc : cfg;
@@ -804,7 +572,7 @@ static unsigned long long *g_trace = nullptr;
 // (4 x u64 per workgroup); tools/conv_trace.py turns that into a per-CU timeline.
 extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 
-extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const float *scale,
+extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
                                      const float *shift, const float *residual, int res_ld,
                                      const float *posbias, float *y, int y_ld, int N, int H, int W, int C,
                                      int K, int R, int S, int stride, int pad, int act, int upsample2x,
@@ -824,7 +592,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;
     }
     ConvArgs p;
-    p.x = x; p.w = w_krsc; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
+    p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
     p.y = y; p.part = (float *)ws;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;
@@ -842,6 +610,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (c >= kNumCfgs) return ppy_x3_dispatch(p, c - kNumCfgs, s, st);
     switch (c) {
         case 0: return launch_cfg<128, 128, 64, 64>(p, s, st);
         case 1: return launch_cfg<128, 64, 64, 32>(p, s, st);

@@ -1,0 +1,436 @@
+// fp32 implicit-GEMM convolution on the bf16 MFMA of gfx950: "bf16x3" operand split.
+//
+// Same operator as conv_igemm.hip (Conv2dUnit.forward of the reference, model/custom_layers.py:243-253,
+// with the residual / CoordConv / upsample terms around it), same tensors (fp32 NHWC in, fp32 out),
+// same epilogue.  Only the inner product is organised differently:
+//
+//   every fp32 operand is split EXACTLY into three bf16 terms  a = a0 + a1 + a2  (8 + 8 + 8
+//   significant bits, round-to-nearest at each level, the residuals a - a0 and a - a0 - a1 are exact
+//   in fp32), and  a*b  is evaluated as the six partial products of weight >= 2^-16
+//       a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0
+//   on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact, accumulation is fp32).  The three
+//   dropped products are <= 2^-24 |a*b| each.  Measured on MI355X against an fp64 reference
+//   (tools/probes/bf16x_probe.hip, profiles/r01_bf16x3_numerics.txt): rms error 2.0-3.5e-8 of
+//   sum|a*b| for K = 256..4608 -- the same or slightly LOWER than the exact-fp32 MFMA's k-ordered fma
+//   chain (2.3-4.2e-8), because 16 products are summed per accumulator rounding instead of one.
+//   The bf16 MFMA runs 16x the fp32 MFMA rate, so six of them cost 6/16 of the fp32 instruction:
+//   the MFMA ceiling of this kernel is 2516.6 / 6 = 419 TFLOP/s of fp32-equivalent work.
+//   (Inf/NaN inputs give NaN where the fp32 kernel gives Inf: inf - inf in the residual.)
+//
+// Data movement (all through the LDS-DMA loader of conv_igemm.hip, counted vmcnt, one barrier per
+// 32-deep chunk):
+//   * activations stay fp32 in HBM and in LDS ([BM][32] floats, XOR-swizzled 16-byte slots); each wave
+//     reads the rows of ITS sub-tile, splits them in registers (v_cvt_pk_bf16_f32, shift/and, subtract:
+//     4.5 VALU instructions per element, issued in the shadow of the MFMAs) and feeds the MFMA directly;
+//   * weights are constant: they are split once per plan into three bf16 planes [3][K][R][S][C]
+//     (ppy_conv2d_split_weights_bf16x3) and DMA'd as three [BN][32] bf16 tiles per chunk.
+// Wave tiles are wide in N (64x128 / 64x64) so that one split of an A fragment feeds 24 / 12 MFMAs.
+#include "conv_shared.h"
+
+#include <type_traits>
+
+#ifndef PPY_X3_ABL
+#define PPY_X3_ABL 0      // ablation switch for experiments (tools/x3_ablate.sh): 1 = no DMA in the loop, 2 = no split
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float floatx2;
+typedef __attribute__((ext_vector_type(4))) unsigned uintx4;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // RNE, a -> low half
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 consecutive-k floats of one row -> three bf16x8 MFMA operands (exact 3-term split)
+__device__ __forceinline__ void split8(const floatx4 lo, const floatx4 hi, bf16x8 (&out)[3]) {
+    uintx4 p0, p1, p2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = q < 2 ? lo[2 * q] : hi[2 * q - 4], b = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+        const unsigned P0 = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(P0 << 16), rb = b - __uint_as_float(P0 & 0xffff0000u);
+        const unsigned P1 = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(P1 << 16), sb = rb - __uint_as_float(P1 & 0xffff0000u);
+        p0[q] = P0;
+        p1[q] = P1;
+        p2[q] = cvt_pk_bf16(sa, sb);
+    }
+    out[0] = __builtin_bit_cast(bf16x8, p0);
+    out[1] = __builtin_bit_cast(bf16x8, p1);
+    out[2] = __builtin_bit_cast(bf16x8, p2);
+}
+
+__global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long long n, unsigned short *out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float a = w[i], b = i + 1 < n ? w[i + 1] : 0.f;
+    const unsigned P0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(P0 << 16), rb = b - __uint_as_float(P0 & 0xffff0000u);
+    const unsigned P1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(P1 << 16), sb = rb - __uint_as_float(P1 & 0xffff0000u);
+    const unsigned P2 = cvt_pk_bf16(sa, sb);
+    out[i] = (unsigned short)P0;
+    out[n + i] = (unsigned short)P1;
+    out[2 * n + i] = (unsigned short)P2;
+    if (i + 1 < n) {
+        out[i + 1] = (unsigned short)(P0 >> 16);
+        out[n + i + 1] = (unsigned short)(P1 >> 16);
+        out[2 * n + i + 1] = (unsigned short)(P2 >> 16);
+    }
+}
+
+// A tile: [BM][32] fp32, 128-byte rows, 16-byte slot c of row r stored at c ^ ((r>>1)&7)   (as conv_igemm.hip)
+// B tile: [3 planes][BN][32] bf16, 64-byte rows, slot c of row r stored at c ^ ((r>>2)&3)
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+__global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int B_ROWS = 3 * BN;
+    static_assert(BM % (8 * NW) == 0 && B_ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
+    constexpr int A_PASS = BM / (8 * NW), B_PASS = B_ROWS / (16 * NW);
+    constexpr int G = A_PASS + B_PASS;                 // DMA instructions per wave per chunk
+    constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    static_assert(STAGES == 2, "two LDS stages (see the main loop)");
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+    char *smem = smem_x3;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations stay on the SALU
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kc_begin = split * p.chunks_per_split;
+    const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
+    const int nchunks = kc_end - kc_begin;
+
+    // ---- per-lane DMA source offsets (bytes), fixed for the whole tile ----
+    const int hw = p.Ho * p.Wo;
+    const unsigned OOB = 0xFFFFFFF0u;
+    const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
+    unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
+    {
+        const int drow = lane >> 3, dslot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < A_PASS; ++j) {
+            const int row = (j * NW + wave) * 8 + drow;
+            const int scol = dslot ^ ((row >> 1) & 7);
+            const int mr = m0 + row;
+            const int m = min(mr, p.M - 1);
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            a_off[j] = (unsigned)((((long long)n * p.H + hi0) * p.W + wi0) * p.x_ld * 4 + bias + scol * 16);
+            unsigned okb = 0;
+            if (mr < p.M) {
+                for (int r = 0; r < p.R; ++r)
+                    for (int s2 = 0; s2 < p.S; ++s2)
+                        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W)
+                            okb |= 1u << (r * p.S + s2);
+            }
+            a_ok[j] = okb;
+        }
+    }
+    {
+        const int drow = lane >> 2, dslot = lane & 3;
+        const long long plane_bytes = (long long)p.K * p.Kred * 2;
+#pragma unroll
+        for (int j = 0; j < B_PASS; ++j) {
+            const int rb = (j * NW + wave) * 16 + drow;        // row of the [3*BN] B tile
+            const int plane = rb / BN, nrow = rb - plane * BN;
+            const int scol = dslot ^ ((rb >> 2) & 3);
+            const int k = min(n0 + nrow, p.K - 1);             // rows >= K are masked at store
+            b_off[j] = (unsigned)(plane * plane_bytes + (long long)k * p.Kred * 2 + scol * 16);
+        }
+    }
+
+    const int RS = p.R * p.S;
+    int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
+    int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
+    const char *xb = reinterpret_cast<const char *>(p.x) - bias;
+    const char *wb = reinterpret_cast<const char *>(p.w3);
+
+    // One chunk = G DMA pieces per wave.  begin/piece/end are separate so that the steady-state loop can
+    // drop one piece into an MFMA slot at a time (a piece costs ~60+ issue cycles: M0 write + buffer_load);
+    // `have` = false turns every piece into an out-of-range access (no memory traffic, zeros into LDS), which
+    // keeps the loop body branch-free after the last chunk has been requested.
+    __amdgpu_buffer_rsrc_t cur_ra, cur_rb;
+    unsigned cur_tapbit = 0, cur_lds = 0;
+    bool cur_have = false;
+    auto issue_begin = [&](int stage, bool have) {
+        const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
+        const long long b_uni = ((long long)l_tap * p.C + l_cc * 32) * 2;
+        cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+        cur_rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? b_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+        cur_tapbit = have ? (1u << l_tap) : 0u;
+        cur_have = have;
+        cur_lds = (unsigned)(stage * STAGE + wave * 1024);
+        ++l_tap;
+        ++l_s;
+        if (l_s == p.S) { l_s = 0; ++l_r; }
+        if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
+    };
+    auto issue_piece = [&](int d) {       // d in [0, G): compile-time after unrolling
+        if (d < A_PASS) {
+            const unsigned off = (a_ok[d] & cur_tapbit) ? a_off[d] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
+        } else {
+            const int j = d - A_PASS;
+            const unsigned off = cur_have ? b_off[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rb, (lds_ptr)(smem + cur_lds + A_BYTES + j * NW * 1024), 16, off, 0,
+                                                     0, 0);
+        }
+    };
+    auto issue = [&](int stage) {
+        issue_begin(stage, true);
+#pragma unroll
+        for (int d = 0; d < G; ++d) issue_piece(d);
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read offsets (bytes).  MFMA k-step s (16 deep), lane-half h: k = 16s + 8h + [0,8)
+    //   A: two 16-byte slots 4s+2h, 4s+2h+1 of row (lane&31);  B: one slot 2s+h of row (lane&31) per plane
+    const int frow = lane & 31, fkh = lane >> 5;
+    const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 2) & 3;
+    int a_foff[2][2], b_foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
+        a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
+    }
+
+    // One "k-step" = 16 reduction elements = one MFMA depth; a 32-deep chunk is two k-steps.
+    // The wave is software-pipelined over k-steps BY HAND: the instruction stream of a step is a
+    // sequence of NM slots { one MFMA of step g ; at most one LDS read for step g+1 ; a few VALU
+    // instructions of the split of step g+1's A fragments }, fenced with sched_barrier so that hipcc
+    // keeps that order (left alone it emits read -> split -> MFMA phases and the matrix pipe idles
+    // during the split; sched_group_barrier pipelines were not honoured in a region this large).
+    // Split of one (a, b) pair = 5 dependent stages (cvt | shift,and,sub,sub | cvt | ... | cvt); the
+    // stages of the 4*TM pairs of a step are issued stage-major so neighbours are independent.
+    struct Frag {        // operands of one k-step
+        uintx4 a[TM][3];         // A: three bf16x8 terms per 32-row tile
+        bf16x8 b[3][TN];         // B: plane x 32-column tile
+    };
+    constexpr int NM = 6 * TM * TN;           // MFMAs per k-step
+    constexpr int NRA = 2 * TM, NRB = 3 * TN; // LDS reads per k-step
+    constexpr int NSL = 5 * 4 * TM;           // split stages per k-step
+    constexpr int LEAD = NRA + 2;             // MFMA slots before the first split stage (raw reads in flight)
+    static_assert(NM >= NRA + NRB && NM > LEAD, "slots");
+    constexpr int PER = (NSL + (NM - LEAD) - 1) / (NM - LEAD);
+
+    constexpr int DSTRIDE = NM / G > 0 ? NM / G : 1;
+    static_assert(G <= NM, "one DMA piece per MFMA slot at most");
+    auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag, auto dma_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        constexpr bool DMA = decltype(dma_tag)::value;   // this step also carries the DMA pieces of a chunk      // k-step (0/1) of the chunk the NEXT operands come from
+        constexpr int ta[6] = {2, 1, 0, 1, 0, 0}, tb[6] = {0, 1, 2, 0, 1, 0};   // smallest products first
+        const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
+        const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
+        floatx4 raw[TM][2];
+        float ra[TM][4], rb[TM][4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            {   // MFMA m, term-major: consecutive MFMAs use different accumulators
+                const int t = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[i][ta[t]]),
+                                                                   cur.b[tb[t]][j], acc[i][j], 0, 0, 0);
+            }
+            if (PPY_X3_ABL >= 5) {
+            } else if (m < NRA) {
+                raw[m >> 1][m & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (m >> 1) * 32 * 128 + a_foff[s][m & 1]);
+            } else if (m < NRA + NRB) {
+                const int pl = (m - NRA) / TN, j = (m - NRA) % TN;
+                nxt.b[pl][j] = *reinterpret_cast<const bf16x8 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
+            }
+            if (DMA && PPY_X3_ABL != 1 && PPY_X3_ABL < 3 && m % DSTRIDE == DSTRIDE - 1 && m / DSTRIDE < G) issue_piece(m / DSTRIDE);
+            if (m >= LEAD) {
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int sl = (m - LEAD) * PER + u;
+                    if (sl < NSL && PPY_X3_ABL != 2 && PPY_X3_ABL < 3) {
+                        const int st = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q = pr % 4;
+                        const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
+                        if (st == 0) {
+                            nxt.a[i][0][q] = cvt_pk_bf16(xa, xb);
+                        } else if (st == 1) {
+                            const unsigned P = nxt.a[i][0][q];
+                            ra[i][q] = xa - __uint_as_float(P << 16);
+                            rb[i][q] = xb - __uint_as_float(P & 0xffff0000u);
+                        } else if (st == 2) {
+                            nxt.a[i][1][q] = cvt_pk_bf16(ra[i][q], rb[i][q]);
+                        } else if (st == 3) {
+                            const unsigned P = nxt.a[i][1][q];
+                            ra[i][q] -= __uint_as_float(P << 16);
+                            rb[i][q] -= __uint_as_float(P & 0xffff0000u);
+                        } else {
+                            nxt.a[i][2][q] = cvt_pk_bf16(ra[i][q], rb[i][q]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // pin the split results here: without a use in this block the optimiser sinks the VALU work of the
+        // loop's last step across the back edge, in front of the next iteration's first MFMA
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+
+    if (nchunks > 0) {
+        Frag f0, f1;
+        issue(0);
+        if (nchunks > 1) {
+            issue(1);
+            wait_vmcnt<G>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        {   // operands of (chunk 0, k-step 0): not overlapped with anything
+            const char *a_ptr = smem + wm * WM * 128;
+            const char *b_ptr = smem + A_BYTES + wn * WN * 64;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 t3[3];
+                split8(*reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]),
+                       *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]), t3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) f0.a[i][pl] = __builtin_bit_cast(uintx4, t3[pl]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    f0.b[pl][j] = *reinterpret_cast<const bf16x8 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
+        }
+        int st = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            // k-step 0 of chunk k  ||  fetch + split k-step 1
+            step(f0, f1, st, S1(), std::false_type());
+            // mid-chunk: every LDS read of chunk k has returned (here and, after the barrier, in all waves)
+            // and chunk k+1 -- issued one chunk ago -- has landed: refill this stage with chunk k+2
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if PPY_X3_ABL < 4
+            __builtin_amdgcn_s_barrier();
+#endif
+            issue_begin(st, k + 2 < nchunks);
+            // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1 (garbage after the last chunk, unused)
+            st ^= 1;
+            step(f1, f0, st, S0(), std::true_type());
+        }
+        // the epilogue reuses the LDS: all reads returned, and the (out-of-range, zero-filling) DMA pieces the
+        // branch-free tail of the loop still issued have landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split);
+#endif
+}
+
+struct X3Cfg {
+    int bm, bn, wm, wn, stages;
+};
+constexpr X3Cfg kX3[] = {
+    {256, 128, 64, 128, 2},   // 0  4 waves (4x1), 112 KB LDS
+    {128, 128, 64, 64, 2},    // 1  4 waves (2x2), 80 KB
+    {128, 128, 32, 128, 2},   // 2  4 waves (4x1), 80 KB
+    {256, 64, 64, 64, 2},     // 3  4 waves (4x1), 88 KB
+    {128, 64, 32, 64, 2},     // 4  4 waves (4x1), 56 KB
+    {256, 128, 64, 64, 2},    // 5  8 waves (4x2), 112 KB
+    {128, 256, 64, 128, 2},   // 6  4 waves (2x2), 128 KB
+    {64, 128, 32, 64, 2},     // 7  4 waves (2x2), 64 KB
+};
+constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
+    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, STAGES, SPLIT, VEC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
+    return PPY_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_x3(ConvArgs p, int splits, hipStream_t stream) {
+    // 32-bit per-lane DMA offsets
+    const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
+    const long long wbytes = (long long)p.K * p.Kred * 6;
+    if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    size_t lds = (size_t)STAGES * (BM * 128 + 3 * BN * 64);
+    const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
+    if (lds < epi) lds = epi;
+    p.chunks_total = p.R * p.S * (p.C / 32);
+    p.chunks_per_split = ceil_div(p.chunks_total, splits);
+    splits = ceil_div(p.chunks_total, p.chunks_per_split);
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
+    const bool vec = vec_epilogue_ok(p);
+    int rc;
+    if (splits > 1) {
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, STAGES, true, true>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, STAGES, true, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+        launch_splitk_reduce(p, splits, vec, stream);
+    } else {
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, STAGES, false, true>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, STAGES, false, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+    }
+    return ppy_launch_status();
+}
+
+}  // namespace
+
+int ppy_x3_num_configs() { return kNumX3; }
+
+int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0) return PPY_ERR_BAD_ARG;
+    switch (c) {
+        case 0: return launch_x3<256, 128, 64, 128, 2>(p, s, st);
+        case 1: return launch_x3<128, 128, 64, 64, 2>(p, s, st);
+        case 2: return launch_x3<128, 128, 32, 128, 2>(p, s, st);
+        case 3: return launch_x3<256, 64, 64, 64, 2>(p, s, st);
+        case 4: return launch_x3<128, 64, 32, 64, 2>(p, s, st);
+        case 5: return launch_x3<256, 128, 64, 64, 2>(p, s, st);
+        case 6: return launch_x3<128, 256, 64, 128, 2>(p, s, st);
+        case 7: return launch_x3<64, 128, 32, 64, 2>(p, s, st);
+    }
+    return PPY_ERR_BAD_ARG;
+}
+
+extern "C" int ppy_conv2d_split_weights_bf16x3(const float *w, long long n, void *out, void *stream) {
+    PPY_CHECK_ARG(w && out && n > 0);
+    const long long pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       n, (unsigned short *)out);
+    return ppy_launch_status();
+}

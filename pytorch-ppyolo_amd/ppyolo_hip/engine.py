@@ -41,8 +41,22 @@ def fold_bn(bn, bias, K_out, device):
     return scale.contiguous(), shift.contiguous()
 
 
-_TUNED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950.json')
-_tuned = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_TUNED_PATHS = {'fp32': os.path.join(_HERE, 'tuned_gfx950.json'), 'bf16x3': os.path.join(_HERE, 'tuned_gfx950_bf16x3.json')}
+_tuned = {}
+NUM_FP32_CFGS = 31       # tile configuration ids below this are the exact-fp32 MFMA kernels (conv_igemm.hip)
+
+
+def math_mode():
+    """How the convolution inner products are evaluated (PPYOLO_HIP_MATH):
+      'bf16x3' (default): exact 3-term bf16 split of both fp32 operands, 6 partial products on the bf16 MFMA,
+                fp32 accumulate -- fp32-grade results (csrc/conv_x3.hip) at 6/16 of the fp32 MFMA cost; the
+                measured table may still pick an exact-fp32 kernel for a layer where that is faster;
+      'fp32':   v_mfma_f32_32x32x2_f32 only (a k-ordered fp32 fma chain)."""
+    m = os.environ.get('PPYOLO_HIP_MATH', 'bf16x3')
+    if m not in _TUNED_PATHS:
+        raise PPYoloHipError('PPYOLO_HIP_MATH must be one of %s' % sorted(_TUNED_PATHS))
+    return m
 
 
 def tune_key(op):
@@ -52,18 +66,18 @@ def tune_key(op):
     return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (op['op'], x.N, x.H, x.W, C, Kout, R, op['stride'])
 
 
-def tuned_table():
+def tuned_table(mode=None):
     """Measured per-shape choices (written by HipExecutor.autotune on an MI355X and committed
-    as tuned_gfx950.json; PPYOLO_HIP_TUNE_CACHE names an extra file).  Unknown shapes fall back
-    to the cost model inside libppyolo_hip.so."""
-    global _tuned
-    if _tuned is None:
-        _tuned = {}
-        for path in (_TUNED_PATH, os.environ.get('PPYOLO_HIP_TUNE_CACHE')):
+    as tuned_gfx950.json / tuned_gfx950_bf16x3.json, one table per math mode; PPYOLO_HIP_TUNE_CACHE
+    names an extra file).  Unknown shapes fall back to the cost model inside libppyolo_hip.so."""
+    mode = mode or math_mode()
+    if mode not in _tuned:
+        _tuned[mode] = {}
+        for path in (_TUNED_PATHS[mode], os.environ.get('PPYOLO_HIP_TUNE_CACHE')):
             if path and os.path.exists(path):
                 with open(path) as fh:
-                    _tuned.update(json.load(fh))
-    return _tuned
+                    _tuned[mode].update(json.load(fh))
+    return _tuned[mode]
 
 
 class Plan(object):
@@ -235,9 +249,15 @@ class HipExecutor(object):
             self.out_dets = torch.zeros((p.N, kk, 6), dtype=torch.float32, device=self.device)
             self.out_count = torch.zeros((p.N,), dtype=torch.int32, device=self.device)
             self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
+        self.math = math_mode()
         self._to_device(p.setup_ops)
         self._to_device(p.ops)
-        tab = tuned_table()
+        if self.math == 'bf16x3':
+            with torch.cuda.device(self.device):
+                for op in p.ops:        # (setup ops -- the CoordConv bias maps -- stay on the exact-fp32 kernel)
+                    if op['op'] in ('conv', 'dcn'):
+                        op['w3'] = K.split_weights_bf16x3(op['w'])
+        tab = tuned_table(self.math)
         for op in p.ops:
             if op['op'] in ('conv', 'dcn') and op['cfg'] < 0 and tune_key(op) in tab:
                 op['cfg'], op['splitk'] = tab[tune_key(op)][:2]
@@ -337,7 +357,7 @@ class HipExecutor(object):
             K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
-                            ws)
+                            ws, op.get('w3'))
         elif t == 'stem':
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
         elif t == 'maxpool':
@@ -348,7 +368,7 @@ class HipExecutor(object):
             K.spp(self.view(op['x']), self.view(op['y5']), self.view(op['y9']), self.view(op['y13']))
         elif t == 'dcn':
             K.dcnv2(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['om']), self.view(op['y']),
-                    op['stride'], op['pad'], op['act'], ws, op['cfg'], op['splitk'])
+                    op['stride'], op['pad'], op['act'], ws, op['cfg'], op['splitk'], op.get('w3'))
         else:
             raise PPYoloHipError('unknown plan op %r' % t)
 
@@ -424,7 +444,7 @@ class HipExecutor(object):
         """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
         guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
         from ._lib import lib
-        ncfg = lib().ppy_conv2d_num_configs()
+        ncfg = lib().ppy_conv2d_num_configs() if self.math == 'bf16x3' else NUM_FP32_CFGS
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
         with torch.cuda.device(self.device):
@@ -467,7 +487,7 @@ class HipExecutor(object):
                     op['cfg'], op['splitk'] = base_cfg, base_split
                     continue
                 op['cfg'], op['splitk'] = best[1], best[2]
-                tuned_table()[tune_key(op)] = [best[1], best[2], round(best[0], 4)]
+                tuned_table(self.math)[tune_key(op)] = [best[1], best[2], round(best[0], 4)]
                 report.append((tune_key(op), best))
                 if verbose:
                     print('autotune %s w=%s H=%d -> cfg %d split %d  %.3f ms' % (op['op'], tuple(op['w'].shape),

@@ -81,14 +81,25 @@ def conv2d_pick(N, H, W, C, K, R, S, stride, pad):
     return c.value, s.value
 
 
+def split_weights_bf16x3(w_krsc):
+    """fp32 weights -> the three bf16 planes [3, *w.shape] (int16 storage) the "bf16x3" conv kernels read."""
+    _dev(w_krsc)
+    assert w_krsc.is_contiguous() and w_krsc.dtype == torch.float32
+    out = torch.empty((3,) + tuple(w_krsc.shape), dtype=torch.int16, device=w_krsc.device)
+    check(lib().ppy_conv2d_split_weights_bf16x3(w_krsc.data_ptr(), w_krsc.numel(), out.data_ptr(), _stream()),
+          'ppy_conv2d_split_weights_bf16x3')
+    return out
+
+
 def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residual=None, posbias=None,
-                  upsample2x=False, cfg=-1, splitk=0, ws=None):
-    """x, y, residual: View.  w_krsc: [K,R,S,C].  See ppy_conv2d_bn_act_f32."""
+                  upsample2x=False, cfg=-1, splitk=0, ws=None, w_x3=None):
+    """x, y, residual: View.  w_krsc: [K,R,S,C].  w_x3: split_weights_bf16x3(w_krsc) or None.
+    See ppy_conv2d_bn_act_f32."""
     _dev(x.t, w_krsc, scale, shift, y.t)
     K, R, S, C = w_krsc.shape
     assert C == x.C and K == y.C and w_krsc.is_contiguous()
     rc = lib().ppy_conv2d_bn_act_f32(
-        x.ptr, x.ld, w_krsc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+        x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), scale.data_ptr(), shift.data_ptr(),
         None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
         _p(posbias), y.ptr, y.ld, x.N, x.H, x.W, C, K, R, S, stride, pad, ACT[act], int(bool(upsample2x)),
         cfg, splitk, _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream())
@@ -136,10 +147,10 @@ def dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg=-1, splitk=0):
     return int(lib().ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
 
 
-def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1, splitk=0):
+def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1, splitk=0, w_x3=None):
     _dev(x.t, w_krsc, offset_mask.t, y.t, ws)
     K = w_krsc.shape[0]
-    check(lib().ppy_dcnv2_f32(x.ptr, x.ld, w_krsc.data_ptr(), scale.data_ptr(), shift.data_ptr(), offset_mask.ptr,
+    check(lib().ppy_dcnv2_f32(x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), scale.data_ptr(), shift.data_ptr(), offset_mask.ptr,
                               offset_mask.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, K, stride, pad, ACT[act], cfg, splitk,
                               ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_f32')
 

@@ -50,6 +50,7 @@ def _check_preds(preds, refs, keep=None, ref_keep=None, box_tol=1e-3, near_tie=2
     for i, (p, r) in enumerate(zip(preds, refs)):
         p = p.cpu()
         assert p.shape == r.shape, (i, p.shape, r.shape)
+        subst = []
         if keep is not None and r[0, 0] >= 0:
             mine = keep[i][:r.shape[0]].cpu().numpy().astype(np.int64)
             if not np.array_equal(mine, ref_keep[i]):
@@ -61,13 +62,21 @@ def _check_preds(preds, refs, keep=None, ref_keep=None, box_tol=1e-3, near_tie=2
                         perm.append(pos[int(k)])
                         assert abs(float(r[j, 1]) - float(r[pos[int(k)], 1])) <= near_tie or pos[int(k)] == j, \
                             'image %d: rows %d/%d reordered but not a near-tie' % (i, j, pos[int(k)])
-                    else:       # only admissible at the keep_top_k cut
+                    else:       # only admissible at the keep_top_k cut: a different detection with a tied score
                         assert abs(float(r[j, 1]) - cut) <= near_tie, 'image %d: kept set differs' % i
-                        perm.append(j)
+                        subst.append(j)
+                        perm.append(-1)
+                free = [j for j in range(len(mine)) if j not in set(perm)]      # my rows the reference cut off
+                assert len(free) == len(subst)
+                for j in subst:
+                    perm[j] = free.pop()
+                    assert abs(float(p[perm[j], 1]) - cut) <= near_tie, 'image %d: kept set differs' % i
                 p = p[torch.tensor(perm)]
-        assert torch.equal(p[:, 0], r[:, 0]), 'image %d: labels / order differ' % i
+        same = torch.ones(r.shape[0], dtype=torch.bool)
+        same[subst] = False
+        assert torch.equal(p[same, 0], r[same, 0]), 'image %d: labels / order differ' % i
         assert (p[:, 1] - r[:, 1]).abs().max() <= 1e-4, 'image %d scores' % i
-        err = (p[:, 2:] - r[:, 2:]).abs().max()
+        err = (p[same, 2:] - r[same, 2:]).abs().max()
         assert err <= box_tol, 'image %d boxes: %.3e > %.3e' % (i, err, box_tol)
 
 

@@ -58,7 +58,10 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-@pytest.mark.parametrize('cfg', range(31))
+NUM_CFGS = 39      # 31 exact-fp32 MFMA configurations + 8 bf16x3 (conv_x3.hip)
+
+
+@pytest.mark.parametrize('cfg', range(NUM_CFGS))
 @pytest.mark.parametrize('splitk', [1, 3])
 def test_conv_every_tile_config(cfg, splitk):
     """Each tile configuration / split-K path, with channel-sliced input & output buffers,
@@ -80,9 +83,11 @@ def test_conv_every_tile_config(cfg, splitk):
     rbuf = torch.zeros(N, H, W, K + 4).cuda()
     rbuf[..., 4:] = nhwc(res).cuda()
     ws = torch.empty(max(4, ops.conv2d_workspace_bytes(N, H, W, C, K, R, R, 1, 1, cfg, splitk) // 4)).cuda()
-    ops.conv2d_bn_act(ops.View(xin, 32, C), w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(),
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    ops.conv2d_bn_act(ops.View(xin, 32, C), wk, scale.cuda(), shift.cuda(),
                       ops.View(yout, 8, K), 1, 1, 'leaky', residual=ops.View(rbuf, 4, K),
-                      posbias=nhwc(posb).contiguous().cuda(), cfg=cfg, splitk=splitk, ws=ws)
+                      posbias=nhwc(posb).contiguous().cuda(), cfg=cfg, splitk=splitk, ws=ws,
+                      w_x3=ops.split_weights_bf16x3(wk) if cfg >= 31 else None)
     torch.cuda.synchronize()
     close(nchw(yout[..., 8:]), ref, what='cfg %d split %d' % (cfg, splitk))
     assert torch.all(yout[..., :8] == -7.0), 'wrote outside the output channel slice'
@@ -328,7 +333,7 @@ def test_conv_random_shapes_all_kernels():
     ncfg = lib().ppy_conv2d_num_configs()
     g = torch.Generator().manual_seed(99)
     ws = torch.empty(8 << 20).cuda()
-    for case in range(60):
+    for case in range(90):
         N = rnd.choice([1, 2, 3])
         C = rnd.choice([32, 64, 96, 160])
         K = rnd.choice([5, 27, 32, 64, 100, 258, 300])
@@ -350,9 +355,39 @@ def test_conv_random_shapes_all_kernels():
         ref = F.relu(ref) if act == 'relu' else (F.leaky_relu(ref, 0.1) if act == 'leaky' else ref)
         Ho, Wo = ref.shape[2], ref.shape[3]
         y = torch.full((N, Ho, Wo, K), 123.0).cuda()
-        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), w.permute(0, 2, 3, 1).contiguous().cuda(), sc.cuda(), sh.cuda(),
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, sc.cuda(), sh.cuda(),
                           ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
-                          cfg=cfg, splitk=splitk, ws=ws)
+                          cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk))
         torch.cuda.synchronize()
         close(nchw(y), ref, what='case %d: N%d C%d K%d R%d s%d %dx%d cfg%d split%d' % (case, N, C, K, R, stride, H, W, cfg,
                                                                                  splitk))
+
+
+def test_bf16x3_split_is_exact_and_fp32_grade():
+    """The three bf16 planes of the weights sum back to the fp32 value exactly, the bf16x3 kernel needs them
+    (BAD_ARG without), and against an fp64 reference its error is at the level of the exact-fp32 MFMA kernel."""
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import PPYoloHipError
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, K = 2, 24, 24, 256, 128
+    x = torch.randn(N, C, H, W, generator=g).abs() * torch.exp(2 * torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.03
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    planes = ops.split_weights_bf16x3(wk)
+    as_f32 = (planes.to(torch.int32) << 16).view(torch.float32)            # bf16 bits -> fp32 value
+    assert torch.equal((as_f32[0] + as_f32[1]) + as_f32[2], wk), 'split is not exact'
+    assert (as_f32[1].abs() <= as_f32[0].abs() * 2.0 ** -8 + 1e-45).all()
+    one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    errs = {}
+    for name, cfg, wx in (('fp32', 19, None), ('bf16x3', 31, planes), ('bf16x3-b', 32, planes)):
+        y = torch.zeros(N, H, W, K).cuda()
+        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, one, zero, ops.View(y), 1, 1, None, cfg=cfg, splitk=1, w_x3=wx)
+        torch.cuda.synchronize()
+        errs[name] = (((nchw(y).cpu().double() - ref) / mag) ** 2).mean().sqrt().item()
+    print('rms error / sum|a*b| vs fp64:', errs)
+    assert errs['bf16x3'] <= 1.25 * errs['fp32'] and errs['bf16x3-b'] <= 1.25 * errs['fp32'], errs
+    with pytest.raises(PPYoloHipError):
+        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, one, zero, ops.View(y), 1, 1, None, cfg=31, splitk=1)

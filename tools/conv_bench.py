@@ -24,11 +24,13 @@ def main():
     y = torch.empty(N, Ho, Wo, K, device='cuda')
     res = torch.randn(N, Ho, Wo, K, device='cuda') if use_res else None
     ws = torch.empty(64 << 20, device='cuda')
+    w3 = ops.split_weights_bf16x3(w)
     flops = 2.0 * N * Ho * Wo * K * R * R * C
     for cfg in cfgs:
         def run():
             ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu',
-                              residual=None if res is None else ops.View(res), cfg=cfg, splitk=splitk, ws=ws)
+                              residual=None if res is None else ops.View(res), cfg=cfg, splitk=splitk, ws=ws,
+                              w_x3=w3)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
