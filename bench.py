@@ -32,6 +32,11 @@ for _p in (ROOT, os.path.join(ROOT, 'pytorch-ppyolo_amd')):
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS     # same guide: fp32 MFMA = 1/16 of the dense bf16 MFMA rate (~2.5 PF)
+# bf16x3 kernels (csrc/conv_x3.hip) execute 6 bf16 MFMA products per fp32 multiply-add: their MFMA roofline in
+# units of ALGORITHMIC fp32 FLOPs is the bf16 peak / 6
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+NUM_FP32_CFGS = 31
 
 WORKLOADS = {
     'r50vd_608': dict(cfg='PPYOLO_2x_Config', size=608, model='PPYOLO ResNet50-vd (DCNv2, CoordConv, SPP)'),
@@ -53,6 +58,11 @@ def build_model(cfg_name, device):
     m.eval()
     hd.set_dropblock(is_test=True)
     return m.to(device), sd, cfg
+
+
+def _tuned_path(mode):
+    from ppyolo_hip import engine
+    return engine._TUNED_PATHS[mode]
 
 
 def conv_flops(plan):
@@ -97,7 +107,14 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
         torch.cuda.synchronize()
         ms = sum(s.elapsed_time(e) for s, e in evs)
         best = ms if best is None else min(best, ms)
-    return best, sum(per_op_flops[i] for i in convs), len(convs)
+    # MFMA-pipe time the same launches would need at peak: per launch flops / (peak of the kernel family it ran on)
+    ideal_s = 0.0
+    x3_flops = 0
+    for i in convs:
+        x3 = ex.plan.ops[i].get('w3') is not None and ex.plan.ops[i]['cfg'] >= NUM_FP32_CFGS
+        ideal_s += per_op_flops[i] / ((X3_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS) * 1e12)
+        x3_flops += per_op_flops[i] if x3 else 0
+    return best, sum(per_op_flops[i] for i in convs), len(convs), ideal_s, x3_flops
 
 
 def layer_report(ex, per_op, path):
@@ -231,8 +248,9 @@ def main():
 
     if rank == 0:
         total_flops, per_op = conv_flops(ex.plan)
-        conv_ms, covered, nconv = timed_conv_pass(ex, per_op)
+        conv_ms, covered, nconv, ideal_s, x3_flops = timed_conv_pass(ex, per_op)
         achieved = covered / (conv_ms * 1e-3) / 1e12
+        peak = covered / ideal_s / 1e12        # flop-weighted peak of the kernel mix of this step
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
         # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
         traffic = None
@@ -240,14 +258,22 @@ def main():
         if a.workload == 'r50vd_608' and a.batch == 8 and os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = round(json.load(fh)['hbm_bytes_per_step'] / nconv)
-        roof = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+        roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
+                    frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit='bytes per launch (mean over the conv launches of a step; PMC '
                                  '2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)',
-                    kernel='conv_igemm_glds_kernel<*> / conv_igemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM), '
-                           '%d launches/step' % nconv,
+                    kernel='conv_igemm_x3_kernel<*> (fp32 implicit GEMM as 6 x v_mfma_f32_32x32x16_bf16 per product, exact '
+                           '3-term bf16 operand split) / conv_igemm_glds_kernel<*> (v_mfma_f32_32x32x2_f32), %d launches/step'
+                           % nconv,
+                    peak_note='achieved = algorithmic fp32 FLOPs / HIP-event time of the conv launches; peak = the same '
+                              'FLOPs / MFMA-pipe time at peak, where a bf16x3 launch is priced at %.1f (= dense bf16 '
+                              'MFMA %.1f / 6 products per multiply-add) and an exact-fp32 launch at %.1f TFLOP/s; '
+                              '%.1f%% of the FLOPs ran on bf16x3 kernels' % (
+                                  X3_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS,
+                                  100.0 * x3_flops / max(1, covered)),
+                    achieved_vs_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
-                    whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
+                    whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4))
         out = dict(metric='images/sec PPYOLO R50-vd 608x608 bs=8' if a.workload == 'r50vd_608'
                    else 'images/sec %s bs=%d' % (a.workload, a.batch),
                    value=round(value, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
@@ -257,7 +283,10 @@ def main():
                                         % (wl['model'], wl['size'], wl['size'], a.batch),
                                global_batch=world * a.batch, parallelism='batch-sharded x%d, all-gather of detections'
                                % world if world > 1 else 'single GPU', hip_graph=not a.no_graph,
-                               tile_table='re-measured' if a.autotune else 'tuned_gfx950.json'),
+                               math=ex.math + (' (fp32 in/out, fp32 accumulate; operands split exactly into 3 bf16 terms, 6 partial '
+                                                'products; error vs fp64 <= the fp32 fma chain, tests/test_gpu_ops.py)'
+                                                if ex.math == 'bf16x3' else ''),
+                               tile_table='re-measured' if a.autotune else os.path.basename(_tuned_path(ex.math))),
                    roofline=roof)
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)

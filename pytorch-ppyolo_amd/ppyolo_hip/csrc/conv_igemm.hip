@@ -587,6 +587,9 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     int c, s;
     int rc = resolve(g, K, cfg, splitk, &c, &s);
     if (rc != PPY_OK) return rc;
+    // no measured choice for this shape: with split weights at hand the 128x64 bf16x3 tile (two workgroups per
+    // CU) is the one that won most layers of the measured tables; narrow / shallow layers stay on the fp32 kernels
+    if (cfg < 0 && w_x3 && K >= 48 && g.chunks >= 4) c = kNumCfgs + 4;
     if (s > 1) {
         const size_t need = (size_t)s * g.M * K * sizeof(float);
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;

@@ -114,6 +114,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     const int kc_begin = split * p.chunks_per_split;
     const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
     const int nchunks = kc_end - kc_begin;
+    unsigned long long t_start = 0, c_start = 0, c_loop = 0, c_epi = 0;
+    if (p.trace) {
+        t_start = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
+        c_start = __builtin_amdgcn_s_memtime();         // shader clock
+    }
 
     // ---- per-lane DMA source offsets (bytes), fixed for the whole tile ----
     const int hw = p.Ho * p.Wo;
@@ -122,24 +127,31 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
     {
         const int drow = lane >> 3, dslot = lane & 7;
+        // (n, ho, wo) of the first row by division, of the following rows (8*NW further each) incrementally
+        const int step_rows = 8 * NW;
+        const int step_ho = step_rows / p.Wo, step_wo = step_rows - step_ho * p.Wo;
+        int m_first = min(m0 + wave * 8 + drow, p.M - 1);
+        int n = m_first / hw, rem = m_first - n * hw;
+        int ho = rem / p.Wo, wo = rem - ho * p.Wo;
 #pragma unroll
         for (int j = 0; j < A_PASS; ++j) {
             const int row = (j * NW + wave) * 8 + drow;
             const int scol = dslot ^ ((row >> 1) & 7);
             const int mr = m0 + row;
-            const int m = min(mr, p.M - 1);
-            const int n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
             a_off[j] = (unsigned)((((long long)n * p.H + hi0) * p.W + wi0) * p.x_ld * 4 + bias + scol * 16);
-            unsigned okb = 0;
-            if (mr < p.M) {
-                for (int r = 0; r < p.R; ++r)
-                    for (int s2 = 0; s2 < p.S; ++s2)
-                        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W)
-                            okb |= 1u << (r * p.S + s2);
-            }
-            a_ok[j] = okb;
+            // taps inside the image: (valid rows r) x (valid columns s) as a bit mask over r*S + s
+            unsigned colmask = 0, okb = 0;
+            for (int s2 = 0; s2 < p.S; ++s2)
+                if ((unsigned)(wi0 + s2) < (unsigned)p.W) colmask |= 1u << s2;
+            for (int r = 0; r < p.R; ++r)
+                if ((unsigned)(hi0 + r) < (unsigned)p.H) okb |= colmask << (r * p.S);
+            a_ok[j] = mr < p.M ? okb : 0u;
+            // advance to the row of the next pass (rows beyond M are masked above; their offsets are unused)
+            wo += step_wo;
+            ho += step_ho;
+            if (wo >= p.Wo) { wo -= p.Wo; ++ho; }
+            while (ho >= p.Ho) { ho -= p.Ho; ++n; }
         }
     }
     {
@@ -299,6 +311,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
 
+    if (p.trace) c_loop = __builtin_amdgcn_s_memtime();
     if (nchunks > 0) {
         Frag f0, f1;
         issue(0);
@@ -346,7 +359,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    if (p.trace) c_epi = __builtin_amdgcn_s_memtime();
     tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split);
+    if (p.trace && tid == 0) {     // debug timeline (ppy_debug_set_trace): wall-clock span + shader-clock phases
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long c_end = __builtin_amdgcn_s_memtime();
+        const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        p.trace[b * 4 + 0] = t_start;
+        p.trace[b * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.trace[b * 4 + 2] = hwid | ((unsigned long long)xcc << 32);
+        // 3 x 21-bit phase lengths in units of 16 shader cycles: setup | main loop | epilogue
+        const unsigned long long a = (c_loop - c_start) >> 4, m = (c_epi - c_loop) >> 4, e = (c_end - c_epi) >> 4;
+        p.trace[b * 4 + 3] = (a & 0x1fffff) | ((m & 0x1fffff) << 21) | ((e & 0x1fffff) << 42);
+    }
 #endif
 }
 

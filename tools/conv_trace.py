@@ -13,14 +13,19 @@ cfg, splitk = int(sys.argv[2]), int(sys.argv[3])
 pad = (R - 1) // 2
 Ho, Wo = ops.conv_out_hw(H, W, R, R, stride, pad)
 x = torch.randn(N, H, W, C, device='cuda'); w = torch.randn(K, R, R, C, device='cuda') * 0.05
+mode = os.environ.get('PPY_TRACE_DATA', 'randn')      # operand data changes the MFMA power draw -> the clock
+if mode == 'zeros': x.zero_(); w.zero_()
+if mode == 'ones': x.fill_(1.0); w.fill_(0.5)
+if mode == 'relu': x.clamp_(min=0)
 sc, sh = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
 y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device='cuda')
 tr = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
 L = _lib.lib()._handle
 lib = ctypes.CDLL(_lib.LIB_PATH)
+w3 = ops.split_weights_bf16x3(w)
 def run():
-    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws)
-for _ in range(3): run()
+    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws, w_x3=w3)
+for _ in range(int(os.environ.get('PPY_TRACE_WARM', '3'))): run()
 torch.cuda.synchronize()
 lib.ppy_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
 run(); torch.cuda.synchronize()
@@ -53,3 +58,14 @@ for k in range(4):
 T = np.linspace(0, en.max(), 21)
 act = [(int(((start.numpy() <= tt) & (end.numpy() > tt)).sum())) for tt in T]
 print('active workgroups over time:', act)
+
+ph = t[:, 3]
+if int(ph.max()) > 0:      # bf16x3 kernels: shader-clock phase lengths
+    a = (ph & 0x1fffff).double() * 16; m = ((ph >> 21) & 0x1fffff).double() * 16; e = ((ph >> 42) & 0x1fffff).double() * 16
+    cyc = a + m + e
+    us = (end - start)
+    print('shader clock during the launch: %.0f MHz (mean over workgroups)' % (cyc / us).mean().item())
+    print('phase cycles mean: setup %.0f  main loop %.0f  epilogue %.0f   (fractions %.1f%% / %.1f%% / %.1f%%)' % (
+        a.mean(), m.mean(), e.mean(), 100 * (a / cyc).mean(), 100 * (m / cyc).mean(), 100 * (e / cyc).mean()))
+    chunks = R * R * C // 32 // splitk
+    print('main loop: %.0f cycles per 32-deep chunk' % (m.mean().item() / chunks))
