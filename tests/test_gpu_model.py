@@ -81,9 +81,10 @@ def _check_preds(preds, refs, keep=None, ref_keep=None, box_tol=1e-3, near_tie=2
 
 
 @pytest.mark.parametrize('tag,cfgc', [('r18vd_320', PPYOLO_r18vd_Config), ('r50vd_160', PPYOLO_2x_Config)])
-@pytest.mark.parametrize('graph', ['0', '1'])
-def test_end_to_end_golden(golden, tag, cfgc, graph, monkeypatch):
+@pytest.mark.parametrize('graph,math', [('0', 'bf16x3'), ('1', 'bf16x3'), ('1', 'fp32')])
+def test_end_to_end_golden(golden, tag, cfgc, graph, math, monkeypatch):
     monkeypatch.setenv('PPYOLO_HIP_GRAPH', graph)
+    monkeypatch.setenv('PPYOLO_HIP_MATH', math)
     g = golden('g7_' + tag)
     S, N, seed, iseed = [int(v) for v in g['meta']]
     cfg = cfgc()
@@ -172,10 +173,13 @@ def test_full_size_vs_oracle_and_batch_properties(cfgc, S):
         assert 1 <= p.shape[0] <= 100 and torch.all(p[:-1, 1] >= p[1:, 1]), 'scores not sorted descending'
 
 
-def test_fp64_three_way():
+@pytest.mark.parametrize('math', ['bf16x3', 'fp32'])
+def test_fp64_three_way(math, monkeypatch):
     """What "parity" means for a 70-layer fp32 network: run the oracle in float64 as the exact
-    answer; the HIP path must be as close to it as the reference's own fp32 forward is
-    (measured on MI355X: head outputs rms error 1.3-2.1e-6 HIP vs 1.7-3.0e-6 reference)."""
+    answer; the HIP path -- in both math modes: bf16x3 split products on the bf16 MFMA (default) and the
+    exact-fp32 MFMA -- must be as close to it as the reference's own fp32 forward is (measured on MI355X:
+    head outputs rms error 1.3-2.1e-6 HIP vs 1.7-3.0e-6 reference)."""
+    monkeypatch.setenv('PPYOLO_HIP_MATH', math)
     cfg = PPYOLO_2x_Config()
     model, sd = build_model(cfg, 0, 'cuda')
     S, N = 320, 2
@@ -191,8 +195,10 @@ def test_fp64_three_way():
         h = ex.view(a).dense().permute(0, 3, 1, 2).cpu().double()
         e_hip = (h - o64[i]).pow(2).mean().sqrt().item()
         e_ref = (o32[i].double() - o64[i]).pow(2).mean().sqrt().item()
+        print('math %s level %d: rms error vs fp64: HIP %.3e, reference fp32 %.3e' % (math, i, e_hip, e_ref))
         assert e_hip <= 1.5 * e_ref + 1e-7, 'level %d: HIP rms error %.3e vs reference fp32 %.3e' % (i, e_hip, e_ref)
         assert (h - o64[i]).abs().max() <= 1e-4
+    assert ex.math == math and (math == 'fp32') == all(op.get('w3') is None for op in ex.plan.ops)
 
 
 def test_autotuned_plan_same_answer():

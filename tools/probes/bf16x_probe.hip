@@ -59,6 +59,9 @@ __global__ void probe(const float* A, const float* B, float* C, int K, int mode,
 }
 
 int main() {
+  printf("# 3-way bf16 split of both operands (a = a0+a1+a2 exactly); N products = the N largest of the 9 partial\n"
+         "# products on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The conv kernels (conv_x3.hip) use 6 products, RNE split.\n"
+         "# dist 0: uniform [-1,1) x 0.05*uniform; dist 1: |u|*exp(3u) (relu-like, wide range) x 0.05*uniform.  32x32 outputs.\n");
   const int Ks[3] = {256, 2304, 4608};
   for (int dist = 0; dist < 2; ++dist)
     for (int ki = 0; ki < 3; ++ki) {
@@ -87,8 +90,8 @@ int main() {
         hipMemcpy(Cc.data(), dC, 4096, hipMemcpyDeviceToHost);
         double mx = 0, ss = 0;
         for (int e = 0; e < 1024; ++e) { double d = (Cc[e] - ref[e]) / mag[e]; mx = fmax(mx, fabs(d)); ss += d * d; }
-        printf("dist %d K %5d  %-18s max|err|/sum|ab| %.3e   rms %.3e\n", dist, K,
-               modes[mi] == 0 ? "fp32 mfma" : (trunc ? "bf16x6 trunc" : (modes[mi] == 3 ? "bf16x3" : modes[mi] == 6 ? "bf16x6" : modes[mi] == 8 ? "bf16x8" : "bf16x9")), mx, sqrt(ss / 1024));
+        printf("dist %d K %5d  %-20s max|err|/sum|ab| %.3e   rms %.3e\n", dist, K,
+               modes[mi] == 0 ? "fp32 mfma" : (trunc ? "6 products (trunc)" : (modes[mi] == 3 ? "3 products" : modes[mi] == 6 ? "6 products" : modes[mi] == 8 ? "8 products" : "9 products")), mx, sqrt(ss / 1024));
       }
       hipFree(dA); hipFree(dB); hipFree(dC);
     }
