@@ -268,7 +268,8 @@ def main():
                     peak_note='achieved = algorithmic fp32 FLOPs / HIP-event time of the conv launches; peak = the same '
                               'FLOPs / MFMA-pipe time at peak, where a bf16x3 launch is priced at %.1f (= dense bf16 '
                               'MFMA %.1f / 6 products per multiply-add) and an exact-fp32 launch at %.1f TFLOP/s; '
-                              '%.1f%% of the FLOPs ran on bf16x3 kernels' % (
+                              '%.1f%% of the FLOPs ran on bf16x3 kernels.  Peaks are at the nominal 2.4 GHz; under dense bf16 MFMA on '
+                              'real operands the chip runs 1.6-1.8 GHz (power management; DESIGN.md 4.1)' % (
                                   X3_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS,
                                   100.0 * x3_flops / max(1, covered)),
                     achieved_vs_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

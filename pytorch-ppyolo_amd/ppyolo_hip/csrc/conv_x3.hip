@@ -389,6 +389,7 @@ constexpr X3Cfg kX3[] = {
     {256, 128, 64, 64, 2},    // 5  8 waves (4x2), 112 KB
     {128, 256, 64, 128, 2},   // 6  4 waves (2x2), 128 KB
     {64, 128, 32, 64, 2},     // 7  4 waves (2x2), 64 KB
+    {64, 64, 32, 32, 2},      // 8  4 waves (2x2), 40 KB: four workgroups per CU for the store-bound 1x1 expand layers
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
@@ -450,6 +451,7 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 5: return launch_x3<256, 128, 64, 64, 2>(p, s, st);
         case 6: return launch_x3<128, 256, 64, 128, 2>(p, s, st);
         case 7: return launch_x3<64, 128, 32, 64, 2>(p, s, st);
+        case 8: return launch_x3<64, 64, 32, 32, 2>(p, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

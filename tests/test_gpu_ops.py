@@ -58,7 +58,7 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-NUM_CFGS = 39      # 31 exact-fp32 MFMA configurations + 8 bf16x3 (conv_x3.hip)
+NUM_CFGS = 40      # 31 exact-fp32 MFMA configurations + 9 bf16x3 (conv_x3.hip)
 
 
 @pytest.mark.parametrize('cfg', range(NUM_CFGS))
