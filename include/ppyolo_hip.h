@@ -153,12 +153,15 @@ int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A,
  * out_dets [N][keep_top_k][6] = (label, score, x0,y0,x1,y1), rows >= out_count[n] are
  * -1; out_count[n] == 0 <=> the reference returns its [[-1]*6] sentinel.
  * out_keep_idx [N][keep_top_k] = box*C + class of every kept row (-1 padding).
- * Limits: 1 <= nms_top_k <= 1024, keep_top_k <= nms_top_k. */
+ * Limits: 1 <= nms_top_k <= 1024, keep_top_k <= nms_top_k.
+ * ws: ppy_matrix_nms_workspace_bytes(N) bytes of scratch, 16-byte aligned (the sorted top-k boxes and the
+ * per-column compensate / decay values travel between the four kernels of one call through it). */
+size_t ppy_matrix_nms_workspace_bytes(int N);
 int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_classes, const uint32_t *cand_key,
                        const uint32_t *cand_idx, const int *cand_count, int cand_cap, int N,
                        float post_threshold, int nms_top_k, int keep_top_k, int use_gaussian,
                        float gaussian_sigma, float *out_dets, int *out_count, int *out_keep_idx,
-                       void *stream);
+                       void *ws, size_t ws_bytes, void *stream);
 /* Candidate extraction from dense scores [N][M][C] (the reference's own input form,
  * model/matrix_nms.py:110-117), for callers that hold yolo_box outputs. */
 int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, float score_threshold,

@@ -44,7 +44,9 @@ _PROTOS = {
                                     c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'ppy_matrix_nms_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
-                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    'ppy_matrix_nms_workspace_bytes': (c_size_t, [c_int]),
     'ppy_nms_candidates_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                        c_int, c_void_p]),
 }

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256) dense_candidates_kernel(const float *__re
 constexpr int NT = 1024;      // threads
 constexpr int KMAX = 1024;    // max nms_top_k
 constexpr int RBITS = 11;     // radix-select digit
+constexpr int CCAP = 8192;    // candidates staged in LDS (64 KB of dynamic shared memory)
 
 // inclusive suffix sum over the workgroup (threads >= tid)
 __device__ __forceinline__ int block_suffix_sum(int v, int *scratch /*[16+1]*/) {
@@ -276,22 +277,35 @@ __device__ __forceinline__ int block_suffix_sum(int v, int *scratch /*[16+1]*/) 
     return s + add;
 }
 
-__device__ __forceinline__ void bitonic_sort_desc(unsigned long long *keys, int P) {
+// Descending sort of n <= KMAX DISTINCT non-zero keys (zeros = padding, they all land behind the real keys)
+// by counting: rank(e) = #{i : key[i] > key[e]}.  Every thread of a wave reads the same key[i] (LDS
+// broadcast), P2/NT threads share an element, and the whole sort costs two barriers instead of the
+// log^2 barrier-separated stages of a bitonic network (1024-thread barriers are what this kernel waits on).
+__device__ __forceinline__ void rank_sort_desc(const unsigned long long *in, unsigned long long *out, int n, int P2,
+                                               int *rank /*[KMAX]*/) {
     const int tid = threadIdx.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int ixj = tid ^ j;
-            if (tid < P && ixj > tid) {
-                const unsigned long long a = keys[tid], b = keys[ixj];
-                const bool desc = (tid & k) == 0;
-                if (desc ? (a < b) : (a > b)) {
-                    keys[tid] = b;
-                    keys[ixj] = a;
-                }
-            }
-            __syncthreads();
+    const int parts = NT / P2;                 // threads per element (P2 = power of two >= n, >= 64)
+    const int e = tid & (P2 - 1), part = tid / P2;
+    if (tid < KMAX) rank[tid] = 0;
+    if (tid < KMAX) out[tid] = 0ull;
+    __syncthreads();
+    if (e < n) {
+        const unsigned long long mine = in[e];
+        const int len = (n + parts - 1) / parts, lo = part * len, hi = min(lo + len, n);
+        int r = 0, i = lo;
+        for (; i + 8 <= hi; i += 8) {          // 8 independent LDS reads in flight (the loop is latency-bound otherwise)
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += v[u] > mine ? 1 : 0;
         }
+        for (; i < hi; ++i) r += in[i] > mine ? 1 : 0;
+        if (parts == 1) rank[e] = r; else atomicAdd(&rank[e], r);
     }
+    __syncthreads();
+    if (tid < n && in[tid] != 0ull) out[rank[tid]] = in[tid];
+    __syncthreads();
 }
 
 __device__ __forceinline__ float nanmin_(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
@@ -304,14 +318,30 @@ struct NmsArgs {
     int *out_count, *out_keep;
     int M_total, C, cand_cap, top_k, keep_k, gaussian, idx_bits;
     float post_thr, sigma;
+    char *ws;                  // per-image intermediates between the four kernels (NmsWs below)
 };
 
-__global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
-    __shared__ unsigned long long skey[KMAX];
-    __shared__ __attribute__((aligned(16))) float sbox[KMAX][4];
-    __shared__ float sscore[KMAX], scomp[KMAX], sdecay[KMAX], ssuf[KMAX];
-    __shared__ int slabel[KMAX], sflat[KMAX];
+// Matrix-NMS runs as FOUR kernels.  As one 1024-thread workgroup per image (the first version) it took
+// 141 us per step, 71 % of it in the two pairwise phases: 125 k box pairs x ~45 VALU instructions incl. two
+// IEEE divisions is simply VALU-bound on ONE CU, while 248 CUs idle.  Now:
+//   A  nms_select_kernel  (1 workgroup / image)   top-k select + sort + box gather           -> ws
+//   B  nms_colmax_kernel  (NMS_G workgroups / image)  compensate-IoU column maxima of a column slice -> ws.comp
+//   C  nms_decay_kernel   (NMS_G workgroups / image)  decay column minima of a column slice          -> ws.decay
+//   D  nms_finish_kernel  (1 workgroup / image)   rescore, post-threshold, second sort, keep_top_k
+// Kernel boundaries are the synchronisation (no spin-waits, no cross-XCD coherence games); arithmetic and
+// order of every value are unchanged, so the results stay bit-identical.
+constexpr int NMS_G = 8;
+struct NmsWs {                 // one per image
+    float box[KMAX][4];
+    float score[KMAX], comp[KMAX], decay[KMAX];
+    int label[KMAX], flat[KMAX];
+    int K, pad[15];
+};
+
+__global__ void __launch_bounds__(NT) nms_select_kernel(const NmsArgs p) {
+    __shared__ unsigned long long skey[KMAX], skey2[KMAX];
     __shared__ unsigned int hist[1 << RBITS];
+    int *srank = reinterpret_cast<int *>(hist);                 // the histogram is dead once the threshold is known
     __shared__ int scratch[32];
     __shared__ int s_bin, s_above, s_binc, s_cnt;
 
@@ -326,14 +356,38 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
 
     for (int i = tid; i < p.keep_k * 6; i += NT) dets[i] = -1.0f;
     for (int i = tid; i < p.keep_k; i += NT) keep[i] = -1;
+    NmsWs *w = reinterpret_cast<NmsWs *>(p.ws) + n;
     if (count == 0) {
-        if (tid == 0) p.out_count[n] = 0;
+        if (tid == 0) { p.out_count[n] = 0; w->K = 0; }
         return;
     }
     // composite key: larger == earlier in (score desc, candidate index asc)
-    auto comp_of = [&](int c) -> unsigned long long {
+    auto comp_global = [&](int c) -> unsigned long long {
         return ((unsigned long long)ckey[c] << ib) | (idx_mask - (unsigned long long)cidx[c]);
     };
+    // The select passes below walk the candidate list up to six times; from global memory every walk is a
+    // chain of dependent ~2 us loads (an LDS atomic sits between consecutive iterations).  Lists of up to
+    // CCAP candidates are therefore staged in LDS once, with all loads of a thread in flight together.
+    extern __shared__ unsigned long long scache[];      // [CCAP] (dynamic)
+    const bool cached = count <= CCAP;
+    if (cached) {
+        for (int base = 0; base < count; base += NT * 8) {
+            uint32_t kk[8], ii[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = base + u * NT + tid;
+                kk[u] = c < count ? ckey[c] : 0u;
+                ii[u] = c < count ? cidx[c] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = base + u * NT + tid;
+                if (c < count) scache[c] = ((unsigned long long)kk[u] << ib) | (idx_mask - (unsigned long long)ii[u]);
+            }
+        }
+        __syncthreads();
+    }
+    auto comp_of = [&](int c) -> unsigned long long { return cached ? scache[c] : comp_global(c); };
 
     // ---- 1. top-k threshold by MSB-first radix select (reference :120-125) ----
     const int K = min(p.top_k, count);
@@ -384,80 +438,105 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
     __syncthreads();
     int P = 64;
     while (P < K) P <<= 1;
-    bitonic_sort_desc(skey, P);
+    rank_sort_desc(skey, skey2, K, P, srank);
     if (tid < K) {
-        const unsigned long long k = skey[tid] - 1ull;
+        const unsigned long long k = skey2[tid] - 1ull;
         const int flat = (int)(idx_mask - (k & idx_mask));
         const int box = flat / p.C;
-        sflat[tid] = flat;
-        slabel[tid] = flat - box * p.C;
-        sscore[tid] = key_to_score((uint32_t)(k >> ib));
-        const floatx4 b = *reinterpret_cast<const floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4);
-        sbox[tid][0] = b[0]; sbox[tid][1] = b[1]; sbox[tid][2] = b[2]; sbox[tid][3] = b[3];
+        w->flat[tid] = flat;
+        w->label[tid] = flat - box * p.C;
+        w->score[tid] = key_to_score((uint32_t)(k >> ib));
+        *reinterpret_cast<floatx4 *>(&w->box[tid][0]) =
+            *reinterpret_cast<const floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4);
+    }
+    if (tid == 0) w->K = K;
+}
+
+
+// D[i][j] = IoU(i,j) * same_class(i,j) for i < j.  One WAVE per column j, lanes stride over the rows i < j,
+// wave butterfly reductions; NaN propagates through max / min exactly like torch.max / torch.min.
+__device__ __forceinline__ float nms_dval(const float (*sbox)[4], const int *slabel, int i, int lj, float bj0, float bj1,
+                                          float bj2, float bj3, float area_j) {
+    const floatx4 a = *reinterpret_cast<const floatx4 *>(&sbox[i][0]);
+    const float iw = fmaxf(fminf(a[2], bj2) - fmaxf(a[0], bj0), 0.0f);
+    const float ih = fmaxf(fminf(a[3], bj3) - fmaxf(a[1], bj1), 0.0f);
+    const float inter = iw * ih;
+    const float area_i = (a[2] - a[0]) * (a[3] - a[1]);
+    const float iou = inter / ((area_i + area_j) - inter);
+    return iou * (slabel[i] == lj ? 1.0f : 0.0f);
+}
+
+// 3a. compensate IoU: column max over the whole column (zeros on/below the diagonal)   (reference _matrix_nms :51-97)
+__global__ void __launch_bounds__(NT) nms_colmax_kernel(const NmsArgs p) {
+    __shared__ __attribute__((aligned(16))) float sbox[KMAX][4];
+    __shared__ int slabel[KMAX];
+    NmsWs *w = reinterpret_cast<NmsWs *>(p.ws) + blockIdx.y;
+    const int K = w->K, tid = threadIdx.x;
+    if (K == 0) return;
+    if (tid < K) {
+        *reinterpret_cast<floatx4 *>(&sbox[tid][0]) = *reinterpret_cast<const floatx4 *>(&w->box[tid][0]);
+        slabel[tid] = w->label[tid];
     }
     __syncthreads();
-
-    // ---- 3. Matrix-NMS decay (reference _matrix_nms :51-97) ----
-    // D[i][j] = IoU(i,j) * same_class(i,j) for i < j (0 elsewhere).  Two threads per column j
-    // split the i range; NaN propagates through max/min exactly like torch.max / torch.min.
-    // Pairwise phase: one WAVE per column j (columns dealt round-robin to the 16 waves), lanes
-    // stride over the rows i < j, wave butterfly reductions.  NaN propagates through max / min
-    // exactly like torch.max / torch.min (any NaN in the column -> NaN).
-    const int lane = tid & 63, wv = tid >> 6;
-    auto dval = [&](int i, int lj, float bj0, float bj1, float bj2, float bj3, float area_j) -> float {
-        const floatx4 a = *reinterpret_cast<const floatx4 *>(&sbox[i][0]);
-        const float iw = fmaxf(fminf(a[2], bj2) - fmaxf(a[0], bj0), 0.0f);
-        const float ih = fmaxf(fminf(a[3], bj3) - fmaxf(a[1], bj1), 0.0f);
-        const float inter = iw * ih;
-        const float area_i = (a[2] - a[0]) * (a[3] - a[1]);
-        const float iou = inter / ((area_i + area_j) - inter);
-        return iou * (slabel[i] == lj ? 1.0f : 0.0f);
-    };
-    // 3a. compensate IoU: column max over the whole column (zeros on/below the diagonal)
-    for (int j = wv; j < K; j += NT / 64) {
+    const int lane = tid & 63, gw = blockIdx.x * (NT / 64) + (tid >> 6), TW = gridDim.x * (NT / 64);
+    for (int j = gw; j < K; j += TW) {
         const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
         const float area_j = (bj2 - bj0) * (bj3 - bj1);
         const int lj = slabel[j];
         float mx = 0.0f;
         bool nan = false;
         for (int i = lane; i < j; i += 64) {
-            const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
+            const float d = nms_dval(sbox, slabel, i, lj, bj0, bj1, bj2, bj3, area_j);
             nan |= (d != d);
             mx = fmaxf(mx, d);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         const bool anynan = __ballot(nan) != 0ull;
-        if (lane == 0) scomp[j] = anynan ? NAN : mx;
+        if (lane == 0) w->comp[j] = anynan ? NAN : mx;
     }
-    __syncthreads();
-    // rows i >= j (and D == 0 entries) contribute f(i) = 1/(1-comp[i])  [gaussian: 1/exp(-s*comp^2)]
-    {
-        float f = INFINITY;
-        if (tid < K) {
-            const float c = scomp[tid];
-            f = p.gaussian ? (expf(-1.0f * p.sigma * (0.0f * 0.0f)) / expf(-1.0f * p.sigma * (c * c)))
-                           : ((1.0f - 0.0f) / (1.0f - c));
+}
+
+// 3b. decay coefficient: column min of (1-D)/(1-comp[i]) [gaussian: exp(-s D^2)/exp(-s comp^2)] over i < j, joined with
+// the rows i >= j (D == 0 there) through a suffix nan-min of f(i) = 1/(1-comp[i])
+__global__ void __launch_bounds__(NT) nms_decay_kernel(const NmsArgs p) {
+    __shared__ __attribute__((aligned(16))) float sbox[KMAX][4];
+    __shared__ int slabel[KMAX];
+    __shared__ float scomp[KMAX], ssuf[KMAX], swave[NT / 64];
+    NmsWs *w = reinterpret_cast<NmsWs *>(p.ws) + blockIdx.y;
+    const int K = w->K, tid = threadIdx.x;
+    if (K == 0) return;
+    float f = INFINITY;
+    if (tid < K) {
+        *reinterpret_cast<floatx4 *>(&sbox[tid][0]) = *reinterpret_cast<const floatx4 *>(&w->box[tid][0]);
+        slabel[tid] = w->label[tid];
+        const float c = w->comp[tid];
+        scomp[tid] = c;
+        f = p.gaussian ? (expf(-1.0f * p.sigma * (0.0f * 0.0f)) / expf(-1.0f * p.sigma * (c * c)))
+                       : ((1.0f - 0.0f) / (1.0f - c));
+    }
+    {   // suffix nan-min scan: inside each wave by shuffles, then the totals of the waves behind it
+        float v = f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_down(v, d);
+            if ((tid & 63) + d < 64) v = nanmin_(v, o);
         }
-        ssuf[tid] = f;
-    }
-    __syncthreads();
-    for (int d = 1; d < KMAX; d <<= 1) {   // suffix nan-min scan
-        float v = ssuf[tid];
-        if (tid + d < KMAX) v = nanmin_(v, ssuf[tid + d]);
+        if ((tid & 63) == 0) swave[tid >> 6] = v;
         __syncthreads();
+        for (int k = (tid >> 6) + 1; k < NT / 64; ++k) v = nanmin_(v, swave[k]);
         ssuf[tid] = v;
         __syncthreads();
     }
-    // 3b. decay coefficient: column min
-    for (int j = wv; j < K; j += NT / 64) {
+    const int lane = tid & 63, gw = blockIdx.x * (NT / 64) + (tid >> 6), TW = gridDim.x * (NT / 64);
+    for (int j = gw; j < K; j += TW) {
         const float bj0 = sbox[j][0], bj1 = sbox[j][1], bj2 = sbox[j][2], bj3 = sbox[j][3];
         const float area_j = (bj2 - bj0) * (bj3 - bj1);
         const int lj = slabel[j];
         float mn = INFINITY;
         bool nan = false;
         for (int i = lane; i < j; i += 64) {
-            const float d = dval(i, lj, bj0, bj1, bj2, bj3, area_j);
+            const float d = nms_dval(sbox, slabel, i, lj, bj0, bj1, bj2, bj3, area_j);
             const float c = scomp[i];
             const float t = p.gaussian ? (expf(-1.0f * p.sigma * (d * d)) / expf(-1.0f * p.sigma * (c * c)))
                                        : ((1.0f - d) / (1.0f - c));
@@ -467,16 +546,27 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
         const bool anynan = __ballot(nan) != 0ull;
-        if (lane == 0) sdecay[j] = nanmin_(anynan ? NAN : mn, ssuf[j]);
+        if (lane == 0) w->decay[j] = nanmin_(anynan ? NAN : mn, ssuf[j]);
     }
-    __syncthreads();
+}
 
-    // ---- 4. rescore, post-threshold (>=), second sort, keep_top_k (reference :128-145) ----
+// 4. rescore, post-threshold (>=), second sort, keep_top_k (reference matrix_nms :128-145)
+__global__ void __launch_bounds__(NT) nms_finish_kernel(const NmsArgs p) {
+    __shared__ unsigned long long skey[KMAX], skey2[KMAX];
+    __shared__ int srank[KMAX];
+    __shared__ float sscore[KMAX];
+    __shared__ int s_cnt;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    NmsWs *w = reinterpret_cast<NmsWs *>(p.ws) + n;
+    const int K = w->K;
+    if (K == 0) return;                    // out_count / padding were written by nms_select_kernel
+    float *dets = p.out_dets + (long long)n * p.keep_k * 6;
+    int *keep = p.out_keep + (long long)n * p.keep_k;
     if (tid == 0) s_cnt = 0;
     skey[tid] = 0ull;
     __syncthreads();
     if (tid < K) {
-        const float ns = sscore[tid] * sdecay[tid];
+        const float ns = w->score[tid] * w->decay[tid];
         sscore[tid] = ns;
         if (ns >= p.post_thr) {
             atomicAdd(&s_cnt, 1);
@@ -485,15 +575,17 @@ __global__ void __launch_bounds__(NT) matrix_nms_kernel(const NmsArgs p) {
     }
     __syncthreads();
     const int kept = s_cnt;
-    bitonic_sort_desc(skey, P);
+    int P = 64;
+    while (P < K) P <<= 1;
+    rank_sort_desc(skey, skey2, K, P, srank);
     const int nout = min(kept, p.keep_k);
     if (tid < nout) {
-        const int src = KMAX - 1 - (int)((skey[tid] - 1ull) & 1023ull);
+        const int src = KMAX - 1 - (int)((skey2[tid] - 1ull) & 1023ull);
         float *o = dets + tid * 6;
-        o[0] = (float)slabel[src];
+        o[0] = (float)w->label[src];
         o[1] = sscore[src];
-        o[2] = sbox[src][0]; o[3] = sbox[src][1]; o[4] = sbox[src][2]; o[5] = sbox[src][3];
-        keep[tid] = sflat[src];
+        o[2] = w->box[src][0]; o[3] = w->box[src][1]; o[4] = w->box[src][2]; o[5] = w->box[src][3];
+        keep[tid] = w->flat[src];
     }
     if (tid == 0) p.out_count[n] = nout;
 }
@@ -555,14 +647,17 @@ extern "C" int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, 
     return ppy_launch_status();
 }
 
+extern "C" size_t ppy_matrix_nms_workspace_bytes(int N) { return N > 0 ? (size_t)N * sizeof(NmsWs) : 0; }
+
 extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_classes, const uint32_t *cand_key,
                                   const uint32_t *cand_idx, const int *cand_count, int cand_cap, int N,
                                   float post_threshold, int nms_top_k, int keep_top_k, int use_gaussian,
                                   float gaussian_sigma, float *out_dets, int *out_count, int *out_keep_idx,
-                                  void *stream) {
+                                  void *ws, size_t ws_bytes, void *stream) {
     PPY_CHECK_ARG(boxes && cand_key && cand_idx && cand_count && out_dets && out_count && out_keep_idx);
     PPY_CHECK_ARG(N > 0 && M_total > 0 && num_classes > 0 && cand_cap > 0);
     PPY_CHECK_ARG(((uintptr_t)boxes & 15) == 0);
+    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < (size_t)N * sizeof(NmsWs)) return PPY_ERR_WORKSPACE;
     if (nms_top_k < 1 || nms_top_k > KMAX || keep_top_k < 1 || keep_top_k > nms_top_k) return PPY_ERR_UNSUPPORTED;
     const long long span = (long long)M_total * num_classes;
     PPY_CHECK_ARG(span < (1ll << 31));
@@ -573,6 +668,18 @@ extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_class
     p.out_dets = out_dets; p.out_count = out_count; p.out_keep = out_keep_idx;
     p.M_total = M_total; p.C = num_classes; p.cand_cap = cand_cap; p.top_k = nms_top_k; p.keep_k = keep_top_k;
     p.gaussian = use_gaussian ? 1 : 0; p.idx_bits = ib; p.post_thr = post_threshold; p.sigma = gaussian_sigma;
-    hipLaunchKernelGGL(matrix_nms_kernel, dim3(N), dim3(NT), 0, (hipStream_t)stream, p);
+    p.ws = (char *)ws;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nms_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                CCAP * 8) != hipSuccess)
+            return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_select_kernel, dim3(N), dim3(NT), CCAP * 8, st, p);
+    hipLaunchKernelGGL(nms_colmax_kernel, dim3(NMS_G, N), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(nms_decay_kernel, dim3(NMS_G, N), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(N), dim3(NT), 0, st, p);
     return ppy_launch_status();
 }

@@ -249,6 +249,7 @@ class HipExecutor(object):
             self.out_dets = torch.zeros((p.N, kk, 6), dtype=torch.float32, device=self.device)
             self.out_count = torch.zeros((p.N,), dtype=torch.int32, device=self.device)
             self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
+            self.nms_ws = K.matrix_nms_workspace(p.N, self.device)
         self.math = math_mode()
         self._to_device(p.setup_ops)
         self._to_device(p.ops)
@@ -384,7 +385,7 @@ class HipExecutor(object):
         n = d['nms']
         K.matrix_nms(self.boxes, d['num_classes'], self.cand_key, self.cand_idx, self.cand_count,
                      n['post_threshold'], n['nms_top_k'], n['keep_top_k'], n['use_gaussian'], n['gaussian_sigma'],
-                     self.out_dets, self.out_count, self.out_keep)
+                     self.out_dets, self.out_count, self.out_keep, self.nms_ws)
 
     def _launch_all(self):
         if not self.multi_stream:

@@ -180,12 +180,20 @@ def nms_candidates(scores, score_threshold, cand_key, cand_idx, cand_count):
           'ppy_nms_candidates_f32')
 
 
+def matrix_nms_workspace(N, device):
+    """Scratch tensor for matrix_nms on a batch of N images."""
+    return torch.empty((int(lib().ppy_matrix_nms_workspace_bytes(N)) + 3) // 4, dtype=torch.float32, device=device)
+
+
 def matrix_nms(boxes, num_classes, cand_key, cand_idx, cand_count, post_threshold, nms_top_k, keep_top_k,
-               use_gaussian, gaussian_sigma, out_dets, out_count, out_keep):
+               use_gaussian, gaussian_sigma, out_dets, out_count, out_keep, ws=None):
     _dev(boxes, cand_key, cand_idx, cand_count, out_dets, out_count, out_keep)
     N, M, _ = boxes.shape
+    if ws is None:
+        ws = matrix_nms_workspace(N, boxes.device)
     check(lib().ppy_matrix_nms_f32(boxes.data_ptr(), M, num_classes, cand_key.data_ptr(), cand_idx.data_ptr(),
                                    cand_count.data_ptr(), cand_key.shape[1], N, float(post_threshold),
                                    int(nms_top_k), int(keep_top_k), int(bool(use_gaussian)), float(gaussian_sigma),
-                                   out_dets.data_ptr(), out_count.data_ptr(), out_keep.data_ptr(), _stream()),
+                                   out_dets.data_ptr(), out_count.data_ptr(), out_keep.data_ptr(), ws.data_ptr(),
+                                   ws.numel() * ws.element_size(), _stream()),
           'ppy_matrix_nms_f32')
