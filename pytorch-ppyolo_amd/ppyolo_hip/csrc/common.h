@@ -13,6 +13,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
         if (!(cond)) return PPY_ERR_BAD_ARG; \
     } while (0)
 
+// hipGetLastError() is sticky per thread: an error left behind by the CALLER's own runtime calls (PyTorch probes
+// host pointers with hipPointerGetAttributes, which fails benignly) would otherwise be reported as ours.
+static inline void ppy_drop_stale_error() { (void)hipGetLastError(); }
+
 static inline int ppy_launch_status() {
     return hipGetLastError() == hipSuccess ? PPY_OK : PPY_ERR_LAUNCH;
 }

@@ -577,6 +577,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
                                      const float *posbias, float *y, int y_ld, int N, int H, int W, int C,
                                      int K, int R, int S, int stride, int pad, int act, int upsample2x,
                                      int cfg, int splitk, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x && w_krsc && scale && shift && y);
     Geometry g;
     if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;

@@ -457,6 +457,7 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
 }
 
 extern "C" int ppy_conv2d_split_weights_bf16x3(const float *w, long long n, void *out, void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(w && out && n > 0);
     const long long pairs = (n + 1) / 2;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,

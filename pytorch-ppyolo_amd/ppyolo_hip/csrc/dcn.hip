@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) dcn_sample_kernel(const float *__restrict
 extern "C" int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offset_mask, int om_ld, float *cols,
                                     int N, int H, int W, int C, int Ho, int Wo, int stride, int pad,
                                     void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x && offset_mask && cols);
     PPY_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && x_ld >= C && x_ld % 4 == 0 && om_ld >= 27);
     PPY_CHECK_ARG(stride > 0 && pad >= 0);

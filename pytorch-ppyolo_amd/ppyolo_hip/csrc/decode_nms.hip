@@ -598,6 +598,7 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
                                    int M_total, int box_offset, float score_threshold, uint32_t *cand_key,
                                    uint32_t *cand_idx, int *cand_count, int cand_cap, float *scores_dense,
                                    void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(head_out && h_anchors_px && im_size && boxes && cand_key && cand_idx && cand_count);
     PPY_CHECK_ARG(N > 0 && S > 0 && A > 0 && A <= 8 && num_classes > 0 && downsample > 0 && cand_cap > 0);
     const int nch = A * (5 + num_classes) + (iou_aware ? A : 0);
@@ -637,6 +638,7 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
 extern "C" int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, float score_threshold,
                                       uint32_t *cand_key, uint32_t *cand_idx, int *cand_count, int cand_cap,
                                       void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(scores && cand_key && cand_idx && cand_count && N > 0 && M > 0 && C > 0 && cand_cap > 0);
     PPY_CHECK_ARG((long long)M * C < (1ll << 31));
     const long long total = (long long)M * C;
@@ -654,6 +656,7 @@ extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_class
                                   float post_threshold, int nms_top_k, int keep_top_k, int use_gaussian,
                                   float gaussian_sigma, float *out_dets, int *out_count, int *out_keep_idx,
                                   void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(boxes && cand_key && cand_idx && cand_count && out_dets && out_count && out_keep_idx);
     PPY_CHECK_ARG(N > 0 && M_total > 0 && num_classes > 0 && cand_cap > 0);
     PPY_CHECK_ARG(((uintptr_t)boxes & 15) == 0);

@@ -180,6 +180,7 @@ int grid_for(long long total) {
 extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
                                            const float *shift, float *y, int y_ld, int N, int H, int W,
                                            int K, int act, void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x_nchw && w_kcrs && scale && shift && y);
     PPY_CHECK_ARG(N > 0 && H > 0 && W > 0 && K > 0 && K % 16 == 0 && y_ld >= K && y_ld % 4 == 0);
     PPY_CHECK_ARG(((uintptr_t)y & 15) == 0);
@@ -193,6 +194,7 @@ extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_k
 
 extern "C" int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C,
                                     void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     PPY_CHECK_ARG(x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
     PPY_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
@@ -205,6 +207,7 @@ extern "C" int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld
 
 extern "C" int ppy_avgpool2x2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C,
                                   void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x && y && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0);
     PPY_CHECK_ARG(x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
     PPY_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
@@ -217,6 +220,7 @@ extern "C" int ppy_avgpool2x2_f32(const float *x, int x_ld, float *y, int y_ld, 
 
 extern "C" int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int y_ld, int N, int H,
                            int W, int C, void *stream) {
+    ppy_drop_stale_error();
     PPY_CHECK_ARG(x && y5 && y9 && y13 && N > 0 && H > 0 && W > 0 && C > 0 && C % SPP_CC == 0);
     PPY_CHECK_ARG(x_ld >= C && y_ld >= C);
     const size_t lds = (size_t)3 * H * W * SPP_CC * sizeof(float);

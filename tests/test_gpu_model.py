@@ -225,3 +225,10 @@ def test_other_input_sizes_use_heuristic_configs(cfgc, S, N):
     dets, cnt, keep = model.forward_padded(x.cuda(), ims.cuda())
     ref = orc.ppyolo_forward(sd, cfg, x, ims, return_index=True)
     _check_preds(preds, [r[0] for r in ref], keep.clone(), [r[1] for r in ref], box_tol=3e-3)
+
+
+def test_graft_entry_smoke():
+    """The driver's round-end smoke check, run as a test so that a regression shows up here first (the library
+    once reported PyTorch's own stale hipGetLastError as a launch failure on exactly this path)."""
+    import __graft_entry__ as ge
+    ge.smoke()
