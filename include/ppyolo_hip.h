@@ -69,15 +69,29 @@ const char *ppy_error_string(int code);
  * fp32 out, error vs fp64 at the level of the exact-fp32 fma chain (csrc/conv_x3.hip,
  * profiles/r01_bf16x3_numerics.txt), 6/16 of the fp32-MFMA cost.  Without w_x3 those ids
  * return PPY_ERR_BAD_ARG.
+ * w_f16x2 / scale_f16x2: NULL, or the outputs of ppy_conv2d_split_weights_f16x2: the weights times a per-output-
+ * channel power of two as two fp16 planes ([2][K][R][S][C], 4*K*R*S*C bytes) and `scale` with the inverse of that
+ * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40): 2-term fp16 split of both operands,
+ * 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation; the activations are scaled on the fly by the
+ * power of two that puts the tensor maximum into [2^13, 2^14), read from `amax_in`.  Error vs fp64 at the level of
+ * the exact-fp32 fma chain (tools/probes/f16x2_probe.hip, profiles/r01_f16x2_numerics.txt).  Needs amax_in and
+ * posbias == NULL, else PPY_ERR_BAD_ARG.
+ * amax_in / amax_out: NULL, or PPY_AMAX_FLOATS floats each: the running max|.| of the input tensor (an upper bound is
+ * enough) and the slots into which this launch merges max|y| of what it stores (atomic max; the owner zeroes the
+ * slots before the first producer of a tensor runs).  A consumer takes the maximum over all PPY_AMAX_FLOATS values.
  */
+#define PPY_AMAX_FLOATS 1024 /* 64 slots, one 64-byte line apart */
 int ppy_conv2d_split_weights_bf16x3(const float *w_krsc, long long n_elems, void *out_planes,
                                     void *stream);
-int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
+int ppy_conv2d_split_weights_f16x2(const float *w_krsc, int K, long long kred, const float *scale,
+                                   void *out_planes, float *scale_out, void *stream);
+int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                          const void *w_f16x2, const float *scale, const float *scale_f16x2,
                           const float *shift, const float *residual, int res_ld,
                           const float *posbias, float *y, int y_ld, int N, int H, int W,
                           int C, int K, int R, int S, int stride, int pad, int act,
-                          int upsample2x, int cfg, int splitk, void *ws, size_t ws_bytes,
-                          void *stream);
+                          int upsample2x, int cfg, int splitk, const float *amax_in, float *amax_out,
+                          void *ws, size_t ws_bytes, void *stream);
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int cfg, int splitk);
 int ppy_conv2d_num_configs(void);
@@ -115,10 +129,11 @@ int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int 
 int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offset_mask, int om_ld,
                          float *cols, int N, int H, int W, int C, int Ho, int Wo, int stride,
                          int pad, void *stream);
-int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
-                  const float *shift, const float *offset_mask, int om_ld, float *y, int y_ld,
-                  int N, int H, int W, int C, int K, int stride, int pad, int act, int cfg,
-                  int splitk, void *ws, size_t ws_bytes, void *stream);
+int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const void *w_f16x2,
+                  const float *scale, const float *scale_f16x2, const float *shift,
+                  const float *offset_mask, int om_ld, float *y, int y_ld, int N, int H, int W, int C,
+                  int K, int stride, int pad, int act, int cfg, int splitk, const float *amax_in,
+                  float *amax_out, void *ws, size_t ws_bytes, void *stream);
 size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int cfg,
                                  int splitk);
 
@@ -145,6 +160,16 @@ int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A,
                         const float *im_size, float *boxes, int M_total, int box_offset,
                         float score_threshold, uint32_t *cand_key, uint32_t *cand_idx,
                         int *cand_count, int cand_cap, float *scores_dense, void *stream);
+
+/* The same for ALL head levels of a model in one launch (per-level arrays of length nlevels <= 4; the anchor
+ * count A is common to the levels).  No dense-score output.  Candidate order inside an image's list differs
+ * from level-by-level calls (the list is an unordered set; matrix_nms orders by (score, index)). */
+int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_out, const int *head_ld, const int *S,
+                               const int *downsample, const float *const *h_anchors_px,
+                               const int *box_offset, int N, int A, int num_classes, double scale_x_y,
+                               int iou_aware, double iou_aware_factor, int clip_bbox, const float *im_size,
+                               float *boxes, int M_total, float score_threshold, uint32_t *cand_key,
+                               uint32_t *cand_idx, int *cand_count, int cand_cap, void *stream);
 
 /* matrix_nms (reference model/matrix_nms.py:102-151) for a batch, from the candidate
  * lists produced by ppy_yolo_decode_f32 / ppy_nms_candidates_f32.

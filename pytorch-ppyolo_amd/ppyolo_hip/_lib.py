@@ -25,8 +25,10 @@ _PROTOS = {
     'ppy_version': (c_int, []),
     'ppy_error_string': (ctypes.c_char_p, [c_int]),
     'ppy_conv2d_split_weights_bf16x3': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
-    'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                       c_void_p, c_void_p, c_int] + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_conv2d_split_weights_f16x2': (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_int] + [c_int] * 13
+                              + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'ppy_conv2d_num_configs': (c_int, []),
     'ppy_conv2d_pick': (c_int, [c_int] * 9 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -37,12 +39,15 @@ _PROTOS = {
     'ppy_spp_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                             c_void_p]),
     'ppy_dcnv2_sample_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p]),
-    'ppy_dcnv2_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
-                      + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_dcnv2_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_int] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_dcnv2_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_yolo_decode_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), c_int,
                                     c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'ppy_yolo_decode_levels_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                           c_int, c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int, c_float,
+                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'ppy_matrix_nms_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                    c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),

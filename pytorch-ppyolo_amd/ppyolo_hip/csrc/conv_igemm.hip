@@ -572,11 +572,13 @@ static unsigned long long *g_trace = nullptr;
 // (4 x u64 per workgroup); tools/conv_trace.py turns that into a per-CU timeline.
 extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 
-extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
+extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                                     const void *w_f16x2, const float *scale, const float *scale_f16x2,
                                      const float *shift, const float *residual, int res_ld,
                                      const float *posbias, float *y, int y_ld, int N, int H, int W, int C,
                                      int K, int R, int S, int stride, int pad, int act, int upsample2x,
-                                     int cfg, int splitk, void *ws, size_t ws_bytes, void *stream) {
+                                     int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
+                                     size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && w_krsc && scale && shift && y);
     Geometry g;
@@ -596,7 +598,8 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;
     }
     ConvArgs p;
-    p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
+    p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.wf16 = (const unsigned short *)w_f16x2;
+    p.scale_f16 = scale_f16x2; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
     p.y = y; p.part = (float *)ws;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;

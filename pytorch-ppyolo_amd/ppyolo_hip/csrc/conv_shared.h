@@ -6,6 +6,10 @@
 struct ConvArgs {
     const float *x, *w, *scale, *shift, *res, *posb;
     const unsigned short *w3;    // weights as 3 bf16 planes [3][K][R][S][C] (conv_x3.hip), or NULL
+    const unsigned short *wf16;  // weights * per-channel power of two as 2 fp16 planes [2][K][R][S][C], or NULL
+    const float *scale_f16;      // `scale` with the inverse weight scale folded in (f16x2 kernels)
+    const float *amax_in;        // tracked max|x| of the input tensor (AMAX_SLOTS slots), or NULL
+    float *amax_out;             // where this launch records max|y| (AMAX_SLOTS slots), or NULL
     float *y, *part;
     int x_ld, res_ld, y_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
@@ -26,8 +30,20 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-__device__ __forceinline__ void epilogue_store(const ConvArgs &p, int m, int col, float v,
-                                               float sc, float sh) {
+// Producer-side tracking of max|y| of a tensor (the f16x2 kernels scale their input by a power of two derived from it).
+// To keep thousands of waves off one address the maximum lives in AMAX_SLOTS slots, AMAX_STRIDE floats apart (one
+// 64-byte line each); a consumer takes the maximum over the slots.  Values are non-negative, so the unsigned image
+// of the float orders like the float.  The owner zeroes the slots before the producers run.
+constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 16;
+__device__ __forceinline__ void amax_track(float mx, float *amax, int slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f)
+        atomicMax(reinterpret_cast<unsigned *>(amax) + (slot & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(mx));
+}
+
+__device__ __forceinline__ float epilogue_store(const ConvArgs &p, int m, int col, float v,
+                                                float sc, float sh) {
     const int hw = p.Ho * p.Wo;
     if (p.posb) v += p.posb[(long long)(m % hw) * p.K + col];
     v = fmaf(v, sc, sh);
@@ -45,6 +61,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs &p, int m, int col
         o[W2 * p.y_ld] = v;
         o[(W2 + 1) * p.y_ld] = v;
     }
+    return v;
 }
 
 // Epilogue shared by both kernels.  Must be entered after a workgroup barrier that follows the
@@ -62,6 +79,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
         // The main loop ended with a barrier, so nobody reads the operand tiles any more.
         float *sE = smem + wave * (32 * LDS_LD);
         const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+        float amx = 0.0f;            // max|y| of what this lane stores (p.amax_out)
         // All residual loads of the wave's sub-tile are issued up front (4*TM*TN x 16 B per lane): the 1x1
         // "expand" layers are bound by this read and the store below, and four loads in flight per wave
         // (one 32x32 tile at a time) left HBM at ~2.6 TB/s on them.
@@ -116,6 +134,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                                 float o = fmaf(v[u], sc[u], sh[u]);
                                 if (p.res) o += rv[i][j][t][u];
                                 v[u] = ppy_apply_act(o, p.act);
+                                amx = fmaxf(amx, fabsf(v[u]));
                             }
                             if (!p.ups) {
                                 *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
@@ -135,8 +154,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (!SPLIT && p.amax_out) amax_track(amx, p.amax_out, blockIdx.x * 8 + wave);
         return;
     }
+    float amx = 0.0f;
     // ---- scalar epilogue: lane l holds channel (l&31) of 16 pixels per 32x32 tile ----
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -157,11 +178,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                     if (SPLIT)
                         p.part[((long long)split * p.M + m) * p.K + col] = acc[i][j][e];
                     else
-                        epilogue_store(p, m, col, acc[i][j][e], sc, sh);
+                        amx = fmaxf(amx, fabsf(epilogue_store(p, m, col, acc[i][j][e], sc, sh)));
                 }
             }
         }
     }
+    if (!SPLIT && p.amax_out) amax_track(amx, p.amax_out, blockIdx.x * 8 + wave);
 }
 
 template <int N>
@@ -176,7 +198,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
     constexpr int W = VEC ? 4 : 1;
     const long long total = (long long)p.M * p.K;
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W;
-    if (i >= total) return;
+    float amx = 0.0f;
+    if (i < total) {
     const int m = (int)(i / p.K), col = (int)(i - (long long)m * p.K);
     if constexpr (VEC) {
         floatx4 v = *reinterpret_cast<const floatx4 *>(p.part + i);
@@ -195,7 +218,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
         floatx4 r = {0.f, 0.f, 0.f, 0.f};
         if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ppy_apply_act(fmaf(v[u], sc[u], sh[u]) + (p.res ? r[u] : 0.f), p.act);
+        for (int u = 0; u < 4; ++u) {
+            v[u] = ppy_apply_act(fmaf(v[u], sc[u], sh[u]) + (p.res ? r[u] : 0.f), p.act);
+            amx = fmaxf(amx, fabsf(v[u]));
+        }
         if (!p.ups) {
             *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
         } else {
@@ -211,7 +237,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
     } else {
         float v = p.part[i];
         for (int z = 1; z < splits; ++z) v += p.part[(long long)z * total + i];
-        epilogue_store(p, m, col, v, p.scale[col], p.shift[col]);
+        amx = fabsf(epilogue_store(p, m, col, v, p.scale[col], p.shift[col]));
+    }
+    }
+    if (p.amax_out) {      // one atomic per workgroup
+        __shared__ float s_amx[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if ((threadIdx.x & 63) == 0) s_amx[threadIdx.x >> 6] = amx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float mx = fmaxf(fmaxf(s_amx[0], s_amx[1]), fmaxf(s_amx[2], s_amx[3]));
+            if (mx > 0.0f)
+                atomicMax(reinterpret_cast<unsigned *>(p.amax_out) + (blockIdx.x & (AMAX_SLOTS - 1)) * AMAX_STRIDE,
+                          __float_as_uint(mx));
+        }
     }
 }
 

@@ -39,6 +39,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float floatx2;
 typedef __attribute__((ext_vector_type(4))) unsigned uintx4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // RNE, a -> low half
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// halves of a packed pair back to fp32 (scalar bit casts: a vector bit_cast of the packed word was mis-combined
+// across the pairs of a fragment by hipcc -O3 -- every pair subtracted the FIRST pair's value)
+__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // RNE, a -> low half
     const floatx2 v = {a, b};
@@ -85,20 +96,23 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long
 
 // A tile: [BM][32] fp32, 128-byte rows, 16-byte slot c of row r stored at c ^ ((r>>1)&7)   (as conv_igemm.hip)
 // B tile: [3 planes][BN][32] bf16, 64-byte rows, slot c of row r stored at c ^ ((r>>2)&3)
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+// F16 = false: "bf16x3" (3 bf16 pieces, 6 products).  F16 = true: "f16x2" -- 2 fp16 pieces of the operands pre-scaled
+// by powers of two into the fp16 range (weights per output channel at plan time, activations by the producer-tracked
+// maximum of the input tensor), 3 products on v_mfma_f32_32x32x16_f16; see the file header.
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    constexpr int B_ROWS = 3 * BN;
+    constexpr int NP = F16 ? 2 : 3;                    // pieces per operand = weight planes
+    constexpr int B_ROWS = NP * BN;
     static_assert(BM % (8 * NW) == 0 && B_ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
     constexpr int A_PASS = BM / (8 * NW), B_PASS = B_ROWS / (16 * NW);
     constexpr int G = A_PASS + B_PASS;                 // DMA instructions per wave per chunk
     constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    static_assert(STAGES == 2, "two LDS stages (see the main loop)");
     typedef __attribute__((address_space(3))) void *lds_ptr;
 
     extern __shared__ __attribute__((aligned(16))) char smem_x3[];
@@ -171,7 +185,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
     int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
     const char *xb = reinterpret_cast<const char *>(p.x) - bias;
-    const char *wb = reinterpret_cast<const char *>(p.w3);
+    const char *wb = reinterpret_cast<const char *>(F16 ? p.wf16 : p.w3);
 
     // One chunk = G DMA pieces per wave.  begin/piece/end are separate so that the steady-state loop can
     // drop one piece into an MFMA slot at a time (a piece costs ~60+ issue cycles: M0 write + buffer_load);
@@ -230,6 +244,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
 
+    // f16x2: activation scale = the power of two that puts the input tensor's maximum (tracked by its producers:
+    // 64 slots of p.amax_in, see amax_track in conv_shared.h) into [2^13, 2^14); both scales are exact.
+    float sa = 1.0f, inv_sa = 1.0f;
+    if constexpr (F16) {
+        float mx = fabsf(p.amax_in[lane * AMAX_STRIDE]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
+        int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
+        f = f < 1 ? 1 : (f > 253 ? 253 : f);
+        f = __builtin_amdgcn_readfirstlane(f);                         // wave-uniform -> scalar registers
+        sa = __uint_as_float((unsigned)f << 23);
+        inv_sa = __uint_as_float((unsigned)(254 - f) << 23);
+    }
+
     // One "k-step" = 16 reduction elements = one MFMA depth; a 32-deep chunk is two k-steps.
     // The wave is software-pipelined over k-steps BY HAND: the instruction stream of a step is a
     // sequence of NM slots { one MFMA of step g ; at most one LDS read for step g+1 ; a few VALU
@@ -239,22 +268,31 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     // Split of one (a, b) pair = 5 dependent stages (cvt | shift,and,sub,sub | cvt | ... | cvt); the
     // stages of the 4*TM pairs of a step are issued stage-major so neighbours are independent.
     struct Frag {        // operands of one k-step
-        uintx4 a[TM][3];         // A: three bf16x8 terms per 32-row tile
-        bf16x8 b[3][TN];         // B: plane x 32-column tile
+        uintx4 a[TM][NP];        // A: NP 8-element terms (bf16x8 / f16x8 bits) per 32-row tile
+        uintx4 b[NP][TN];        // B: plane x 32-column tile
     };
-    constexpr int NM = 6 * TM * TN;           // MFMAs per k-step
-    constexpr int NRA = 2 * TM, NRB = 3 * TN; // LDS reads per k-step
-    constexpr int NSL = 5 * 4 * TM;           // split stages per k-step
-    constexpr int LEAD = NRA + 2;             // MFMA slots before the first split stage (raw reads in flight)
-    static_assert(NM >= NRA + NRB && NM > LEAD, "slots");
+    constexpr int NPROD = F16 ? 3 : 6;        // partial products per multiply-add
+    constexpr int NST = F16 ? 3 : 5;          // dependent split stages per pair
+    constexpr int NM = NPROD * TM * TN;       // MFMAs per k-step
+    constexpr int NRA = 2 * TM, NRB = NP * TN; // LDS reads per k-step
+    constexpr int NSL = NST * 4 * TM;         // split stages per k-step
+    // slot plan: LDS reads first (RPS per slot; the raw A rows lead), split stages from slot LEAD on (PER per slot),
+    // DMA pieces spread over the step (DPS per hosting slot)
+    constexpr int NR = NRA + NRB;
+    constexpr int RPS = (NR + NM - 1) / NM;
+    constexpr int LEAD0 = (NRA + RPS - 1) / RPS + 1;
+    constexpr int LEAD = LEAD0 < NM ? LEAD0 : NM - 1;
     constexpr int PER = (NSL + (NM - LEAD) - 1) / (NM - LEAD);
-
-    constexpr int DSTRIDE = NM / G > 0 ? NM / G : 1;
-    static_assert(G <= NM, "one DMA piece per MFMA slot at most");
+    constexpr int DPS = (G + NM - 1) / NM;
+    constexpr int ND = (G + DPS - 1) / DPS;            // slots that host DMA pieces
+    constexpr int DSTRIDE = NM / ND;
+    static_assert(NM > LEAD && ND * DSTRIDE <= NM && DSTRIDE >= 1, "slots");
     auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag, auto dma_tag) {
         constexpr int s = decltype(s_tag)::value;
         constexpr bool DMA = decltype(dma_tag)::value;   // this step also carries the DMA pieces of a chunk      // k-step (0/1) of the chunk the NEXT operands come from
-        constexpr int ta[6] = {2, 1, 0, 1, 0, 0}, tb[6] = {0, 1, 2, 0, 1, 0};   // smallest products first
+        // partial products (piece of A, piece of B), smallest first; f16x2 uses the last three with pieces {0,1}
+        constexpr int ta[6] = {2, 1, 0, 1, 0, 0}, tb[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int T0 = 6 - NPROD;
         const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
         const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
         floatx4 raw[TM][2];
@@ -262,18 +300,30 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             {   // MFMA m, term-major: consecutive MFMAs use different accumulators
-                const int t = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[i][ta[t]]),
-                                                                   cur.b[tb[t]][j], acc[i][j], 0, 0, 0);
+                const int t = T0 + m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                if constexpr (F16)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][ta[t]]),
+                                                                      __builtin_bit_cast(f16x8, cur.b[tb[t]][j]), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[i][ta[t]]),
+                                                                       __builtin_bit_cast(bf16x8, cur.b[tb[t]][j]), acc[i][j], 0, 0, 0);
             }
-            if (PPY_X3_ABL >= 5) {
-            } else if (m < NRA) {
-                raw[m >> 1][m & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (m >> 1) * 32 * 128 + a_foff[s][m & 1]);
-            } else if (m < NRA + NRB) {
-                const int pl = (m - NRA) / TN, j = (m - NRA) % TN;
-                nxt.b[pl][j] = *reinterpret_cast<const bf16x8 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
+#pragma unroll
+            for (int u = 0; u < RPS; ++u) {
+                const int r = m * RPS + u;
+                if (PPY_X3_ABL >= 5 || r >= NR) {
+                } else if (r < NRA) {
+                    raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                } else {
+                    const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
+                    nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
+                }
             }
-            if (DMA && PPY_X3_ABL != 1 && PPY_X3_ABL < 3 && m % DSTRIDE == DSTRIDE - 1 && m / DSTRIDE < G) issue_piece(m / DSTRIDE);
+            if (DMA && PPY_X3_ABL != 1 && PPY_X3_ABL < 3 && m % DSTRIDE == DSTRIDE - 1 && m / DSTRIDE < ND) {
+#pragma unroll
+                for (int u = 0; u < DPS; ++u)
+                    if ((m / DSTRIDE) * DPS + u < G) issue_piece((m / DSTRIDE) * DPS + u);
+            }
             if (m >= LEAD) {
 #pragma unroll
                 for (int u = 0; u < PER; ++u) {
@@ -281,7 +331,17 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                     if (sl < NSL && PPY_X3_ABL != 2 && PPY_X3_ABL < 3) {
                         const int st = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q = pr % 4;
                         const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
-                        if (st == 0) {
+                        if constexpr (F16) {
+                            if (st == 0) {
+                                nxt.a[i][0][q] = cvt_pk_f16(xa * sa, xb * sa);
+                            } else if (st == 1) {     // residual of the SCALED value: fma(x, sa, -a0) is exact
+                                const unsigned P = nxt.a[i][0][q];
+                                ra[i][q] = fmaf(xa, sa, -f16_lo(P));
+                                rb[i][q] = fmaf(xb, sa, -f16_hi(P));
+                            } else {
+                                nxt.a[i][1][q] = cvt_pk_f16(ra[i][q], rb[i][q]);
+                            }
+                        } else if (st == 0) {
                             nxt.a[i][0][q] = cvt_pk_bf16(xa, xb);
                         } else if (st == 1) {
                             const unsigned P = nxt.a[i][0][q];
@@ -306,7 +366,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
+            for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
     };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
@@ -327,17 +387,28 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
             const char *b_ptr = smem + A_BYTES + wn * WN * 64;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                bf16x8 t3[3];
-                split8(*reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]),
-                       *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]), t3);
+                const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
+                const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+                if constexpr (F16) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) f0.a[i][pl] = __builtin_bit_cast(uintx4, t3[pl]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float xa = q < 2 ? lo[2 * q] : hi[2 * q - 4], xb = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+                        const unsigned P0 = cvt_pk_f16(xa * sa, xb * sa);
+                        f0.a[i][0][q] = P0;
+                        f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sa, -f16_lo(P0)), fmaf(xb, sa, -f16_hi(P0)));
+                    }
+                } else {
+                    bf16x8 t3[3];
+                    split8(lo, hi, t3);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) f0.a[i][pl] = __builtin_bit_cast(uintx4, t3[pl]);
+                }
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    f0.b[pl][j] = *reinterpret_cast<const bf16x8 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
+                    f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
         }
         int st = 0;
         for (int k = 0; k < nchunks; ++k) {
@@ -360,6 +431,14 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         __builtin_amdgcn_s_barrier();
     }
     if (p.trace) c_epi = __builtin_amdgcn_s_memtime();
+    if constexpr (F16) {       // back to the unscaled sum (the weight scale is folded into p.scale by the caller)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_sa;
+    }
     tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split);
     if (p.trace && tid == 0) {     // debug timeline (ppy_debug_set_trace): wall-clock span + shader-clock phases
         unsigned hwid, xcc;
@@ -378,24 +457,24 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 }
 
 struct X3Cfg {
-    int bm, bn, wm, wn, stages;
+    int bm, bn, wm, wn;
 };
-constexpr X3Cfg kX3[] = {
-    {256, 128, 64, 128, 2},   // 0  4 waves (4x1), 112 KB LDS
-    {128, 128, 64, 64, 2},    // 1  4 waves (2x2), 80 KB
-    {128, 128, 32, 128, 2},   // 2  4 waves (4x1), 80 KB
-    {256, 64, 64, 64, 2},     // 3  4 waves (4x1), 88 KB
-    {128, 64, 32, 64, 2},     // 4  4 waves (4x1), 56 KB
-    {256, 128, 64, 64, 2},    // 5  8 waves (4x2), 112 KB
-    {128, 256, 64, 128, 2},   // 6  4 waves (2x2), 128 KB
-    {64, 128, 32, 64, 2},     // 7  4 waves (2x2), 64 KB
-    {64, 64, 32, 32, 2},      // 8  4 waves (2x2), 40 KB: four workgroups per CU for the store-bound 1x1 expand layers
+constexpr X3Cfg kX3[] = {     // the same nine tiles for both schemes (LDS sizes for bf16x3 / f16x2, two stages)
+    {256, 128, 64, 128},   // 0  4 waves (4x1), 112 / 96 KB
+    {128, 128, 64, 64},    // 1  4 waves (2x2), 80 / 64 KB
+    {128, 128, 32, 128},   // 2  4 waves (4x1), 80 / 64 KB
+    {256, 64, 64, 64},     // 3  4 waves (4x1), 88 / 80 KB
+    {128, 64, 32, 64},     // 4  4 waves (4x1), 56 / 48 KB
+    {256, 128, 64, 64},    // 5  8 waves (4x2), 112 / 96 KB
+    {128, 256, 64, 128},   // 6  4 waves (2x2), 128 / 96 KB
+    {64, 128, 32, 64},     // 7  4 waves (2x2), 64 / 48 KB
+    {64, 64, 32, 32},      // 8  4 waves (2x2), 40 / 32 KB: four workgroups per CU for the store-bound 1x1 expand layers
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT, bool VEC>
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC>
 int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, STAGES, SPLIT, VEC>;
+    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -407,14 +486,15 @@ int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStrea
     return PPY_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, bool F16>
 int launch_x3(ConvArgs p, int splits, hipStream_t stream) {
     // 32-bit per-lane DMA offsets
+    constexpr int NP = F16 ? 2 : 3;
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
-    const long long wbytes = (long long)p.K * p.Kred * 6;
+    const long long wbytes = (long long)p.K * p.Kred * 2 * NP;
     if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
     constexpr int NW = (BM / WM) * (BN / WN);
-    size_t lds = (size_t)STAGES * (BM * 128 + 3 * BN * 64);
+    size_t lds = (size_t)2 * (BM * 128 + NP * BN * 64);
     const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
     p.chunks_total = p.R * p.S * (p.C / 32);
@@ -424,36 +504,87 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream) {
     const bool vec = vec_epilogue_ok(p);
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, STAGES, true, true>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, STAGES, true, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, F16, true, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, STAGES, false, true>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, STAGES, false, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, false, true>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, F16, false, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
 }
 
-}  // namespace
-
-int ppy_x3_num_configs() { return kNumX3; }
-
-int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
-    if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0) return PPY_ERR_BAD_ARG;
+template <bool F16>
+int dispatch_scheme(const ConvArgs &p, int c, int s, hipStream_t st) {
     switch (c) {
-        case 0: return launch_x3<256, 128, 64, 128, 2>(p, s, st);
-        case 1: return launch_x3<128, 128, 64, 64, 2>(p, s, st);
-        case 2: return launch_x3<128, 128, 32, 128, 2>(p, s, st);
-        case 3: return launch_x3<256, 64, 64, 64, 2>(p, s, st);
-        case 4: return launch_x3<128, 64, 32, 64, 2>(p, s, st);
-        case 5: return launch_x3<256, 128, 64, 64, 2>(p, s, st);
-        case 6: return launch_x3<128, 256, 64, 128, 2>(p, s, st);
-        case 7: return launch_x3<64, 128, 32, 64, 2>(p, s, st);
-        case 8: return launch_x3<64, 64, 32, 32, 2>(p, s, st);
+        case 0: return launch_x3<256, 128, 64, 128, F16>(p, s, st);
+        case 1: return launch_x3<128, 128, 64, 64, F16>(p, s, st);
+        case 2: return launch_x3<128, 128, 32, 128, F16>(p, s, st);
+        case 3: return launch_x3<256, 64, 64, 64, F16>(p, s, st);
+        case 4: return launch_x3<128, 64, 32, 64, F16>(p, s, st);
+        case 5: return launch_x3<256, 128, 64, 64, F16>(p, s, st);
+        case 6: return launch_x3<128, 256, 64, 128, F16>(p, s, st);
+        case 7: return launch_x3<64, 128, 32, 64, F16>(p, s, st);
+        case 8: return launch_x3<64, 64, 32, 32, F16>(p, s, st);
     }
     return PPY_ERR_BAD_ARG;
+}
+
+// One workgroup per output channel: s_w = the power of two that puts max|w[k,:]| into [2^13, 2^14); planes of w*s_w as two
+// fp16 terms (RNE each), and the epilogue scale with 1/s_w folded in (exact).
+__global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, int K, long long kred, const float *scale,
+                                                                unsigned short *out, float *scale_out) {
+    __shared__ float smax[4];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const float *row = w + (long long)k * kred;
+    float mx = 0.f;
+    for (long long i = tid; i < kred; i += 256) mx = fmaxf(mx, fabsf(row[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) smax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    int f = 267 - e;
+    f = f < 1 ? 1 : (f > 253 ? 253 : f);
+    const float sw = __uint_as_float((unsigned)f << 23), inv = __uint_as_float((unsigned)(254 - f) << 23);
+    const long long n = (long long)K * kred;
+    for (long long i = tid; i < kred; i += 256) {
+        const float v = row[i] * sw;
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)(v - (float)h0);
+        out[(long long)k * kred + i] = __builtin_bit_cast(unsigned short, h0);
+        out[n + (long long)k * kred + i] = __builtin_bit_cast(unsigned short, h1);
+    }
+    if (tid == 0) scale_out[k] = scale[k] * inv;
+}
+
+}  // namespace
+
+int ppy_x3_num_configs() { return 2 * kNumX3; }      // [0, 9): bf16x3, [9, 18): f16x2
+
+int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (c < kNumX3) {
+        if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0) return PPY_ERR_BAD_ARG;
+        return dispatch_scheme<false>(p, c, s, st);
+    }
+    // f16x2 needs the split weights + folded scale, the tracked maximum of the input, and no CoordConv bias map
+    // (it would have to be pre-scaled per channel)
+    if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || p.posb) return PPY_ERR_BAD_ARG;
+    ConvArgs q = p;
+    q.scale = p.scale_f16;
+    return dispatch_scheme<true>(q, c - kNumX3, s, st);
+}
+
+extern "C" int ppy_conv2d_split_weights_f16x2(const float *w_krsc, int K, long long kred, const float *scale,
+                                              void *out_planes, float *scale_out, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(w_krsc && scale && out_planes && scale_out && K > 0 && kred > 0);
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w_krsc, K, kred, scale,
+                       (unsigned short *)out_planes, scale_out);
+    return ppy_launch_status();
 }
 
 extern "C" int ppy_conv2d_split_weights_bf16x3(const float *w, long long n, void *out, void *stream) {

@@ -108,10 +108,11 @@ extern "C" size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, i
     return cols + ppy_conv2d_workspace_bytes(N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, cfg, splitk);
 }
 
-extern "C" int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const float *scale,
+extern "C" int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const void *w_f16x2,
+                             const float *scale, const float *scale_f16x2,
                              const float *shift, const float *offset_mask, int om_ld, float *y, int y_ld, int N,
                              int H, int W, int C, int K, int stride, int pad, int act, int cfg, int splitk,
-                             void *ws, size_t ws_bytes, void *stream) {
+                             const float *amax_in, float *amax_out, void *ws, size_t ws_bytes, void *stream) {
     PPY_CHECK_ARG(stride > 0 && C % 32 == 0);
     const int Ho = (H + 2 * pad - 2) / stride, Wo = (W + 2 * pad - 2) / stride;
     PPY_CHECK_ARG(Ho > 0 && Wo > 0);
@@ -122,7 +123,8 @@ extern "C" int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, cons
     int rc = ppy_dcnv2_sample_f32(x, x_ld, offset_mask, om_ld, cols, N, H, W, C, Ho, Wo, stride, pad, stream);
     if (rc != PPY_OK) return rc;
     // contraction over (tap, c): a 1x1 conv on the columns viewed as NHWC [N,Ho,Wo,9C]
-    return ppy_conv2d_bn_act_f32(cols, 9 * C, w_krsc, w_x3, scale, shift, nullptr, 0, nullptr, y, y_ld, N, Ho, Wo,
-                                 9 * C, K, 1, 1, 1, 0, act, 0, cfg, splitk, (char *)ws + cols_bytes,
+    // |column| <= max|x| (bilinear weights and the sigmoid mask are <= 1): the input's tracked maximum bounds the columns
+    return ppy_conv2d_bn_act_f32(cols, 9 * C, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, nullptr, 0, nullptr, y, y_ld, N, Ho, Wo,
+                                 9 * C, K, 1, 1, 1, 0, act, 0, cfg, splitk, amax_in, amax_out, (char *)ws + cols_bytes,
                                  ws_bytes - cols_bytes, stream);
 }

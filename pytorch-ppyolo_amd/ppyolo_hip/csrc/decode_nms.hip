@@ -70,7 +70,7 @@ struct DecodeArgs {
 //      a wave ballot appends them to the image's candidate list.
 constexpr int DEC_CELLS = 64;
 
-__global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
+__device__ __forceinline__ void yolo_decode_body(const DecodeArgs &p, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int per = 5 + p.C;
     const int nch = p.A * per + (p.iou_aware ? p.A : 0);
@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
     float *s_bound = s_conf + DEC_CELLS * p.A;          // [DEC_CELLS * A]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cells_img = p.S * p.S;
-    const int cell_in_img0 = blockIdx.x * DEC_CELLS;
-    const long long cell0 = (long long)blockIdx.y * cells_img + cell_in_img0;
+    const int cell_in_img0 = bx * DEC_CELLS;
+    const long long cell0 = (long long)by * cells_img + cell_in_img0;
     const int ncl = min(DEC_CELLS, cells_img - cell_in_img0);
 
     // ---- phase 1: stage ----
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
     __shared__ int l_n, l_base;
     if (tid == 0) l_n = 0;
     __syncthreads();
-    const int n = blockIdx.y;
+    const int n = by;
     uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
     uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
     for (int q = tid; q < ncl * p.A; q += 256) {
@@ -230,6 +230,25 @@ __global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) {
             cidx[g] = l_idx[i];
         }
     }
+}
+
+__global__ void __launch_bounds__(256) yolo_decode_kernel(const DecodeArgs p) { yolo_decode_body(p, blockIdx.x, blockIdx.y); }
+
+// All head levels in ONE launch (blockIdx.x walks level 0's cell blocks, then level 1's, ...): the 19x19 and
+// 38x38 levels are 48 / 184 workgroups each and were latency-bound on their own (19 + 20 + 36 us as three launches).
+constexpr int DEC_MAX_LEVELS = 4;
+struct DecodeMulti {
+    DecodeArgs lv[DEC_MAX_LEVELS];
+    int nb[DEC_MAX_LEVELS];
+    int nlevels;
+};
+__global__ void __launch_bounds__(256) yolo_decode_multi_kernel(const DecodeMulti m) {
+    int bx = blockIdx.x, l = 0;
+    while (l + 1 < m.nlevels && bx >= m.nb[l]) {
+        bx -= m.nb[l];
+        ++l;
+    }
+    yolo_decode_body(m.lv[l], bx, blockIdx.y);
 }
 
 // Candidate extraction from dense scores [N][M][C] (reference model/matrix_nms.py:110-117).
@@ -592,13 +611,11 @@ __global__ void __launch_bounds__(NT) nms_finish_kernel(const NmsArgs p) {
 
 }  // namespace
 
-extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A, int num_classes,
-                                   const float *h_anchors_px, int downsample, double scale_x_y, int iou_aware,
-                                   double iou_aware_factor, int clip_bbox, const float *im_size, float *boxes,
-                                   int M_total, int box_offset, float score_threshold, uint32_t *cand_key,
-                                   uint32_t *cand_idx, int *cand_count, int cand_cap, float *scores_dense,
-                                   void *stream) {
-    ppy_drop_stale_error();
+static int decode_pack(DecodeArgs &p, const float *head_out, int head_ld, int N, int S, int A, int num_classes,
+                       const float *h_anchors_px, int downsample, double scale_x_y, int iou_aware,
+                       double iou_aware_factor, int clip_bbox, const float *im_size, float *boxes, int M_total,
+                       int box_offset, float score_threshold, uint32_t *cand_key, uint32_t *cand_idx, int *cand_count,
+                       int cand_cap, float *scores_dense, size_t *lds_out) {
     PPY_CHECK_ARG(head_out && h_anchors_px && im_size && boxes && cand_key && cand_idx && cand_count);
     PPY_CHECK_ARG(N > 0 && S > 0 && A > 0 && A <= 8 && num_classes > 0 && downsample > 0 && cand_cap > 0);
     const int nch = A * (5 + num_classes) + (iou_aware ? A : 0);
@@ -606,7 +623,6 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
     PPY_CHECK_ARG(box_offset >= 0 && box_offset + S * S * A <= M_total);
     PPY_CHECK_ARG((long long)M_total * num_classes < (1ll << 31));
     PPY_CHECK_ARG(((uintptr_t)boxes & 15) == 0);
-    DecodeArgs p;
     p.head = head_out; p.im_size = im_size; p.boxes = boxes; p.scores_dense = scores_dense;
     p.cand_key = cand_key; p.cand_idx = cand_idx; p.cand_count = cand_count;
     p.head_ld = head_ld; p.N = N; p.S = S; p.A = A; p.C = num_classes; p.M_total = M_total;
@@ -619,19 +635,71 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
     p.e_obj = (float)(1.0 - iou_aware_factor);
     p.e_iou = (float)iou_aware_factor;
     p.thr = score_threshold;
-    const long long cells = (long long)N * S * S;
-    const size_t lds = ((size_t)DEC_CELLS * nch + 2 * DEC_CELLS * A) * sizeof(float);
+    *lds_out = ((size_t)DEC_CELLS * nch + 2 * DEC_CELLS * A) * sizeof(float);
+    if (*lds_out > 96 * 1024) return PPY_ERR_UNSUPPORTED;
+    return PPY_OK;
+}
+
+template <typename Kern>
+static int decode_attr(Kern k) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) ==
+                   hipSuccess
+               ? PPY_OK
+               : PPY_ERR_LAUNCH;
+}
+
+extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A, int num_classes,
+                                   const float *h_anchors_px, int downsample, double scale_x_y, int iou_aware,
+                                   double iou_aware_factor, int clip_bbox, const float *im_size, float *boxes,
+                                   int M_total, int box_offset, float score_threshold, uint32_t *cand_key,
+                                   uint32_t *cand_idx, int *cand_count, int cand_cap, float *scores_dense,
+                                   void *stream) {
+    ppy_drop_stale_error();
+    DecodeArgs p;
+    size_t lds;
+    int rc = decode_pack(p, head_out, head_ld, N, S, A, num_classes, h_anchors_px, downsample, scale_x_y, iou_aware,
+                         iou_aware_factor, clip_bbox, im_size, boxes, M_total, box_offset, score_threshold, cand_key,
+                         cand_idx, cand_count, cand_cap, scores_dense, &lds);
+    if (rc != PPY_OK) return rc;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(yolo_decode_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-            return PPY_ERR_LAUNCH;
+        if (decode_attr(yolo_decode_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
         attr_done = true;
     }
-    if (lds > 96 * 1024) return PPY_ERR_UNSUPPORTED;
-    (void)cells;
     hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((S * S + DEC_CELLS - 1) / DEC_CELLS), N), dim3(256), lds,
                        (hipStream_t)stream, p);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_out, const int *head_ld, const int *S,
+                                          const int *downsample, const float *const *h_anchors_px,
+                                          const int *box_offset, int N, int A, int num_classes, double scale_x_y,
+                                          int iou_aware, double iou_aware_factor, int clip_bbox, const float *im_size,
+                                          float *boxes, int M_total, float score_threshold, uint32_t *cand_key,
+                                          uint32_t *cand_idx, int *cand_count, int cand_cap, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(nlevels >= 1 && nlevels <= DEC_MAX_LEVELS && head_out && head_ld && S && downsample && h_anchors_px &&
+                  box_offset);
+    DecodeMulti m;
+    m.nlevels = nlevels;
+    size_t lds = 0;
+    unsigned blocks = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        size_t one;
+        int rc = decode_pack(m.lv[l], head_out[l], head_ld[l], N, S[l], A, num_classes, h_anchors_px[l], downsample[l],
+                             scale_x_y, iou_aware, iou_aware_factor, clip_bbox, im_size, boxes, M_total, box_offset[l],
+                             score_threshold, cand_key, cand_idx, cand_count, cand_cap, nullptr, &one);
+        if (rc != PPY_OK) return rc;
+        lds = one > lds ? one : lds;
+        m.nb[l] = (S[l] * S[l] + DEC_CELLS - 1) / DEC_CELLS;
+        blocks += (unsigned)m.nb[l];
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (decode_attr(yolo_decode_multi_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(yolo_decode_multi_kernel, dim3(blocks, N), dim3(256), lds, (hipStream_t)stream, m);
     return ppy_launch_status();
 }
 

@@ -42,13 +42,19 @@ def fold_bn(bn, bias, K_out, device):
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_TUNED_PATHS = {'fp32': os.path.join(_HERE, 'tuned_gfx950.json'), 'bf16x3': os.path.join(_HERE, 'tuned_gfx950_bf16x3.json')}
+_TUNED_PATHS = {'fp32': os.path.join(_HERE, 'tuned_gfx950.json'), 'bf16x3': os.path.join(_HERE, 'tuned_gfx950_bf16x3.json'),
+                'f16x2': os.path.join(_HERE, 'tuned_gfx950_f16x2.json')}
 _tuned = {}
 NUM_FP32_CFGS = 31       # tile configuration ids below this are the exact-fp32 MFMA kernels (conv_igemm.hip)
+NUM_X3_CFGS = 9          # then the bf16x3 kernels [31, 40), then the f16x2 kernels [40, 49) (conv_x3.hip)
 
 
 def math_mode():
     """How the convolution inner products are evaluated (PPYOLO_HIP_MATH):
+      'f16x2':  2-term fp16 split of both operands after power-of-two scaling into the fp16 range (weights per output
+                channel at plan time, activations by the maximum their producers track), 3 partial products on the fp16
+                MFMA, fp32 accumulate -- fp32-grade results at half the MFMA work of bf16x3; layers whose input
+                maximum is not tracked (stem side) or that carry a CoordConv bias map use the modes below;
       'bf16x3' (default): exact 3-term bf16 split of both fp32 operands, 6 partial products on the bf16 MFMA,
                 fp32 accumulate -- fp32-grade results (csrc/conv_x3.hip) at 6/16 of the fp32 MFMA cost; the
                 measured table may still pick an exact-fp32 kernel for a layer where that is faster;
@@ -253,11 +259,14 @@ class HipExecutor(object):
         self.math = math_mode()
         self._to_device(p.setup_ops)
         self._to_device(p.ops)
-        if self.math == 'bf16x3':
+        if self.math in ('bf16x3', 'f16x2'):
             with torch.cuda.device(self.device):
                 for op in p.ops:        # (setup ops -- the CoordConv bias maps -- stay on the exact-fp32 kernel)
                     if op['op'] in ('conv', 'dcn'):
                         op['w3'] = K.split_weights_bf16x3(op['w'])
+                        if self.math == 'f16x2' and op.get('posb') is None:
+                            op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
+        self._assign_amax()
         tab = tuned_table(self.math)
         for op in p.ops:
             if op['op'] in ('conv', 'dcn') and op['cfg'] < 0 and tune_key(op) in tab:
@@ -275,6 +284,31 @@ class HipExecutor(object):
             for op in p.setup_ops:
                 self._run_op(op)
             torch.cuda.synchronize()
+
+    def _assign_amax(self):
+        """Tracked tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
+        output buffer; pooled tensors inherit the slots of their input (max- and average-pooling never exceed it; SPP
+        writes into its own input buffer; the DCN columns are bounded by the DCN input).  The stem output is not
+        tracked."""
+        amax_of, nblocks = {}, 0
+        for op in self.plan.ops:
+            t = op['op']
+            if t in ('conv', 'dcn'):
+                b = op['y'].buf
+                if b not in amax_of:
+                    amax_of[b] = nblocks
+                    nblocks += 1
+                op['amax_out_id'] = amax_of[b]
+                op['amax_in_id'] = amax_of.get(op['x'].buf)
+            elif t in ('maxpool', 'avgpool'):
+                if amax_of.get(op['x'].buf) is not None:
+                    amax_of[op['y'].buf] = amax_of[op['x'].buf]
+            elif t == 'stem':
+                amax_of[op['y'].buf] = None
+        self.amax = torch.zeros(max(1, nblocks) * K.AMAX_FLOATS, dtype=torch.float32, device=self.device)
+
+    def _amax(self, idx):
+        return None if idx is None else self.amax[idx * K.AMAX_FLOATS:(idx + 1) * K.AMAX_FLOATS]
 
     # ---- helpers ---------------------------------------------------------------------------
     def _to_device(self, oplist):
@@ -358,7 +392,8 @@ class HipExecutor(object):
             K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
-                            ws, op.get('w3'))
+                            ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
+                            self._amax(op.get('amax_out_id')))
         elif t == 'stem':
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
         elif t == 'maxpool':
@@ -369,25 +404,25 @@ class HipExecutor(object):
             K.spp(self.view(op['x']), self.view(op['y5']), self.view(op['y9']), self.view(op['y13']))
         elif t == 'dcn':
             K.dcnv2(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['om']), self.view(op['y']),
-                    op['stride'], op['pad'], op['act'], ws, op['cfg'], op['splitk'], op.get('w3'))
+                    op['stride'], op['pad'], op['act'], ws, op['cfg'], op['splitk'], op.get('w3'), op.get('wf16'),
+                    self._amax(op.get('amax_in_id')), self._amax(op.get('amax_out_id')))
         else:
             raise PPYoloHipError('unknown plan op %r' % t)
 
     def _run_decode(self):
         d = self.plan.decode
         self.cand_count.zero_()
-        off = 0
-        for lvl, a in zip(d['levels'], self.plan.head_outs):
-            K.yolo_decode(self.view(a), lvl['anchors'], lvl['downsample'], d['num_classes'], d['scale_x_y'],
-                          d['iou_aware'], d['iou_aware_factor'], d['clip_bbox'], self.im_size, self.boxes, off,
-                          d['nms']['score_threshold'], self.cand_key, self.cand_idx, self.cand_count)
-            off += a.H * a.W * len(lvl['anchors'])
+        K.yolo_decode_levels([self.view(a) for a in self.plan.head_outs], [lvl['anchors'] for lvl in d['levels']],
+                             [lvl['downsample'] for lvl in d['levels']], d['num_classes'], d['scale_x_y'], d['iou_aware'],
+                             d['iou_aware_factor'], d['clip_bbox'], self.im_size, self.boxes,
+                             d['nms']['score_threshold'], self.cand_key, self.cand_idx, self.cand_count)
         n = d['nms']
         K.matrix_nms(self.boxes, d['num_classes'], self.cand_key, self.cand_idx, self.cand_count,
                      n['post_threshold'], n['nms_top_k'], n['keep_top_k'], n['use_gaussian'], n['gaussian_sigma'],
                      self.out_dets, self.out_count, self.out_keep, self.nms_ws)
 
     def _launch_all(self):
+        self.amax.zero_()        # tracked tensor maxima restart with every step (one memset node in the graph)
         if not self.multi_stream:
             for op in self.plan.ops:
                 self._run_op(op)
@@ -445,7 +480,7 @@ class HipExecutor(object):
         """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
         guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
         from ._lib import lib
-        ncfg = lib().ppy_conv2d_num_configs() if self.math == 'bf16x3' else NUM_FP32_CFGS
+        ncfg = {'fp32': NUM_FP32_CFGS, 'bf16x3': NUM_FP32_CFGS + NUM_X3_CFGS}.get(self.math, lib().ppy_conv2d_num_configs())
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
         with torch.cuda.device(self.device):

@@ -91,18 +91,44 @@ def split_weights_bf16x3(w_krsc):
     return out
 
 
+AMAX_FLOATS = 1024      # PPY_AMAX_FLOATS: slots of a tracked tensor maximum
+
+
+def split_weights_f16x2(w_krsc, scale):
+    """-> (planes [2, *w.shape] int16 storage, scale_f16x2 [K]): the operands of the "f16x2" conv kernels."""
+    _dev(w_krsc, scale)
+    assert w_krsc.is_contiguous() and w_krsc.dtype == torch.float32 and scale.is_contiguous()
+    K = w_krsc.shape[0]
+    planes = torch.empty((2,) + tuple(w_krsc.shape), dtype=torch.int16, device=w_krsc.device)
+    sc = torch.empty_like(scale)
+    check(lib().ppy_conv2d_split_weights_f16x2(w_krsc.data_ptr(), K, w_krsc.numel() // K, scale.data_ptr(),
+                                               planes.data_ptr(), sc.data_ptr(), _stream()),
+          'ppy_conv2d_split_weights_f16x2')
+    return planes, sc
+
+
+def amax_slots(t=None, device=None):
+    """A zeroed block of tracked-maximum slots; with a tensor, pre-filled with its max|.| (tests / stand-alone calls)."""
+    a = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=device if t is None else t.device)
+    if t is not None:
+        a[0] = t.abs().max()
+    return a
+
+
 def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residual=None, posbias=None,
-                  upsample2x=False, cfg=-1, splitk=0, ws=None, w_x3=None):
+                  upsample2x=False, cfg=-1, splitk=0, ws=None, w_x3=None, w_f16=None, amax_in=None, amax_out=None):
     """x, y, residual: View.  w_krsc: [K,R,S,C].  w_x3: split_weights_bf16x3(w_krsc) or None.
+    w_f16: split_weights_f16x2(w_krsc, scale) or None; amax_in / amax_out: amax_slots blocks or None.
     See ppy_conv2d_bn_act_f32."""
     _dev(x.t, w_krsc, scale, shift, y.t)
     K, R, S, C = w_krsc.shape
     assert C == x.C and K == y.C and w_krsc.is_contiguous()
     rc = lib().ppy_conv2d_bn_act_f32(
-        x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), scale.data_ptr(), shift.data_ptr(),
+        x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), None if w_f16 is None else w_f16[0].data_ptr(), scale.data_ptr(),
+        None if w_f16 is None else w_f16[1].data_ptr(), shift.data_ptr(),
         None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
         _p(posbias), y.ptr, y.ld, x.N, x.H, x.W, C, K, R, S, stride, pad, ACT[act], int(bool(upsample2x)),
-        cfg, splitk, _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream())
+        cfg, splitk, _p(amax_in), _p(amax_out), _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream())
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
@@ -147,12 +173,14 @@ def dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg=-1, splitk=0):
     return int(lib().ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
 
 
-def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1, splitk=0, w_x3=None):
+def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1, splitk=0, w_x3=None, w_f16=None,
+          amax_in=None, amax_out=None):
     _dev(x.t, w_krsc, offset_mask.t, y.t, ws)
     K = w_krsc.shape[0]
-    check(lib().ppy_dcnv2_f32(x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), scale.data_ptr(), shift.data_ptr(), offset_mask.ptr,
+    check(lib().ppy_dcnv2_f32(x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), None if w_f16 is None else w_f16[0].data_ptr(),
+                              scale.data_ptr(), None if w_f16 is None else w_f16[1].data_ptr(), shift.data_ptr(), offset_mask.ptr,
                               offset_mask.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, K, stride, pad, ACT[act], cfg, splitk,
-                              ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_f32')
+                              _p(amax_in), _p(amax_out), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_f32')
 
 
 def yolo_decode(head_out, anchors_px, downsample, num_classes, scale_x_y, iou_aware, iou_aware_factor, clip_bbox,
@@ -169,6 +197,29 @@ def yolo_decode(head_out, anchors_px, downsample, num_classes, scale_x_y, iou_aw
                                     int(box_offset), float(score_threshold), cand_key.data_ptr(), cand_idx.data_ptr(),
                                     cand_count.data_ptr(), cand_key.shape[1], _p(scores_dense), _stream()),
           'ppy_yolo_decode_f32')
+
+
+def yolo_decode_levels(head_outs, anchors_px, downsamples, num_classes, scale_x_y, iou_aware, iou_aware_factor, clip_bbox,
+                       im_size, boxes, score_threshold, cand_key, cand_idx, cand_count):
+    """All head levels in one launch.  head_outs: list of View [N,S,S,nch]; anchors_px: list (per level) of (w,h) lists.
+    Level l writes box rows [sum_{k<l} S_k^2*A, ...) -- the reference's concatenation order (head.py:446-461)."""
+    L = len(head_outs)
+    _dev(*([h.t for h in head_outs] + [im_size, boxes, cand_key, cand_idx, cand_count]))
+    A = len(anchors_px[0])
+    assert all(len(a) == A for a in anchors_px) and all(h.H == h.W for h in head_outs)
+    anchor_arrs = [(ctypes.c_float * (2 * A))(*[float(v) for a in lvl for v in a]) for lvl in anchors_px]
+    offs, off = [], 0
+    for h in head_outs:
+        offs.append(off)
+        off += h.H * h.W * A
+    vp = ctypes.c_void_p
+    check(lib().ppy_yolo_decode_levels_f32(
+        L, (vp * L)(*[h.ptr for h in head_outs]), (ctypes.c_int * L)(*[h.ld for h in head_outs]),
+        (ctypes.c_int * L)(*[h.H for h in head_outs]), (ctypes.c_int * L)(*[int(d) for d in downsamples]),
+        (vp * L)(*[ctypes.cast(a, vp) for a in anchor_arrs]), (ctypes.c_int * L)(*offs), head_outs[0].N, A, num_classes,
+        float(scale_x_y), int(bool(iou_aware)), float(iou_aware_factor), int(bool(clip_bbox)), im_size.data_ptr(),
+        boxes.data_ptr(), boxes.shape[1], float(score_threshold), cand_key.data_ptr(), cand_idx.data_ptr(),
+        cand_count.data_ptr(), cand_key.shape[1], _stream()), 'ppy_yolo_decode_levels_f32')
 
 
 def nms_candidates(scores, score_threshold, cand_key, cand_idx, cand_count):

@@ -58,7 +58,7 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-NUM_CFGS = 40      # 31 exact-fp32 MFMA configurations + 9 bf16x3 (conv_x3.hip)
+NUM_CFGS = 49      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 (conv_x3.hip)
 
 
 @pytest.mark.parametrize('cfg', range(NUM_CFGS))
@@ -84,11 +84,18 @@ def test_conv_every_tile_config(cfg, splitk):
     rbuf[..., 4:] = nhwc(res).cuda()
     ws = torch.empty(max(4, ops.conv2d_workspace_bytes(N, H, W, C, K, R, R, 1, 1, cfg, splitk) // 4)).cuda()
     wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    f16 = cfg >= 40                      # the f16x2 kernels take no per-position bias: fold it into the residual instead
+    if f16:
+        rbuf[..., 4:] += (nhwc(posb) * scale.view(1, 1, 1, -1)).cuda()
+    amax_out = ops.amax_slots(device='cuda')
     ops.conv2d_bn_act(ops.View(xin, 32, C), wk, scale.cuda(), shift.cuda(),
                       ops.View(yout, 8, K), 1, 1, 'leaky', residual=ops.View(rbuf, 4, K),
-                      posbias=nhwc(posb).contiguous().cuda(), cfg=cfg, splitk=splitk, ws=ws,
-                      w_x3=ops.split_weights_bf16x3(wk) if cfg >= 31 else None)
+                      posbias=None if f16 else nhwc(posb).contiguous().cuda(), cfg=cfg, splitk=splitk, ws=ws,
+                      w_x3=ops.split_weights_bf16x3(wk) if 31 <= cfg < 40 else None,
+                      w_f16=ops.split_weights_f16x2(wk, scale.cuda()) if f16 else None,
+                      amax_in=ops.amax_slots(xin) if f16 else None, amax_out=amax_out)
     torch.cuda.synchronize()
+    assert abs(amax_out.max().item() - ref.abs().max().item()) <= 1e-3, "tracked max|y| is off"
     close(nchw(yout[..., 8:]), ref, what='cfg %d split %d' % (cfg, splitk))
     assert torch.all(yout[..., :8] == -7.0), 'wrote outside the output channel slice'
 
@@ -356,9 +363,11 @@ def test_conv_random_shapes_all_kernels():
         Ho, Wo = ref.shape[2], ref.shape[3]
         y = torch.full((N, Ho, Wo, K), 123.0).cuda()
         wk = w.permute(0, 2, 3, 1).contiguous().cuda()
-        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, sc.cuda(), sh.cuda(),
+        xd = nhwc(x).cuda()
+        ops.conv2d_bn_act(ops.View(xd), wk, sc.cuda(), sh.cuda(),
                           ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
-                          cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk))
+                          cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk),
+                          w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
         torch.cuda.synchronize()
         close(nchw(y), ref, what='case %d: N%d C%d K%d R%d s%d %dx%d cfg%d split%d' % (case, N, C, K, R, stride, H, W, cfg,
                                                                                  splitk))
@@ -382,12 +391,16 @@ def test_bf16x3_split_is_exact_and_fp32_grade():
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
     errs = {}
-    for name, cfg, wx in (('fp32', 19, None), ('bf16x3', 31, planes), ('bf16x3-b', 32, planes)):
+    xd = nhwc(x).cuda()
+    wf = ops.split_weights_f16x2(wk, one)
+    for name, cfg, wx in (('fp32', 19, None), ('bf16x3', 31, planes), ('bf16x3-b', 32, planes), ('f16x2', 40, None),
+                          ('f16x2-b', 44, None)):
         y = torch.zeros(N, H, W, K).cuda()
-        ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, one, zero, ops.View(y), 1, 1, None, cfg=cfg, splitk=1, w_x3=wx)
+        ops.conv2d_bn_act(ops.View(xd), wk, one, zero, ops.View(y), 1, 1, None, cfg=cfg, splitk=1, w_x3=wx,
+                          w_f16=wf if cfg >= 40 else None, amax_in=ops.amax_slots(xd) if cfg >= 40 else None)
         torch.cuda.synchronize()
         errs[name] = (((nchw(y).cpu().double() - ref) / mag) ** 2).mean().sqrt().item()
     print('rms error / sum|a*b| vs fp64:', errs)
-    assert errs['bf16x3'] <= 1.25 * errs['fp32'] and errs['bf16x3-b'] <= 1.25 * errs['fp32'], errs
+    assert all(errs[k] <= 1.25 * errs['fp32'] for k in errs), errs
     with pytest.raises(PPYoloHipError):
         ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, one, zero, ops.View(y), 1, 1, None, cfg=31, splitk=1)

@@ -25,12 +25,14 @@ def main():
     res = torch.randn(N, Ho, Wo, K, device='cuda') if use_res else None
     ws = torch.empty(64 << 20, device='cuda')
     w3 = ops.split_weights_bf16x3(w)
+    wf = ops.split_weights_f16x2(w, sc)
+    amax = ops.amax_slots(x)
     flops = 2.0 * N * Ho * Wo * K * R * R * C
     for cfg in cfgs:
         def run():
             ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu',
                               residual=None if res is None else ops.View(res), cfg=cfg, splitk=splitk, ws=ws,
-                              w_x3=w3)
+                              w_x3=w3, w_f16=wf, amax_in=amax)
         for _ in range(3):
             run()
         torch.cuda.synchronize()

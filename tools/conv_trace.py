@@ -22,9 +22,9 @@ y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device=
 tr = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
 L = _lib.lib()._handle
 lib = ctypes.CDLL(_lib.LIB_PATH)
-w3 = ops.split_weights_bf16x3(w)
+w3 = ops.split_weights_bf16x3(w); wf16 = ops.split_weights_f16x2(w, sc); amax0 = ops.amax_slots(x)
 def run():
-    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws, w_x3=w3)
+    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0)
 for _ in range(int(os.environ.get('PPY_TRACE_WARM', '3'))): run()
 torch.cuda.synchronize()
 lib.ppy_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))

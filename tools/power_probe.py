@@ -16,7 +16,7 @@ Ho, Wo = ops.conv_out_hw(H, W, R, R, stride, pad)
 x = torch.randn(N, H, W, C, device='cuda'); w = torch.randn(K, R, R, C, device='cuda') * 0.05
 if mode == 'zeros': x.zero_(); w.zero_()
 sc, sh = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
-y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device='cuda'); w3 = ops.split_weights_bf16x3(w)
+y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device='cuda'); w3 = ops.split_weights_bf16x3(w); wf16 = ops.split_weights_f16x2(w, sc); amax0 = ops.amax_slots(x)
 samples = []
 stop = False
 def poll():
@@ -32,7 +32,7 @@ th = threading.Thread(target=poll); th.start()
 t0 = time.time(); it = 0
 while time.time() - t0 < secs:
     for _ in range(200):
-        ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=1, ws=ws, w_x3=w3)
+        ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=1, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0)
     torch.cuda.synchronize(); it += 200
 dt = time.time() - t0
 stop = True; th.join()
