@@ -593,6 +593,8 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     // no measured choice for this shape: with split weights at hand the 128x64 bf16x3 tile (two workgroups per
     // CU) is the one that won most layers of the measured tables; narrow / shallow layers stay on the fp32 kernels
     if (cfg < 0 && w_x3 && K >= 48 && g.chunks >= 4) c = kNumCfgs + 4;
+    if (cfg < 0 && w_f16x2 && scale_f16x2 && amax_in && !posbias && K >= 48 && g.chunks >= 4)
+        c = kNumCfgs + ppy_x3_num_configs() / 2 + 4;      // the same tile on the f16x2 kernel
     if (s > 1) {
         const size_t need = (size_t)s * g.M * K * sizeof(float);
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;

@@ -51,25 +51,28 @@ NUM_X3_CFGS = 9          # then the bf16x3 kernels [31, 40), then the f16x2 kern
 
 def math_mode():
     """How the convolution inner products are evaluated (PPYOLO_HIP_MATH):
-      'f16x2':  2-term fp16 split of both operands after power-of-two scaling into the fp16 range (weights per output
+      'f16x2' (default):  2-term fp16 split of both operands after power-of-two scaling into the fp16 range (weights per output
                 channel at plan time, activations by the maximum their producers track), 3 partial products on the fp16
                 MFMA, fp32 accumulate -- fp32-grade results at half the MFMA work of bf16x3; layers whose input
                 maximum is not tracked (stem side) or that carry a CoordConv bias map use the modes below;
-      'bf16x3' (default): exact 3-term bf16 split of both fp32 operands, 6 partial products on the bf16 MFMA,
+      'bf16x3': exact 3-term bf16 split of both fp32 operands, 6 partial products on the bf16 MFMA,
                 fp32 accumulate -- fp32-grade results (csrc/conv_x3.hip) at 6/16 of the fp32 MFMA cost; the
                 measured table may still pick an exact-fp32 kernel for a layer where that is faster;
       'fp32':   v_mfma_f32_32x32x2_f32 only (a k-ordered fp32 fma chain)."""
-    m = os.environ.get('PPYOLO_HIP_MATH', 'bf16x3')
+    m = os.environ.get('PPYOLO_HIP_MATH', 'f16x2')
     if m not in _TUNED_PATHS:
         raise PPYoloHipError('PPYOLO_HIP_MATH must be one of %s' % sorted(_TUNED_PATHS))
     return m
 
 
 def tune_key(op):
-    """Shape key of a conv / DCN launch in the measured (tile config, split-K) table."""
+    """Shape key of a conv / DCN launch in the measured (tile config, split-K) table.  Launches that can use the
+    f16x2 kernels (split fp16 weights at hand, tracked input maximum) carry ':f' -- the same shape without them
+    (CoordConv layers, stem side) needs its own entry."""
     x = op['x']
     Kout, R, S, C = op['w'].shape
-    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (op['op'], x.N, x.H, x.W, C, Kout, R, op['stride'])
+    f16 = op.get('wf16') is not None and op.get('amax_in_id') is not None
+    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s' % (op['op'], x.N, x.H, x.W, C, Kout, R, op['stride'], ':f' if f16 else '')
 
 
 def tuned_table(mode=None):
@@ -268,9 +271,12 @@ class HipExecutor(object):
                             op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
         self._assign_amax()
         tab = tuned_table(self.math)
+        tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
         for op in p.ops:
-            if op['op'] in ('conv', 'dcn') and op['cfg'] < 0 and tune_key(op) in tab:
-                op['cfg'], op['splitk'] = tab[tune_key(op)][:2]
+            if op['op'] in ('conv', 'dcn') and op['cfg'] < 0:
+                ent = tab.get(tune_key(op)) or tab_x3.get(tune_key(op))      # (a layer without ':f' behaves as in bf16x3 mode)
+                if ent:
+                    op['cfg'], op['splitk'] = ent[:2]
         self.ws = None
         self.ws_side = None
         self._size_workspace()

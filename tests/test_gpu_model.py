@@ -81,7 +81,7 @@ def _check_preds(preds, refs, keep=None, ref_keep=None, box_tol=1e-3, near_tie=2
 
 
 @pytest.mark.parametrize('tag,cfgc', [('r18vd_320', PPYOLO_r18vd_Config), ('r50vd_160', PPYOLO_2x_Config)])
-@pytest.mark.parametrize('graph,math', [('0', 'bf16x3'), ('1', 'bf16x3'), ('1', 'fp32')])
+@pytest.mark.parametrize('graph,math', [('0', 'bf16x3'), ('1', 'bf16x3'), ('1', 'fp32'), ('1', 'f16x2'), ('0', 'f16x2')])
 def test_end_to_end_golden(golden, tag, cfgc, graph, math, monkeypatch):
     monkeypatch.setenv('PPYOLO_HIP_GRAPH', graph)
     monkeypatch.setenv('PPYOLO_HIP_MATH', math)
@@ -173,7 +173,7 @@ def test_full_size_vs_oracle_and_batch_properties(cfgc, S):
         assert 1 <= p.shape[0] <= 100 and torch.all(p[:-1, 1] >= p[1:, 1]), 'scores not sorted descending'
 
 
-@pytest.mark.parametrize('math', ['bf16x3', 'fp32'])
+@pytest.mark.parametrize('math', ['f16x2', 'bf16x3', 'fp32'])
 def test_fp64_three_way(math, monkeypatch):
     """What "parity" means for a 70-layer fp32 network: run the oracle in float64 as the exact
     answer; the HIP path -- in both math modes: bf16x3 split products on the bf16 MFMA (default) and the
@@ -199,6 +199,7 @@ def test_fp64_three_way(math, monkeypatch):
         assert e_hip <= 1.5 * e_ref + 1e-7, 'level %d: HIP rms error %.3e vs reference fp32 %.3e' % (i, e_hip, e_ref)
         assert (h - o64[i]).abs().max() <= 1e-4
     assert ex.math == math and (math == 'fp32') == all(op.get('w3') is None for op in ex.plan.ops)
+    assert (math == 'f16x2') == any(op.get('wf16') is not None for op in ex.plan.ops)
 
 
 def test_autotuned_plan_same_answer():
