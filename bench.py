@@ -36,7 +36,9 @@ BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS     # same guide: fp32 MFMA =
 # bf16x3 kernels (csrc/conv_x3.hip) execute 6 bf16 MFMA products per fp32 multiply-add: their MFMA roofline in
 # units of ALGORITHMIC fp32 FLOPs is the bf16 peak / 6
 X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
-NUM_FP32_CFGS = 31
+# f16x2 kernels: 3 fp16 MFMA products per multiply-add (fp16 MFMA rate = bf16 rate)
+F16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+NUM_FP32_CFGS, NUM_X3_CFGS = 31, 9
 
 WORKLOADS = {
     'r50vd_608': dict(cfg='PPYOLO_2x_Config', size=608, model='PPYOLO ResNet50-vd (DCNv2, CoordConv, SPP)'),
@@ -109,12 +111,14 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
         best = ms if best is None else min(best, ms)
     # MFMA-pipe time the same launches would need at peak: per launch flops / (peak of the kernel family it ran on)
     ideal_s = 0.0
-    x3_flops = 0
+    fam_flops = {'fp32': 0, 'bf16x3': 0, 'f16x2': 0}
     for i in convs:
-        x3 = ex.plan.ops[i].get('w3') is not None and ex.plan.ops[i]['cfg'] >= NUM_FP32_CFGS
-        ideal_s += per_op_flops[i] / ((X3_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS) * 1e12)
-        x3_flops += per_op_flops[i] if x3 else 0
-    return best, sum(per_op_flops[i] for i in convs), len(convs), ideal_s, x3_flops
+        cfg = ex.plan.ops[i]['cfg']
+        fam = 'fp32' if cfg < NUM_FP32_CFGS else ('bf16x3' if cfg < NUM_FP32_CFGS + NUM_X3_CFGS else 'f16x2')
+        peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16x3': X3_PEAK_TFLOPS, 'f16x2': F16X2_PEAK_TFLOPS}[fam]
+        ideal_s += per_op_flops[i] / (peak * 1e12)
+        fam_flops[fam] += per_op_flops[i]
+    return best, sum(per_op_flops[i] for i in convs), len(convs), ideal_s, fam_flops
 
 
 def layer_report(ex, per_op, path):
@@ -291,7 +295,7 @@ def main():
 
     if rank == 0:
         total_flops, per_op = conv_flops(ex.plan)
-        conv_ms, covered, nconv, ideal_s, x3_flops = timed_conv_pass(ex, per_op)
+        conv_ms, covered, nconv, ideal_s, fam_flops = timed_conv_pass(ex, per_op)
         achieved = covered / (conv_ms * 1e-3) / 1e12
         peak = covered / ideal_s / 1e12        # flop-weighted peak of the kernel mix of this step
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
@@ -305,16 +309,16 @@ def main():
                     frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit='bytes per launch (mean over the conv launches of a step; PMC '
                                  '2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)',
-                    kernel='conv_igemm_x3_kernel<*> (fp32 implicit GEMM as 6 x v_mfma_f32_32x32x16_bf16 per product, exact '
-                           '3-term bf16 operand split) / conv_igemm_glds_kernel<*> (v_mfma_f32_32x32x2_f32), %d launches/step'
-                           % nconv,
+                    kernel='conv_igemm_x3_kernel<*> (fp32-in/fp32-out implicit GEMM on the 16-bit MFMA: f16x2 = 3 x '
+                           'v_mfma_f32_32x32x16_f16 per product after a 2-term fp16 split, bf16x3 = 6 x ..._bf16 after a 3-term '
+                           'bf16 split) / conv_igemm_glds_kernel<*> (v_mfma_f32_32x32x2_f32), %d launches/step' % nconv,
                     peak_note='achieved = algorithmic fp32 FLOPs / HIP-event time of the conv launches; peak = the same '
-                              'FLOPs / MFMA-pipe time at peak, where a bf16x3 launch is priced at %.1f (= dense bf16 '
-                              'MFMA %.1f / 6 products per multiply-add) and an exact-fp32 launch at %.1f TFLOP/s; '
-                              '%.1f%% of the FLOPs ran on bf16x3 kernels.  Peaks are at the nominal 2.4 GHz; under dense bf16 MFMA on '
-                              'real operands the chip runs 1.6-1.8 GHz (power management; DESIGN.md 4.1)' % (
-                                  X3_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS,
-                                  100.0 * x3_flops / max(1, covered)),
+                              'FLOPs / MFMA-pipe time at peak, pricing a launch by its kernel family: f16x2 %.1f (= dense '
+                              '16-bit MFMA %.1f / 3 products per multiply-add), bf16x3 %.1f (/ 6), exact fp32 %.1f TFLOP/s; '
+                              'FLOP shares: %s.  Peaks are at the nominal 2.4 GHz; under dense 16-bit MFMA on real '
+                              'operands the board runs at its 1400 W power cap and ~1.8-2.1 GHz (DESIGN.md 4.1)' % (
+                                  F16X2_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, X3_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS,
+                                  ', '.join('%s %.1f%%' % (k, 100.0 * v / max(1, covered)) for k, v in fam_flops.items())),
                     achieved_vs_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
                     whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4))
@@ -327,9 +331,12 @@ def main():
                                         % (wl['model'], wl['size'], wl['size'], a.batch),
                                global_batch=world * a.batch, parallelism='batch-sharded x%d, all-gather of detections'
                                % world if world > 1 else 'single GPU', hip_graph=not a.no_graph,
-                               math=ex.math + (' (fp32 in/out, fp32 accumulate; operands split exactly into 3 bf16 terms, 6 partial '
-                                                'products; error vs fp64 <= the fp32 fma chain, tests/test_gpu_ops.py)'
-                                                if ex.math == 'bf16x3' else ''),
+                               math=ex.math + {'f16x2': ' (fp32 in/out, fp32 accumulate; operands scaled by powers of two and split into 2 '
+                                                         'fp16 terms, 3 partial products; error vs fp64 <= the fp32 fma chain, '
+                                                         'tests/test_gpu_ops.py, tests/test_gpu_model.py::test_fp64_three_way)',
+                                                'bf16x3': ' (fp32 in/out, fp32 accumulate; operands split exactly into 3 bf16 '
+                                                          'terms, 6 partial products; error vs fp64 <= the fp32 fma chain)'
+                                                }.get(ex.math, ''),
                                tile_table='re-measured' if a.autotune else os.path.basename(_tuned_path(ex.math))),
                    roofline=roof)
         if a.layer_report:
