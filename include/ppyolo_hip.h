@@ -74,8 +74,9 @@ const char *ppy_error_string(int code);
  * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40): 2-term fp16 split of both operands,
  * 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation; the activations are scaled on the fly by the
  * power of two that puts the tensor maximum into [2^13, 2^14), read from `amax_in`.  Error vs fp64 at the level of
- * the exact-fp32 fma chain (tools/probes/f16x2_probe.hip, profiles/r01_f16x2_numerics.txt).  Needs amax_in and
- * posbias == NULL, else PPY_ERR_BAD_ARG.
+ * the exact-fp32 fma chain (tools/probes/f16x2_probe.hip, profiles/r01_f16x2_numerics.txt).  Needs amax_in, and with a
+ * posbias also posbias_f16x2 = posbias[., k] * scale[k] / scale_f16x2[k] (the bias map in the scaled-weight domain),
+ * else PPY_ERR_BAD_ARG.
  * amax_in / amax_out: NULL, or PPY_AMAX_FLOATS floats each: the running max|.| of the input tensor (an upper bound is
  * enough) and the slots into which this launch merges max|y| of what it stores (atomic max; the owner zeroes the
  * slots before the first producer of a tensor runs).  A consumer takes the maximum over all PPY_AMAX_FLOATS values.
@@ -88,8 +89,8 @@ int ppy_conv2d_split_weights_f16x2(const float *w_krsc, int K, long long kred, c
 int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
                           const void *w_f16x2, const float *scale, const float *scale_f16x2,
                           const float *shift, const float *residual, int res_ld,
-                          const float *posbias, float *y, int y_ld, int N, int H, int W,
-                          int C, int K, int R, int S, int stride, int pad, int act,
+                          const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N,
+                          int H, int W, int C, int K, int R, int S, int stride, int pad, int act,
                           int upsample2x, int cfg, int splitk, const float *amax_in, float *amax_out,
                           void *ws, size_t ws_bytes, void *stream);
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,

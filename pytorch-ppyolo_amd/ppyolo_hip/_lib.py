@@ -27,7 +27,7 @@ _PROTOS = {
     'ppy_conv2d_split_weights_bf16x3': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
     'ppy_conv2d_split_weights_f16x2': (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_int, c_void_p, c_void_p, c_int] + [c_int] * 13
+                                       c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 13
                               + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'ppy_conv2d_num_configs': (c_int, []),

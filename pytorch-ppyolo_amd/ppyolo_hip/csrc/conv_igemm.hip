@@ -575,8 +575,8 @@ extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
                                      const void *w_f16x2, const float *scale, const float *scale_f16x2,
                                      const float *shift, const float *residual, int res_ld,
-                                     const float *posbias, float *y, int y_ld, int N, int H, int W, int C,
-                                     int K, int R, int S, int stride, int pad, int act, int upsample2x,
+                                     const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
                                      int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
                                      size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
@@ -593,7 +593,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     // no measured choice for this shape: with split weights at hand the 128x64 bf16x3 tile (two workgroups per
     // CU) is the one that won most layers of the measured tables; narrow / shallow layers stay on the fp32 kernels
     if (cfg < 0 && w_x3 && K >= 48 && g.chunks >= 4) c = kNumCfgs + 4;
-    if (cfg < 0 && w_f16x2 && scale_f16x2 && amax_in && !posbias && K >= 48 && g.chunks >= 4)
+    if (cfg < 0 && w_f16x2 && scale_f16x2 && amax_in && (!posbias || posbias_f16x2) && K >= 48 && g.chunks >= 4)
         c = kNumCfgs + ppy_x3_num_configs() / 2 + 4;      // the same tile on the f16x2 kernel
     if (s > 1) {
         const size_t need = (size_t)s * g.M * K * sizeof(float);
@@ -601,7 +601,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     }
     ConvArgs p;
     p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.wf16 = (const unsigned short *)w_f16x2;
-    p.scale_f16 = scale_f16x2; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
+    p.scale_f16 = scale_f16x2; p.posb_f16 = posbias_f16x2; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
     p.y = y; p.part = (float *)ws;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;

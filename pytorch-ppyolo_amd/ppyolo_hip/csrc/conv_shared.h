@@ -8,6 +8,7 @@ struct ConvArgs {
     const unsigned short *w3;    // weights as 3 bf16 planes [3][K][R][S][C] (conv_x3.hip), or NULL
     const unsigned short *wf16;  // weights * per-channel power of two as 2 fp16 planes [2][K][R][S][C], or NULL
     const float *scale_f16;      // `scale` with the inverse weight scale folded in (f16x2 kernels)
+    const float *posb_f16;       // posb times the per-channel weight scale (f16x2 kernels), or NULL
     const float *amax_in;        // tracked max|x| of the input tensor (AMAX_SLOTS slots), or NULL
     float *amax_out;             // where this launch records max|y| (AMAX_SLOTS slots), or NULL
     float *y, *part;

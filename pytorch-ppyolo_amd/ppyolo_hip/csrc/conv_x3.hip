@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
         int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
-        f = f < 1 ? 1 : (f > 253 ? 253 : f);
+        f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite
         f = __builtin_amdgcn_readfirstlane(f);                         // wave-uniform -> scalar registers
         sa = __uint_as_float((unsigned)f << 23);
         inv_sa = __uint_as_float((unsigned)(254 - f) << 23);
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, 
     mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
     const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
     int f = 267 - e;
-    f = f < 1 ? 1 : (f > 253 ? 253 : f);
+    f = f < 103 ? 103 : (f > 167 ? 167 : f);      // [2^-24, 2^40], as for the activations
     const float sw = __uint_as_float((unsigned)f << 23), inv = __uint_as_float((unsigned)(254 - f) << 23);
     const long long n = (long long)K * kred;
     for (long long i = tid; i < kred; i += 256) {
@@ -570,11 +570,12 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0) return PPY_ERR_BAD_ARG;
         return dispatch_scheme<false>(p, c, s, st);
     }
-    // f16x2 needs the split weights + folded scale, the tracked maximum of the input, and no CoordConv bias map
-    // (it would have to be pre-scaled per channel)
-    if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || p.posb) return PPY_ERR_BAD_ARG;
+    // f16x2 needs the split weights + folded scale, the tracked maximum of the input, and a CoordConv bias map
+    // pre-multiplied by the per-channel weight scale
+    if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
     ConvArgs q = p;
     q.scale = p.scale_f16;
+    q.posb = p.posb ? p.posb_f16 : nullptr;
     return dispatch_scheme<true>(q, c - kNumX3, s, st);
 }
 

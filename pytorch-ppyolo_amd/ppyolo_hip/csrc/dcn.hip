@@ -124,7 +124,7 @@ extern "C" int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, cons
     if (rc != PPY_OK) return rc;
     // contraction over (tap, c): a 1x1 conv on the columns viewed as NHWC [N,Ho,Wo,9C]
     // |column| <= max|x| (bilinear weights and the sigmoid mask are <= 1): the input's tracked maximum bounds the columns
-    return ppy_conv2d_bn_act_f32(cols, 9 * C, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, nullptr, 0, nullptr, y, y_ld, N, Ho, Wo,
+    return ppy_conv2d_bn_act_f32(cols, 9 * C, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, nullptr, 0, nullptr, nullptr, y, y_ld, N, Ho, Wo,
                                  9 * C, K, 1, 1, 1, 0, act, 0, cfg, splitk, amax_in, amax_out, (char *)ws + cols_bytes,
                                  ws_bytes - cols_bytes, stream);
 }

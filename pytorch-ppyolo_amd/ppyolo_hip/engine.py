@@ -267,7 +267,7 @@ class HipExecutor(object):
                 for op in p.ops:        # (setup ops -- the CoordConv bias maps -- stay on the exact-fp32 kernel)
                     if op['op'] in ('conv', 'dcn'):
                         op['w3'] = K.split_weights_bf16x3(op['w'])
-                        if self.math == 'f16x2' and op.get('posb') is None:
+                        if self.math == 'f16x2':
                             op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
         self._assign_amax()
         tab = tuned_table(self.math)
@@ -290,6 +290,10 @@ class HipExecutor(object):
             for op in p.setup_ops:
                 self._run_op(op)
             torch.cuda.synchronize()
+            for op in p.ops:      # CoordConv bias maps in the scaled-weight domain of the f16x2 kernels (exact: powers of two)
+                if op.get('wf16') is not None and op.get('posb') is not None:
+                    s_w = torch.where(op['scale'] != 0, op['scale'] / op['wf16'][1], torch.ones_like(op['scale']))
+                    op['posb_f16'] = (self.bufs[op['posb'].buf] * s_w).contiguous()
 
     def _assign_amax(self):
         """Tracked tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
@@ -399,7 +403,7 @@ class HipExecutor(object):
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
                             ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
-                            self._amax(op.get('amax_out_id')))
+                            self._amax(op.get('amax_out_id')), op.get('posb_f16'))
         elif t == 'stem':
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
         elif t == 'maxpool':

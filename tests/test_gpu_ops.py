@@ -84,16 +84,16 @@ def test_conv_every_tile_config(cfg, splitk):
     rbuf[..., 4:] = nhwc(res).cuda()
     ws = torch.empty(max(4, ops.conv2d_workspace_bytes(N, H, W, C, K, R, R, 1, 1, cfg, splitk) // 4)).cuda()
     wk = w.permute(0, 2, 3, 1).contiguous().cuda()
-    f16 = cfg >= 40                      # the f16x2 kernels take no per-position bias: fold it into the residual instead
-    if f16:
-        rbuf[..., 4:] += (nhwc(posb) * scale.view(1, 1, 1, -1)).cuda()
+    f16 = cfg >= 40
+    wf = ops.split_weights_f16x2(wk, scale.cuda()) if f16 else None
+    pb = nhwc(posb).contiguous().cuda()
     amax_out = ops.amax_slots(device='cuda')
     ops.conv2d_bn_act(ops.View(xin, 32, C), wk, scale.cuda(), shift.cuda(),
                       ops.View(yout, 8, K), 1, 1, 'leaky', residual=ops.View(rbuf, 4, K),
-                      posbias=None if f16 else nhwc(posb).contiguous().cuda(), cfg=cfg, splitk=splitk, ws=ws,
-                      w_x3=ops.split_weights_bf16x3(wk) if 31 <= cfg < 40 else None,
-                      w_f16=ops.split_weights_f16x2(wk, scale.cuda()) if f16 else None,
-                      amax_in=ops.amax_slots(xin) if f16 else None, amax_out=amax_out)
+                      posbias=pb, cfg=cfg, splitk=splitk, ws=ws,
+                      w_x3=ops.split_weights_bf16x3(wk) if 31 <= cfg < 40 else None, w_f16=wf,
+                      amax_in=ops.amax_slots(xin) if f16 else None, amax_out=amax_out,
+                      posbias_f16=(pb * (scale.cuda() / wf[1])).contiguous() if f16 else None)
     torch.cuda.synchronize()
     assert abs(amax_out.max().item() - ref.abs().max().item()) <= 1e-3, "tracked max|y| is off"
     close(nchw(yout[..., 8:]), ref, what='cfg %d split %d' % (cfg, splitk))
