@@ -106,7 +106,7 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  * x: [N,3,H,W] NCHW contiguous.  w: [K][3][3][3] in the reference's own KCRS order. */
 int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
                                 const float *shift, float *y, int y_ld, int N, int H, int W,
-                                int K, int act, void *stream);
+                                int K, int act, float *amax_out /* NULL or PPY_AMAX_FLOATS slots */, void *stream);
 
 /* torch.nn.MaxPool2d(3, 2, 1) of the stem (reference model/resnet_vd.py:103, :136). */
 int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W,

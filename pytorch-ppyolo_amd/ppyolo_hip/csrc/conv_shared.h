@@ -31,18 +31,6 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-// Producer-side tracking of max|y| of a tensor (the f16x2 kernels scale their input by a power of two derived from it).
-// To keep thousands of waves off one address the maximum lives in AMAX_SLOTS slots, AMAX_STRIDE floats apart (one
-// 64-byte line each); a consumer takes the maximum over the slots.  Values are non-negative, so the unsigned image
-// of the float orders like the float.  The owner zeroes the slots before the producers run.
-constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 16;
-__device__ __forceinline__ void amax_track(float mx, float *amax, int slot) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f)
-        atomicMax(reinterpret_cast<unsigned *>(amax) + (slot & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(mx));
-}
-
 __device__ __forceinline__ float epilogue_store(const ConvArgs &p, int m, int col, float v,
                                                 float sc, float sh) {
     const int hw = p.Ho * p.Wo;

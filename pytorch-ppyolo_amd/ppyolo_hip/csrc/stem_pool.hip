@@ -17,10 +17,11 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float *__restrict_
                                                         const float *__restrict__ scale,
                                                         const float *__restrict__ shift, float *y,
                                                         int y_ld, int N, int H, int W, int Ho, int Wo,
-                                                        int K, int act) {
+                                                        int K, int act, float *amax_out) {
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)N * Ho * Wo;
-    if (pix >= total) return;
+    float amx = 0.0f;
+    if (pix < total) {
     const int k0 = blockIdx.y * KT;
     const int wo = (int)(pix % Wo);
     const int ho = (int)((pix / Wo) % Ho);
@@ -49,9 +50,12 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float *__restrict_
 #pragma unroll
             for (int t = 0; t < 27; ++t) acc = fmaf(in[t], w[k * 27 + t], acc);
             r4[u] = ppy_apply_act(fmaf(acc, scale[k], shift[k]), act);
+            amx = fmaxf(amx, fabsf(r4[u]));
         }
         *reinterpret_cast<floatx4 *>(o + kk) = r4;
     }
+    }
+    if (amax_out) amax_track(amx, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));      // tracked max|y| (f16x2 consumers)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -179,7 +183,7 @@ int grid_for(long long total) {
 
 extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
                                            const float *shift, float *y, int y_ld, int N, int H, int W,
-                                           int K, int act, void *stream) {
+                                           int K, int act, float *amax_out, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x_nchw && w_kcrs && scale && shift && y);
     PPY_CHECK_ARG(N > 0 && H > 0 && W > 0 && K > 0 && K % 16 == 0 && y_ld >= K && y_ld % 4 == 0);
@@ -188,7 +192,7 @@ extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_k
     const long long total = (long long)N * Ho * Wo;
     dim3 grid((unsigned)((total + 255) / 256), K / 16);
     hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, w_kcrs, scale,
-                       shift, y, y_ld, N, H, W, Ho, Wo, K, act);
+                       shift, y, y_ld, N, H, W, Ho, Wo, K, act, amax_out);
     return ppy_launch_status();
 }
 

@@ -298,8 +298,8 @@ class HipExecutor(object):
     def _assign_amax(self):
         """Tracked tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
         output buffer; pooled tensors inherit the slots of their input (max- and average-pooling never exceed it; SPP
-        writes into its own input buffer; the DCN columns are bounded by the DCN input).  The stem output is not
-        tracked."""
+        writes into its own input buffer; the DCN columns are bounded by the DCN input); the stem kernel tracks its
+        output as well."""
         amax_of, nblocks = {}, 0
         for op in self.plan.ops:
             t = op['op']
@@ -314,7 +314,9 @@ class HipExecutor(object):
                 if amax_of.get(op['x'].buf) is not None:
                     amax_of[op['y'].buf] = amax_of[op['x'].buf]
             elif t == 'stem':
-                amax_of[op['y'].buf] = None
+                amax_of[op['y'].buf] = nblocks
+                op['amax_out_id'] = nblocks
+                nblocks += 1
         self.amax = torch.zeros(max(1, nblocks) * K.AMAX_FLOATS, dtype=torch.float32, device=self.device)
 
     def _amax(self, idx):
@@ -405,7 +407,8 @@ class HipExecutor(object):
                             ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
                             self._amax(op.get('amax_out_id')), op.get('posb_f16'))
         elif t == 'stem':
-            K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'])
+            K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'],
+                        self._amax(op.get('amax_out_id')))
         elif t == 'maxpool':
             K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
         elif t == 'avgpool':

@@ -133,12 +133,12 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
-def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu'):
+def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None):
     _dev(x_nchw, w_kcrs, scale, shift, y.t)
     N, C, H, W = x_nchw.shape
     assert C == 3 and x_nchw.is_contiguous() and w_kcrs.is_contiguous() and tuple(w_kcrs.shape[1:]) == (3, 3, 3)
     check(lib().ppy_stem_conv3x3s2_nchw_f32(x_nchw.data_ptr(), w_kcrs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                            y.ptr, y.ld, N, H, W, w_kcrs.shape[0], ACT[act], _stream()),
+                                            y.ptr, y.ld, N, H, W, w_kcrs.shape[0], ACT[act], _p(amax_out), _stream()),
           'ppy_stem_conv3x3s2_nchw_f32')
 
 
