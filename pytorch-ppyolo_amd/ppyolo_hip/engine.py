@@ -512,26 +512,36 @@ class HipExecutor(object):
                 Kout = op['w'].shape[0]
                 Kred = op['w'].shape[1] * op['w'].shape[2] * op['w'].shape[3]
                 chunks = Kred // 32
-                best = None
                 base_cfg, base_split = op['cfg'], op['splitk']
+
+                def measure(c, s, n):
+                    op['cfg'], op['splitk'] = c, s
+                    try:
+                        self._run_op(op)
+                    except PPYoloHipError:
+                        return None
+                    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    st.record()
+                    for _ in range(n):
+                        self._run_op(op)
+                    en.record()
+                    en.synchronize()
+                    return st.elapsed_time(en) / n
+
+                cands = []
                 for c in range(ncfg):
                     for s in splits:
                         if s > 1 and chunks // s < 4:
                             continue
-                        op['cfg'], op['splitk'] = c, s
-                        try:
-                            self._run_op(op)
-                        except PPYoloHipError:
-                            continue
-                        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        st.record()
-                        for _ in range(iters):
-                            self._run_op(op)
-                        en.record()
-                        en.synchronize()
-                        ms = st.elapsed_time(en) / iters
-                        if best is None or ms < best[0]:
-                            best = (ms, c, s)
+                        ms = measure(c, s, iters)
+                        if ms is not None:
+                            cands.append((ms, c, s))
+                # second look at the front-runners: short kernels are noisy at `iters` repetitions
+                best = None
+                for ms, c, s in sorted(cands)[:6]:
+                    again = min(measure(c, s, 4 * iters), measure(c, s, 4 * iters))
+                    if best is None or again < best[0]:
+                        best = (again, c, s)
                 if best is None:
                     op['cfg'], op['splitk'] = base_cfg, base_split
                     continue
