@@ -1,30 +1,33 @@
-// fp32 implicit-GEMM convolution on the bf16 MFMA of gfx950: "bf16x3" operand split.
+// fp32 implicit-GEMM convolution on the 16-bit MFMA of gfx950: "f16x2" and "bf16x3" operand splits.
 //
 // Same operator as conv_igemm.hip (Conv2dUnit.forward of the reference, model/custom_layers.py:243-253,
 // with the residual / CoordConv / upsample terms around it), same tensors (fp32 NHWC in, fp32 out),
-// same epilogue.  Only the inner product is organised differently:
+// same epilogue.  Only the inner product is organised differently -- gfx950 has no TF32-class path and its
+// exact-fp32 MFMA runs at 1/16 of the 16-bit rate, so an fp32 product is assembled from exactly-split pieces:
 //
-//   every fp32 operand is split EXACTLY into three bf16 terms  a = a0 + a1 + a2  (8 + 8 + 8
-//   significant bits, round-to-nearest at each level, the residuals a - a0 and a - a0 - a1 are exact
-//   in fp32), and  a*b  is evaluated as the six partial products of weight >= 2^-16
-//       a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0
-//   on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact, accumulation is fp32).  The three
-//   dropped products are <= 2^-24 |a*b| each.  Measured on MI355X against an fp64 reference
-//   (tools/probes/bf16x_probe.hip, profiles/r01_bf16x3_numerics.txt): rms error 2.0-3.5e-8 of
-//   sum|a*b| for K = 256..4608 -- the same or slightly LOWER than the exact-fp32 MFMA's k-ordered fma
-//   chain (2.3-4.2e-8), because 16 products are summed per accumulator rounding instead of one.
-//   The bf16 MFMA runs 16x the fp32 MFMA rate, so six of them cost 6/16 of the fp32 instruction:
-//   the MFMA ceiling of this kernel is 2516.6 / 6 = 419 TFLOP/s of fp32-equivalent work.
-//   (Inf/NaN inputs give NaN where the fp32 kernel gives Inf: inf - inf in the residual.)
+//   bf16x3 (F16 = false): every fp32 operand is split EXACTLY into three bf16 terms  a = a0 + a1 + a2  (8 + 8 + 8
+//     significant bits, round-to-nearest at each level, the residuals are exact in fp32) and  a*b  is evaluated as
+//     the six partial products of weight >= 2^-16   a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0
+//     on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact, accumulation is fp32); the three dropped
+//     products are <= 2^-24 |a*b| each.  No scaling, no range question.  MFMA ceiling 2516.8 / 6 = 419.5 TFLOP/s.
+//   f16x2 (F16 = true): both operands are first scaled by a power of two into the fp16 range -- weights per output
+//     channel at plan time (ppy_conv2d_split_weights_f16x2, 1/s folded into the epilogue scale), activations per
+//     tensor at run time from the maximum their producers track (amax_track / ConvArgs::amax_in, 64 atomic-max
+//     slots) -- and split into TWO fp16 terms  a*s = a0 + a1  (RNE; the residual fma(a, s, -a0) is exact); a*b is
+//     the three leading products  a1*b0 + a0*b1 + a0*b0  on v_mfma_f32_32x32x16_f16.  Representation error <= 2^-22
+//     per operand, unbiased, so it averages out over the reduction.  MFMA ceiling 2516.8 / 3 = 839 TFLOP/s.
+//   Measured on MI355X against fp64 (tools/probes/f16x2_probe.hip, bf16x_probe.hip -> profiles/r01_*_numerics.txt):
+//   rms error of sum|a*b| for K = 64..4608: f16x2 1.5-3.3e-8, bf16x3 1.9-3.6e-8, exact-fp32 MFMA 2.3-4.5e-8 (a
+//   k-ordered fma chain rounds once per product; here 16 products are summed per accumulator rounding).
+//   (Inf/NaN inputs give NaN where the fp32 kernel gives Inf.)
 //
-// Data movement (all through the LDS-DMA loader of conv_igemm.hip, counted vmcnt, one barrier per
-// 32-deep chunk):
-//   * activations stay fp32 in HBM and in LDS ([BM][32] floats, XOR-swizzled 16-byte slots); each wave
-//     reads the rows of ITS sub-tile, splits them in registers (v_cvt_pk_bf16_f32, shift/and, subtract:
-//     4.5 VALU instructions per element, issued in the shadow of the MFMAs) and feeds the MFMA directly;
-//   * weights are constant: they are split once per plan into three bf16 planes [3][K][R][S][C]
-//     (ppy_conv2d_split_weights_bf16x3) and DMA'd as three [BN][32] bf16 tiles per chunk.
-// Wave tiles are wide in N (64x128 / 64x64) so that one split of an A fragment feeds 24 / 12 MFMAs.
+// Data movement (all through the LDS-DMA loader of conv_igemm.hip, counted vmcnt, one barrier per 32-deep chunk):
+//   * activations stay fp32 in HBM and in LDS ([BM][32] floats, XOR-swizzled 16-byte slots); each wave reads the
+//     rows of ITS sub-tile, scales/splits them in registers (f16x2: 3 VALU instructions per element, bf16x3: 4.5,
+//     issued in the shadow of the MFMAs) and feeds the MFMA directly;
+//   * weights are constant: split once per plan into 2 fp16 / 3 bf16 planes [NP][K][R][S][C] and DMA'd as NP
+//     [BN][32] 16-bit tiles per chunk.
+// Wave tiles are wide in N (64x128 ... 32x64) so that one split of an A fragment feeds many MFMAs.
 #include "conv_shared.h"
 
 #include <type_traits>
