@@ -142,6 +142,37 @@ def layer_report(ex, per_op, path):
         json.dump(rows, fh, indent=0)
 
 
+def alt_math_leg(wl, dev, x, ims, steps, current):
+    """Not `value`: the same step with the other convolution math modes, measured in the same process right after the
+    headline run (hipGraph replay, inputs resident): 'fp32' = every convolution on the exact-fp32 MFMA."""
+    out = {}
+    keep = os.environ.get('PPYOLO_HIP_MATH')
+    for mode in ('f16x2', 'bf16x3', 'fp32'):
+        if mode == current:
+            continue
+        os.environ['PPYOLO_HIP_MATH'] = mode
+        try:
+            model, _, _ = build_model(wl['cfg'], dev)
+            ex = model._plans.executor(x)
+            ex.set_inputs(x, ims)
+            for _ in range(5):
+                ex.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ex.run()
+            torch.cuda.synchronize()
+            out[mode] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
+            del ex, model
+        finally:
+            if keep is None:
+                os.environ.pop('PPYOLO_HIP_MATH', None)
+            else:
+                os.environ['PPYOLO_HIP_MATH'] = keep
+    out['unit'] = 'images/s'
+    return out
+
+
 def host_input_leg(ex, x, ims, steps):
     """Not `value`: the same step when the batch is handed over as a HOST buffer (pinned), i.e. with the PCIe copy
     inside the loop -- serialised on the launch stream, and overlapped (copy of batch i+1 on a second stream while
@@ -224,6 +255,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-input', action='store_true', help='skip the PCIe-inclusive side measurement')
+    ap.add_argument('--no-alt-math', action='store_true', help='skip the side measurement of the other math modes')
     ap.add_argument('--autotune', action='store_true', help='re-measure tile configs instead of using the '
                     'committed tuned_gfx950.json table')
     ap.add_argument('--save-tuning', default=None, help='write the measured table to this JSON file')
@@ -341,6 +373,8 @@ def main():
                    roofline=roof)
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
+        if world == 1 and not a.no_alt_math:
+            out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math)
         if world == 1 and not a.no_host_input:
             out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30))
         if world == 1 and not a.no_cpu_baseline:
