@@ -404,3 +404,51 @@ def test_bf16x3_split_is_exact_and_fp32_grade():
     assert all(errs[k] <= 1.25 * errs['fp32'] for k in errs), errs
     with pytest.raises(PPYoloHipError):
         ops.conv2d_bn_act(ops.View(nhwc(x).cuda()), wk, one, zero, ops.View(y), 1, 1, None, cfg=31, splitk=1)
+
+
+@pytest.mark.parametrize('case', ['zeros', 'tiny', 'huge', 'outlier', 'negative_only', 'loose_bound'])
+def test_f16x2_extreme_ranges(case):
+    """The f16x2 kernels scale their input by a power of two derived from the tracked tensor maximum: all-zero,
+    1e-6-sized, 1e6-sized and outlier-dominated tensors, and a maximum that is only a loose upper bound (as for pooled
+    tensors), must all stay at the fp32 kernel's error level against an fp64 reference."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C, K = 1, 20, 20, 128, 96
+    x = torch.randn(N, C, H, W, generator=g).abs() * torch.exp(2 * torch.randn(N, C, H, W, generator=g))
+    amax_mul = 1.0
+    if case == 'zeros':
+        x = torch.zeros_like(x)
+    elif case == 'tiny':
+        x = x * 1e-6
+    elif case == 'huge':
+        x = x * 1e6
+    elif case == 'outlier':
+        x[0, 3, 5, 7] = 3e4
+    elif case == 'negative_only':
+        x = -x
+    elif case == 'loose_bound':
+        amax_mul = 37.0
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.03
+    w[5] *= 1e-5                 # output channels with very different weight magnitudes get their own scale
+    w[6] *= 1e4
+    w[7] = 0.0
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xd = nhwc(x).cuda()
+    one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1) + 1e-300
+    errs = {}
+    for name, cfg in (('fp32', 19), ('f16x2', 44), ('f16x2-b', 41)):
+        y = torch.full((N, H, W, K), 7.0).cuda()
+        ops.conv2d_bn_act(ops.View(xd), wk, one, zero, ops.View(y), 1, 1, None, cfg=cfg, splitk=1,
+                          w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(xd) * amax_mul)
+        torch.cuda.synchronize()
+        got = nchw(y).cpu().double()
+        assert torch.isfinite(got).all(), (case, name)
+        errs[name] = (((got - ref) / mag) ** 2).mean().sqrt().item()
+        if case == 'zeros':
+            assert (got == 0).all()
+        assert (got[:, 7] == 0).all(), 'all-zero weight row'
+    print(case, errs)
+    if case != 'zeros':
+        assert errs['f16x2'] <= 1.5 * errs['fp32'] + 1e-9 and errs['f16x2-b'] <= 1.5 * errs['fp32'] + 1e-9, (case, errs)
