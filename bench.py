@@ -142,6 +142,40 @@ def layer_report(ex, per_op, path):
         json.dump(rows, fh, indent=0)
 
 
+def decode_nms_leg(ex, reps=5):
+    """Secondary rooflines: the decode kernel against HBM bandwidth -- algorithmic bytes = the head outputs
+    read once + boxes written once -- and the Matrix-NMS launches (latency-bound, reported as time)."""
+    from ppyolo_hip import ops as K
+    d = ex.plan.decode
+    heads = [ex.view(a) for a in ex.plan.head_outs]
+    byt = sum(h.N * h.H * h.W * h.C * 4 for h in heads) + ex.boxes.numel() * 4
+    n = d['nms']
+    best_dec, best_nms = None, None
+    for _ in range(reps):
+        ex.cand_count.zero_()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        K.yolo_decode_levels(heads, [lvl['anchors'] for lvl in d['levels']], [lvl['downsample'] for lvl in d['levels']],
+                             d['num_classes'], d['scale_x_y'], d['iou_aware'], d['iou_aware_factor'], d['clip_bbox'],
+                             ex.im_size, ex.boxes, n['score_threshold'], ex.cand_key, ex.cand_idx, ex.cand_count)
+        e1.record()
+        K.matrix_nms(ex.boxes, d['num_classes'], ex.cand_key, ex.cand_idx, ex.cand_count, n['post_threshold'],
+                     n['nms_top_k'], n['keep_top_k'], n['use_gaussian'], n['gaussian_sigma'], ex.out_dets, ex.out_count,
+                     ex.out_keep, ex.nms_ws)
+        e2.record()
+        e2.synchronize()
+        dec, nms = e0.elapsed_time(e1), e1.elapsed_time(e2)
+        best_dec = dec if best_dec is None else min(best_dec, dec)
+        best_nms = nms if best_nms is None else min(best_nms, nms)
+    gbs = byt / (best_dec * 1e-3) / 1e9
+    return dict(decode=dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s', frac=round(gbs / 8000.0, 4),
+                            bytes_per_launch=byt, us_per_launch=round(best_dec * 1e3, 1),
+                            kernel='yolo_decode_multi_kernel (all head levels, one launch)'),
+                matrix_nms=dict(bound='latency', us_per_step=round(best_nms * 1e3, 1),
+                                candidates_per_image=int(ex.cand_count.float().mean().item()),
+                                kernels='nms_select / nms_colmax / nms_decay / nms_finish'))
+
+
 def alt_math_leg(wl, dev, x, ims, steps, current):
     """Not `value`: the same step with the other convolution math modes, measured in the same process right after the
     headline run (hipGraph replay, inputs resident): 'fp32' = every convolution on the exact-fp32 MFMA."""
@@ -371,6 +405,7 @@ def main():
                                                 }.get(ex.math, ''),
                                tile_table='re-measured' if a.autotune else os.path.basename(_tuned_path(ex.math))),
                    roofline=roof)
+        out['roofline_other'] = decode_nms_leg(ex)
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:
