@@ -526,7 +526,25 @@ class HipExecutor(object):
                         self._run_op(op)
                     en.record()
                     en.synchronize()
-                    return st.elapsed_time(en) / n
+                    ms = st.elapsed_time(en) / n
+                    if ms < 0.04:
+                        # a launch this short is hidden behind the ~10-20 us the host needs per ctypes launch: time it
+                        # the way it will run, as nodes of a captured graph
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            for _ in range(16):
+                                self._run_op(op)
+                        g.replay()
+                        st.record()
+                        for _ in range(max(1, n // 4)):
+                            g.replay()
+                        en.record()
+                        en.synchronize()
+                        ms = st.elapsed_time(en) / (16 * max(1, n // 4))
+                        g.reset()
+                        del g
+                    return ms
 
                 cands = []
                 for c in range(ncfg):
@@ -555,10 +573,13 @@ class HipExecutor(object):
         self.graph = None
         return report
 
-    @staticmethod
-    def save_tuning(path):
+    def save_tuning(self, path):
+        """Write the entries THIS executor measured (not the whole loaded table: merging files of several workloads
+        would otherwise let one file's stale copies override another's fresh entries)."""
+        tab = tuned_table(self.math)
+        keys = {tune_key(op) for op in self.plan.ops if op['op'] in ('conv', 'dcn')}
         with open(path, 'w') as fh:
-            json.dump(tuned_table(), fh, indent=0, sort_keys=True)
+            json.dump({k: tab[k] for k in sorted(keys) if k in tab}, fh, indent=0, sort_keys=True)
 
 
 def run_single(unit, x_nchw):

@@ -61,3 +61,17 @@ def model_shapes():
         hd = select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
         return {k: tuple(v.shape) for k, v in PPYOLO(bb, hd).state_dict().items()}
     return _shapes
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _drain_gpu_at_exit():
+    """Captured hipGraphs and their memory pools are released while the HIP runtime is still alive (an interpreter
+    that tears the runtime down first can die in the graphs' destructors)."""
+    yield
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
