@@ -72,16 +72,18 @@ const char *ppy_error_string(int code);
  * w_f16x2 / scale_f16x2: NULL, or the outputs of ppy_conv2d_split_weights_f16x2: the weights times a per-output-
  * channel power of two as two fp16 planes ([2][K][R][S][C], 4*K*R*S*C bytes) and `scale` with the inverse of that
  * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40): 2-term fp16 split of both operands,
- * 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation; the activations are scaled on the fly by the
- * power of two that puts the tensor maximum into [2^13, 2^14), read from `amax_in`.  Error vs fp64 at the level of
+ * 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation; the activations of an image are scaled on the
+ * fly by the power of two that puts that image's maximum into [2^13, 2^14), read from `amax_in`.  Error vs fp64 at the level of
  * the exact-fp32 fma chain (tools/probes/f16x2_probe.hip, profiles/r01_f16x2_numerics.txt).  Needs amax_in, and with a
  * posbias also posbias_f16x2 = posbias[., k] * scale[k] / scale_f16x2[k] (the bias map in the scaled-weight domain),
  * else PPY_ERR_BAD_ARG.
- * amax_in / amax_out: NULL, or PPY_AMAX_FLOATS floats each: the running max|.| of the input tensor (an upper bound is
- * enough) and the slots into which this launch merges max|y| of what it stores (atomic max; the owner zeroes the
- * slots before the first producer of a tensor runs).  A consumer takes the maximum over all PPY_AMAX_FLOATS values.
+ * amax_in / amax_out: NULL, or N * PPY_AMAX_FLOATS_PER_IMAGE floats each: the running PER-IMAGE max|.| of the input
+ * tensor (an upper bound is enough) and the slots into which this launch merges the per-image max|y| of what it stores
+ * (atomic max; the owner zeroes the slots before the first producer of a tensor runs).  Image n owns 8 slots, one
+ * 64-byte line apart: floats [(n*8 + s)*16], s = 0..7; a consumer takes the maximum over the 8 slots of an image.
+ * Per-image scales keep every image's result independent of the rest of the batch.
  */
-#define PPY_AMAX_FLOATS 1024 /* 64 slots, one 64-byte line apart */
+#define PPY_AMAX_FLOATS_PER_IMAGE 128 /* 8 slots x 16 floats */
 int ppy_conv2d_split_weights_bf16x3(const float *w_krsc, long long n_elems, void *out_planes,
                                     void *stream);
 int ppy_conv2d_split_weights_f16x2(const float *w_krsc, int K, long long kred, const float *scale,
@@ -106,7 +108,7 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  * x: [N,3,H,W] NCHW contiguous.  w: [K][3][3][3] in the reference's own KCRS order. */
 int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
                                 const float *shift, float *y, int y_ld, int N, int H, int W,
-                                int K, int act, float *amax_out /* NULL or PPY_AMAX_FLOATS slots */, void *stream);
+                                int K, int act, float *amax_out /* NULL or N * PPY_AMAX_FLOATS_PER_IMAGE floats */, void *stream);
 
 /* torch.nn.MaxPool2d(3, 2, 1) of the stem (reference model/resnet_vd.py:103, :136). */
 int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W,

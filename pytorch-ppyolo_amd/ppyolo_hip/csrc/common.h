@@ -29,15 +29,45 @@ __device__ __forceinline__ float ppy_apply_act(float v, int act) {
     return v;
 }
 
-// Producer-side tracking of max|y| of a tensor (the f16x2 kernels scale their input by a power of two derived from it).
-// To keep thousands of waves off one address the maximum lives in AMAX_SLOTS slots, AMAX_STRIDE floats apart (one
-// 64-byte line each); a consumer takes the maximum over the slots.  Values are non-negative, so the unsigned image
-// of the float orders like the float.  The owner zeroes the slots before the producers run.
-static constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 16;
-static __device__ __forceinline__ void amax_track(float mx, float *amax, int slot) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f)
-        atomicMax(reinterpret_cast<unsigned *>(amax) + (slot & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(mx));
+// Producer-side tracking of max|y| PER IMAGE of a tensor (the f16x2 kernels scale the rows of an image by a power of
+// two derived from it, so a result never depends on the other images of the batch).  To keep thousands of waves off
+// one address every image owns AMAX_SLOTS slots, AMAX_STRIDE floats apart (one 64-byte line each); a consumer takes
+// the maximum over the slots of the image.  Values are non-negative, so the unsigned image of the float orders like
+// the float.  The owner zeroes all slots before the producers run.  Layout: amax[(n * AMAX_SLOTS + slot) * AMAX_STRIDE].
+static constexpr int AMAX_SLOTS = 8, AMAX_STRIDE = 16;
+static __device__ __forceinline__ void amax_store(float mx, float *amax, int n, int slot) {
+    if (mx > 0.0f)
+        atomicMax(reinterpret_cast<unsigned *>(amax) + ((long long)n * AMAX_SLOTS + (slot & (AMAX_SLOTS - 1))) * AMAX_STRIDE,
+                  __float_as_uint(mx));
 }
-
+// All 64 lanes must call.  One atomic per wave when the wave's values belong to one image, else one per lane.
+static __device__ __forceinline__ void amax_track(float mx, int n, float *amax, int slot) {
+    const int n0 = __builtin_amdgcn_readfirstlane(n);
+    if (__ballot(n != n0) == 0ull) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) amax_store(mx, amax, n0, slot);
+    } else {
+        amax_store(mx, amax, n, slot + (int)(threadIdx.x & 63));
+    }
+}
+// A wave whose rows span images n_lo..n_hi (wave-uniform): `lo` = max over the rows of image n_lo, `hi` = max over all
+// later rows.  Two images (the case for feature maps of >= 64 pixels): exact per image; more (tiny maps): `hi` is
+// merged into every later image, an upper bound.
+static __device__ __forceinline__ void amax_track2(float lo, float hi, int n_lo, int n_hi, float *amax, int slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmaxf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        amax_store(lo, amax, n_lo, slot);
+        for (int n = n_lo + 1; n <= n_hi; ++n) amax_store(hi, amax, n, slot);
+    }
+}
+static __device__ __forceinline__ float amax_read(const float *amax, int n) {     // max over the slots of image n
+    float mx = 0.0f;
+#pragma unroll
+    for (int s = 0; s < AMAX_SLOTS; ++s) mx = fmaxf(mx, fabsf(amax[((long long)n * AMAX_SLOTS + s) * AMAX_STRIDE]));
+    return mx;
+}

@@ -9,8 +9,8 @@ struct ConvArgs {
     const unsigned short *wf16;  // weights * per-channel power of two as 2 fp16 planes [2][K][R][S][C], or NULL
     const float *scale_f16;      // `scale` with the inverse weight scale folded in (f16x2 kernels)
     const float *posb_f16;       // posb times the per-channel weight scale (f16x2 kernels), or NULL
-    const float *amax_in;        // tracked max|x| of the input tensor (AMAX_SLOTS slots), or NULL
-    float *amax_out;             // where this launch records max|y| (AMAX_SLOTS slots), or NULL
+    const float *amax_in;        // tracked per-image max|x| of the input tensor (N * AMAX_SLOTS slots), or NULL
+    float *amax_out;             // where this launch records per-image max|y| (N * AMAX_SLOTS slots), or NULL
     float *y, *part;
     int x_ld, res_ld, y_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
@@ -58,7 +58,10 @@ __device__ __forceinline__ float epilogue_store(const ConvArgs &p, int m, int co
 // transpose patch).
 template <int TM, int TN, int WM, int WN, bool SPLIT, bool VEC>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)[TM][TN], float *smem, int m0,
-                                              int n0, int wm, int wn, int lane, int wave, int split) {
+                                              int n0, int wm, int wn, int lane, int wave, int split,
+                                              const float (*rowscale)[4] = nullptr) {
+    // rowscale (vector path only): factor for the rows (lane>>3) + 8t of tile i that this lane finishes -- the f16x2
+    // kernels undo their per-image activation scale here, after the transposition, instead of on the accumulators
     const int hw = p.Ho * p.Wo;
     if constexpr (VEC) {
         // ---- vector epilogue: each 32x32 accumulator tile goes through a wave-private LDS
@@ -68,7 +71,13 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
         // The main loop ended with a barrier, so nobody reads the operand tiles any more.
         float *sE = smem + wave * (32 * LDS_LD);
         const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-        float amx = 0.0f;            // max|y| of what this lane stores (p.amax_out)
+        // max|y| per image of what this wave stores (p.amax_out), branch-free inside the store loop (an atomic behind a
+        // branch there cost +70 % on the 1x1 expand layers: it fences the batched stores): rows before / from `bnd`, the
+        // first row of the next image, go to two running maxima that are merged once at the end.
+        const int mw0 = min(m0 + wm * WM, p.M - 1), mw1 = min(m0 + wm * WM + WM - 1, p.M - 1);
+        const int n_lo = mw0 / hw, n_hi = mw1 / hw;
+        const int bnd = (n_lo + 1) * hw;
+        float amx = 0.0f, amx_hi = 0.0f;
         // All residual loads of the wave's sub-tile are issued up front (4*TM*TN x 16 B per lane): the 1x1
         // "expand" layers are bound by this read and the store below, and four loads in flight per wave
         // (one 32x32 tile at a time) left HBM at ~2.6 TB/s on them.
@@ -109,6 +118,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                 for (int t = 0; t < 4; ++t) {
                     const int m = mbase + 8 * t;
                     floatx4 v = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * t) * LDS_LD + ec4);
+                    if (rowscale) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] *= rowscale[i][t];
+                    }
                     if (colok && m < p.M) {
                         if (SPLIT) {
                             *reinterpret_cast<floatx4 *>(p.part + ((long long)split * p.M + m) * p.K + col) = v;
@@ -123,7 +136,11 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                                 float o = fmaf(v[u], sc[u], sh[u]);
                                 if (p.res) o += rv[i][j][t][u];
                                 v[u] = ppy_apply_act(o, p.act);
-                                amx = fmaxf(amx, fabsf(v[u]));
+                            }
+                            {
+                                const float rmx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                                amx = fmaxf(amx, m < bnd ? rmx : 0.0f);
+                                amx_hi = fmaxf(amx_hi, m < bnd ? 0.0f : rmx);
                             }
                             if (!p.ups) {
                                 *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
@@ -143,10 +160,13 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!SPLIT && p.amax_out) amax_track(amx, p.amax_out, blockIdx.x * 8 + wave);
+        if (!SPLIT && p.amax_out) amax_track2(amx, amx_hi, n_lo, n_hi, p.amax_out, blockIdx.x * 8 + wave);
         return;
     }
-    float amx = 0.0f;
+    float amx = 0.0f, amx_hi = 0.0f;
+    const int mw0 = min(m0 + wm * WM, p.M - 1), mw1 = min(m0 + wm * WM + WM - 1, p.M - 1);
+    const int n_lo = mw0 / hw, n_hi = mw1 / hw;
+    const int bnd = (n_lo + 1) * hw;
     // ---- scalar epilogue: lane l holds channel (l&31) of 16 pixels per 32x32 tile ----
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -167,12 +187,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                     if (SPLIT)
                         p.part[((long long)split * p.M + m) * p.K + col] = acc[i][j][e];
                     else
-                        amx = fmaxf(amx, fabsf(epilogue_store(p, m, col, acc[i][j][e], sc, sh)));
+                    {
+                        const float a = fabsf(epilogue_store(p, m, col, acc[i][j][e], sc, sh));
+                        amx = fmaxf(amx, m < bnd ? a : 0.0f);
+                        amx_hi = fmaxf(amx_hi, m < bnd ? 0.0f : a);
+                    }
                 }
             }
         }
     }
-    if (!SPLIT && p.amax_out) amax_track(amx, p.amax_out, blockIdx.x * 8 + wave);
+    if (!SPLIT && p.amax_out) amax_track2(amx, amx_hi, n_lo, n_hi, p.amax_out, blockIdx.x * 8 + wave);
 }
 
 template <int N>
@@ -229,18 +253,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
         amx = fabsf(epilogue_store(p, m, col, v, p.scale[col], p.shift[col]));
     }
     }
-    if (p.amax_out) {      // one atomic per workgroup
-        __shared__ float s_amx[4];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
-        if ((threadIdx.x & 63) == 0) s_amx[threadIdx.x >> 6] = amx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float mx = fmaxf(fmaxf(s_amx[0], s_amx[1]), fmaxf(s_amx[2], s_amx[3]));
-            if (mx > 0.0f)
-                atomicMax(reinterpret_cast<unsigned *>(p.amax_out) + (blockIdx.x & (AMAX_SLOTS - 1)) * AMAX_STRIDE,
-                          __float_as_uint(mx));
-        }
+    if (p.amax_out) {
+        const long long ic = i < total ? i : total - 1;
+        amax_track(amx, (int)(ic / p.K) / (p.Ho * p.Wo), p.amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
     }
 }
 

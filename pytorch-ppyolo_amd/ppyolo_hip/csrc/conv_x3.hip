@@ -12,8 +12,8 @@
 //     products are <= 2^-24 |a*b| each.  No scaling, no range question.  MFMA ceiling 2516.8 / 6 = 419.5 TFLOP/s.
 //   f16x2 (F16 = true): both operands are first scaled by a power of two into the fp16 range -- weights per output
 //     channel at plan time (ppy_conv2d_split_weights_f16x2, 1/s folded into the epilogue scale), activations per
-//     tensor at run time from the maximum their producers track (amax_track / ConvArgs::amax_in, 64 atomic-max
-//     slots) -- and split into TWO fp16 terms  a*s = a0 + a1  (RNE; the residual fma(a, s, -a0) is exact); a*b is
+//     image at run time from the maximum their producers track (amax_track / ConvArgs::amax_in, 8 atomic-max
+//     slots per image) -- and split into TWO fp16 terms  a*s = a0 + a1  (RNE; the residual fma(a, s, -a0) is exact); a*b is
 //     the three leading products  a1*b0 + a0*b1 + a0*b0  on v_mfma_f32_32x32x16_f16.  Representation error <= 2^-22
 //     per operand, unbiased, so it averages out over the reduction.  MFMA ceiling 2516.8 / 3 = 839 TFLOP/s.
 //   Measured on MI355X against fp64 (tools/probes/f16x2_probe.hip, bf16x_probe.hip -> profiles/r01_*_numerics.txt):
@@ -247,20 +247,12 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
 
-    // f16x2: activation scale = the power of two that puts the input tensor's maximum (tracked by its producers:
-    // 64 slots of p.amax_in, see amax_track in conv_shared.h) into [2^13, 2^14); both scales are exact.
-    float sa = 1.0f, inv_sa = 1.0f;
-    if constexpr (F16) {
-        float mx = fabsf(p.amax_in[lane * AMAX_STRIDE]);
+    // f16x2: activation scale PER IMAGE = the power of two that puts the image's maximum (tracked by its producers,
+    // amax_track in common.h) into [2^13, 2^14); a lane keeps the scale of the image of each of its TM tile rows.
+    // Both scales are exact powers of two.
+    float sa[TM], inv_sa[TM];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
-        int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
-        f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite
-        f = __builtin_amdgcn_readfirstlane(f);                         // wave-uniform -> scalar registers
-        sa = __uint_as_float((unsigned)f << 23);
-        inv_sa = __uint_as_float((unsigned)(254 - f) << 23);
-    }
+    for (int i = 0; i < TM; ++i) sa[i] = inv_sa[i] = 1.0f;
 
     // One "k-step" = 16 reduction elements = one MFMA depth; a 32-deep chunk is two k-steps.
     // The wave is software-pipelined over k-steps BY HAND: the instruction stream of a step is a
@@ -336,11 +328,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                         const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
                         if constexpr (F16) {
                             if (st == 0) {
-                                nxt.a[i][0][q] = cvt_pk_f16(xa * sa, xb * sa);
+                                nxt.a[i][0][q] = cvt_pk_f16(xa * sa[i], xb * sa[i]);
                             } else if (st == 1) {     // residual of the SCALED value: fma(x, sa, -a0) is exact
                                 const unsigned P = nxt.a[i][0][q];
-                                ra[i][q] = fmaf(xa, sa, -f16_lo(P));
-                                rb[i][q] = fmaf(xb, sa, -f16_hi(P));
+                                ra[i][q] = fmaf(xa, sa[i], -f16_lo(P));
+                                rb[i][q] = fmaf(xb, sa[i], -f16_hi(P));
                             } else {
                                 nxt.a[i][1][q] = cvt_pk_f16(ra[i][q], rb[i][q]);
                             }
@@ -378,8 +370,20 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     if (nchunks > 0) {
         Frag f0, f1;
         issue(0);
+        if (nchunks > 1) issue(1);
+        if constexpr (F16) {       // after the first DMA requests, so that this latency (a division, 8 loads) hides behind theirs
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mrow = min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1);
+                const float mx = amax_read(p.amax_in, mrow / hw);
+                const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
+                int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
+                f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite
+                sa[i] = __uint_as_float((unsigned)f << 23);
+                inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
+            }
+        }
         if (nchunks > 1) {
-            issue(1);
             wait_vmcnt<G>();
         } else {
             wait_vmcnt<0>();
@@ -396,9 +400,9 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float xa = q < 2 ? lo[2 * q] : hi[2 * q - 4], xb = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
-                        const unsigned P0 = cvt_pk_f16(xa * sa, xb * sa);
+                        const unsigned P0 = cvt_pk_f16(xa * sa[i], xb * sa[i]);
                         f0.a[i][0][q] = P0;
-                        f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sa, -f16_lo(P0)), fmaf(xb, sa, -f16_hi(P0)));
+                        f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sa[i], -f16_lo(P0)), fmaf(xb, sa[i], -f16_hi(P0)));
                     }
                 } else {
                     bf16x8 t3[3];
@@ -434,15 +438,29 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         __builtin_amdgcn_s_barrier();
     }
     if (p.trace) c_epi = __builtin_amdgcn_s_memtime();
-    if constexpr (F16) {       // back to the unscaled sum (the weight scale is folded into p.scale by the caller)
+    // back to the unscaled sum (the weight scale is folded into p.scale by the caller): the inverse scale of tile row r
+    // sits in lane r.  Vector epilogue: applied after the transposition to the 4 rows per tile a lane finishes;
+    // scalar epilogue (K % 4 != 0, rare): applied to the accumulators, element e = row (e&3) + 8(e>>2) + 4(lane>>5).
+    float rowscale[TM][4];
+    if constexpr (F16) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int t = 0; t < 4; ++t) rowscale[i][t] = __shfl(inv_sa[i], (lane >> 3) + 8 * t);
+        } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_sa;
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float inv = __shfl(inv_sa[i], (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][e] *= inv;
+                }
+        }
     }
-    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split);
+    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
+                                              (F16 && VEC) ? rowscale : nullptr);
     if (p.trace && tid == 0) {     // debug timeline (ppy_debug_set_trace): wall-clock span + shader-clock phases
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float *__restrict_
         *reinterpret_cast<floatx4 *>(o + kk) = r4;
     }
     }
-    if (amax_out) amax_track(amx, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));      // tracked max|y| (f16x2 consumers)
+    if (amax_out) {      // tracked per-image max|y| (f16x2 consumers)
+        const long long pc = pix < total ? pix : total - 1;
+        amax_track(amx, (int)(pc / ((long long)Wo * Ho)), amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -296,7 +296,7 @@ class HipExecutor(object):
                     op['posb_f16'] = (self.bufs[op['posb'].buf] * s_w).contiguous()
 
     def _assign_amax(self):
-        """Tracked tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
+        """Tracked per-image tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
         output buffer; pooled tensors inherit the slots of their input (max- and average-pooling never exceed it; SPP
         writes into its own input buffer; the DCN columns are bounded by the DCN input); the stem kernel tracks its
         output as well."""
@@ -317,10 +317,11 @@ class HipExecutor(object):
                 amax_of[op['y'].buf] = nblocks
                 op['amax_out_id'] = nblocks
                 nblocks += 1
-        self.amax = torch.zeros(max(1, nblocks) * K.AMAX_FLOATS, dtype=torch.float32, device=self.device)
+        self._amax_block = self.plan.N * K.AMAX_FLOATS_PER_IMAGE
+        self.amax = torch.zeros(max(1, nblocks) * self._amax_block, dtype=torch.float32, device=self.device)
 
     def _amax(self, idx):
-        return None if idx is None else self.amax[idx * K.AMAX_FLOATS:(idx + 1) * K.AMAX_FLOATS]
+        return None if idx is None else self.amax[idx * self._amax_block:(idx + 1) * self._amax_block]
 
     # ---- helpers ---------------------------------------------------------------------------
     def _to_device(self, oplist):

@@ -91,7 +91,7 @@ def split_weights_bf16x3(w_krsc):
     return out
 
 
-AMAX_FLOATS = 1024      # PPY_AMAX_FLOATS: slots of a tracked tensor maximum
+AMAX_FLOATS_PER_IMAGE = 128      # PPY_AMAX_FLOATS_PER_IMAGE: 8 slots x 16 floats of a tracked per-image maximum
 
 
 def split_weights_f16x2(w_krsc, scale):
@@ -107,11 +107,13 @@ def split_weights_f16x2(w_krsc, scale):
     return planes, sc
 
 
-def amax_slots(t=None, device=None):
-    """A zeroed block of tracked-maximum slots; with a tensor, pre-filled with its max|.| (tests / stand-alone calls)."""
-    a = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=device if t is None else t.device)
+def amax_slots(t=None, device=None, N=None):
+    """A zeroed block of tracked per-image maximum slots for N images; with an NHWC tensor, pre-filled with each image's
+    max|.| (tests / stand-alone calls)."""
+    N = t.shape[0] if t is not None else N
+    a = torch.zeros(N * AMAX_FLOATS_PER_IMAGE, dtype=torch.float32, device=device if t is None else t.device)
     if t is not None:
-        a[0] = t.abs().max()
+        a.view(N, AMAX_FLOATS_PER_IMAGE)[:, 0] = t.reshape(N, -1).abs().amax(dim=1)
     return a
 
 

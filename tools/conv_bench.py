@@ -27,12 +27,13 @@ def main():
     w3 = ops.split_weights_bf16x3(w)
     wf = ops.split_weights_f16x2(w, sc)
     amax = ops.amax_slots(x)
+    amax_out = ops.amax_slots(device='cuda', N=N) if os.environ.get('PPY_BENCH_TRACK', '1') == '1' else None
     flops = 2.0 * N * Ho * Wo * K * R * R * C
     for cfg in cfgs:
         def run():
             ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu',
                               residual=None if res is None else ops.View(res), cfg=cfg, splitk=splitk, ws=ws,
-                              w_x3=w3, w_f16=wf, amax_in=amax)
+                              w_x3=w3, w_f16=wf, amax_in=amax, amax_out=amax_out)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
