@@ -12,6 +12,15 @@ for p in (ROOT, PKG):
 
 
 def pytest_configure(config):
+    # a native crash (GPU memory fault -> abort) leaves its Python stack in gpurun_out/ instead of vanishing
+    try:
+        import faulthandler
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        config._ppy_fault_log = open(os.path.join(d, 'pytest_fault.log'), 'w')
+        faulthandler.enable(file=config._ppy_fault_log, all_threads=True)
+    except Exception:
+        pass
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
 
 
