@@ -280,9 +280,10 @@ class HipExecutor(object):
         self.ws = None
         self.ws_side = None
         self._size_workspace()
-        # measured on MI355X: running the independent branches on a second stream is neutral-to-slightly
-        # negative (R50-608 bs8: 923 vs 932 img/s), so it is opt-in (PPYOLO_HIP_STREAMS=2)
-        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' and any(
+        # independent branches (projection shortcut, head tip / output convs) on a second stream: neutral while the
+        # convolutions were long (fp32 MFMA era: 923 vs 932 img/s), +3 % now that a kernel boundary (~5 us in the replayed
+        # graph) is a visible fraction of a layer (R50-608 bs8: 1481 -> 1526 img/s).  PPYOLO_HIP_STREAMS=1 disables it.
+        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '2') == '2' and any(
             op.get('stream', 0) for op in p.ops)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.multi_stream else None
         self._build_sync_plan()
