@@ -283,7 +283,9 @@ class HipExecutor(object):
         # independent branches (projection shortcut, head tip / output convs) on a second stream: neutral while the
         # convolutions were long (fp32 MFMA era: 923 vs 932 img/s), +3 % now that a kernel boundary (~5 us in the replayed
         # graph) is a visible fraction of a layer (R50-608 bs8: 1481 -> 1526 img/s).  PPYOLO_HIP_STREAMS=1 disables it.
-        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '2') == '2' and any(
+        # (small batches are latency-bound and lose on the fork/join: r18vd-320 bs 1 0.483 -> 0.528 ms, so the default is
+        # two streams from batch 4 on)
+        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '2' if p.N >= 4 else '1') == '2' and any(
             op.get('stream', 0) for op in p.ops)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.multi_stream else None
         self._build_sync_plan()
