@@ -176,7 +176,7 @@ def decode_nms_leg(ex, reps=5):
                                 kernels='nms_select / nms_colmax / nms_decay / nms_finish'))
 
 
-def alt_math_leg(wl, dev, x, ims, steps, current):
+def alt_math_leg(wl, dev, x, ims, steps, current, depth=1):
     """Not `value`: the same step with the other convolution math modes, measured in the same process right after the
     headline run (hipGraph replay, inputs resident): 'fp32' = every convolution on the exact-fp32 MFMA."""
     out = {}
@@ -187,17 +187,21 @@ def alt_math_leg(wl, dev, x, ims, steps, current):
         os.environ['PPYOLO_HIP_MATH'] = mode
         try:
             model, _, _ = build_model(wl['cfg'], dev)
-            ex = model._plans.executor(x)
-            ex.set_inputs(x, ims)
-            for _ in range(5):
-                ex.run()
-            torch.cuda.synchronize()
+            lanes = model.in_flight(depth).lanes(x)
+            for e, _ in lanes:
+                e.set_inputs(x, ims)
+
+            def go(n):
+                for i in range(n):
+                    e, st = lanes[i % depth]
+                    with torch.cuda.stream(st):
+                        e.run()
+                torch.cuda.synchronize()
+            go(3 * depth)
             t0 = time.perf_counter()
-            for _ in range(steps):
-                ex.run()
-            torch.cuda.synchronize()
+            go(steps)
             out[mode] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
-            del ex, model
+            del lanes, model
         finally:
             if keep is None:
                 os.environ.pop('PPYOLO_HIP_MATH', None)
@@ -287,6 +291,8 @@ def main():
     ap.add_argument('--workload', default='r50vd_608', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--in-flight', type=int, default=2, help='batches kept on the device at once (runtime.InFlight: one '
+                    'executor + hipGraph + stream per lane, steps go round-robin over the lanes); 1 = one batch at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-input', action='store_true', help='skip the PCIe-inclusive side measurement')
     ap.add_argument('--no-alt-math', action='store_true', help='skip the side measurement of the other math modes')
@@ -320,24 +326,39 @@ def main():
     from ppyolo_hip import synth
     x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank).to(dev)
     ims = synth.synth_im_size(a.batch).to(dev)
-    ex = model._plans.executor(x)
-    ex.set_inputs(x, ims)                   # inputs resident in HBM before the timed region
-    ex.use_graph = False
-    ex.run()
+    depth = max(1, a.in_flight)
+    lanes = model.in_flight(depth).lanes(x)            # [(executor, stream)]; depth 1 = the plain forward's executor
+    ex = lanes[0][0]
+    for k, (e, _) in enumerate(lanes):
+        # inputs resident in HBM before the timed region (every lane holds its own batch)
+        e.set_inputs(x if k == 0 else synth.synth_images(a.batch, wl['size'], seed=1234 + rank + 100 * k).to(dev), ims)
+        e.use_graph = False
+        e.run()
     torch.cuda.synchronize()
     if a.autotune:
         ex.autotune(iters=5)
         if a.save_tuning and rank == 0:
             ex.save_tuning(a.save_tuning)
-    ex.use_graph = not a.no_graph
-    gat = pd.DetectionGatherer(a.batch, ex.out_dets.shape[1], dev, world)
+        for e, _ in lanes[1:]:
+            for op, src in zip(e.plan.ops, ex.plan.ops):
+                if 'cfg' in src:
+                    op['cfg'], op['splitk'] = src['cfg'], src['splitk']
+            e._size_workspace()
+    gats = [pd.DetectionGatherer(a.batch, ex.out_dets.shape[1], dev, world) for _ in lanes]
+    for e, _ in lanes:
+        e.use_graph = not a.no_graph
+    it = [0]
 
     def step():
-        ex.run()
-        if world > 1:
-            gat.gather(ex.out_dets, ex.out_count)
+        k = it[0] % depth
+        it[0] += 1
+        e, st = lanes[k]
+        with torch.cuda.stream(st):
+            e.run()
+            if world > 1:
+                gats[k].gather(e.out_dets, e.out_count)
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, depth)):
         step()
 
     def barrier():
@@ -358,6 +379,15 @@ def main():
 
     ms_per_step = dt / a.steps * 1e3
     value = world * a.batch * a.steps / dt
+    one_at_a_time = None
+    if depth > 1 and world == 1:              # not `value`: the same steps with one batch on the device at a time
+        torch.cuda.synchronize()
+        with torch.cuda.stream(lanes[0][1]):
+            t1 = time.perf_counter()
+            for _ in range(min(a.steps, 30)):
+                ex.run()
+        torch.cuda.synchronize()
+        one_at_a_time = round(a.batch * min(a.steps, 30) / (time.perf_counter() - t1), 1)
 
     if rank == 0:
         total_flops, per_op = conv_flops(ex.plan)
@@ -397,6 +427,9 @@ def main():
                                         % (wl['model'], wl['size'], wl['size'], a.batch),
                                global_batch=world * a.batch, parallelism='batch-sharded x%d, all-gather of detections'
                                % world if world > 1 else 'single GPU', hip_graph=not a.no_graph,
+                               in_flight='%d batches of %d on the device at once (one executor, hipGraph and stream per lane; '
+                                         'a step = one batch through the whole path; every step is computed in full)'
+                                         % (depth, a.batch) if depth > 1 else '1 (one batch at a time)',
                                math=ex.math + {'f16x2': ' (fp32 in/out, fp32 accumulate; operands scaled by powers of two and split into 2 '
                                                          'fp16 terms, 3 partial products; error vs fp64 <= the fp32 fma chain, '
                                                          'tests/test_gpu_ops.py, tests/test_gpu_model.py::test_fp64_three_way)',
@@ -405,11 +438,15 @@ def main():
                                                 }.get(ex.math, ''),
                                tile_table='re-measured' if a.autotune else os.path.basename(_tuned_path(ex.math))),
                    roofline=roof)
+        if one_at_a_time is not None:
+            out['one_batch_at_a_time'] = dict(value=one_at_a_time, unit='images/s',
+                                              note='same lane-0 graph replayed alone, i.e. --in-flight 1 without the second '
+                                                   'stream of its forked graph')
         out['roofline_other'] = decode_nms_leg(ex)
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:
-            out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math)
+            out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math, depth)
         if world == 1 and not a.no_host_input:
             out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30))
         if world == 1 and not a.no_cpu_baseline:

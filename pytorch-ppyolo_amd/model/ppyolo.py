@@ -7,7 +7,7 @@ torch tensors are storage only.  There is no CPU fallback: CPU inputs raise.
 """
 import torch
 
-from ppyolo_hip.runtime import PlanCache
+from ppyolo_hip.runtime import InFlight, PlanCache
 
 
 class PPYOLO(torch.nn.Module):
@@ -33,6 +33,11 @@ class PPYOLO(torch.nn.Module):
         ex.set_inputs(x, im_size)
         ex.run()
         return ex.out_dets, ex.out_count, ex.out_keep
+
+    def in_flight(self, depth=2):
+        """Throughput mode (not in the reference): a submit/collect pipeline that keeps `depth` batches on the device
+        at once -- see ppyolo_hip.runtime.InFlight."""
+        return InFlight(self, depth)
 
     # any change of parameters / device invalidates the folded weights held by the plans
     def load_state_dict(self, *a, **k):

@@ -9,7 +9,7 @@ import os
 from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libppyolo_hip.so')
+LIB_PATH = os.environ.get('PPYOLO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libppyolo_hip.so')     # (override: experiments)
 
 OK = 0
 ACT = {None: 0, 'relu': 1, 'leaky': 2}

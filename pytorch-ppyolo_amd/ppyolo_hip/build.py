@@ -16,7 +16,18 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libppyolo_hip.so')
 SOURCES = ['capi.hip', 'conv_igemm.hip', 'conv_x3.hip', 'stem_pool.hip', 'dcn.hip', 'decode_nms.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-function']
+# No packed-fp32 VALU ops (v_pk_add/mul/fma_f32) in any kernel of this library.  Measured on MI355X (ROCm 7.2): while
+# waves of the 16-bit-MFMA convolution kernels are resident on a CU, v_pk_*_f32 instructions of ANOTHER kernel's waves on
+# that CU (two batches in flight on two streams) intermittently return a wrong HIGH half for one 16-lane pass -- the
+# decode kernel's y0/y1 came out as the box centre in 4-40 % of the steps, bit-exactly reproducible with
+# tools/pk_hazard_probe.py, never with one stream, never with the scalar forms (0 mismatches in tools/lane_soak.py).
+# The scalar forms are also not slower here (R50-608 bs8, two lanes: 1826 vs 1790 img/s).  tests/test_build.py checks
+# the built code objects.
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+if os.environ.get('PPY_ALLOW_PACKED_FP32', '0') != '1':          # (the probe's reproducer builds with packed ops)
+    FLAGS += NO_PACKED_FP32
 FLAGS += os.environ.get('PPY_EXTRA_HIPCC_FLAGS', '').split()      # experiments (-D...): part of the build stamp
+_HOST_PASS_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"      # the x86 pass of hipcc
 
 
 def _digest():
@@ -30,11 +41,11 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, out=None):
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = LIB + '.sha256'
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if out is None and not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = os.path.join(LIBDIR, 'obj')
@@ -46,17 +57,39 @@ def build(force=False, verbose=True):
         cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+        jobs.append((cmd, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, universal_newlines=True)))
     for cmd, obj, proc in jobs:
-        if proc.wait() != 0:
+        err = proc.communicate()[1]
+        err = ''.join(ln for ln in err.splitlines(True) if _HOST_PASS_NOISE not in ln)
+        if err.strip():
+            sys.stderr.write(err)
+        if proc.returncode != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[1] for j in jobs] + ['-o', LIB]
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[1] for j in jobs] + ['-o', out or LIB]
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.check_call(link)
+    if out is not None:          # a variant for an experiment: the stamp keeps describing the product library
+        return out
     with open(stamp, 'w') as fh:
         fh.write(dig)
     return LIB
+
+
+def packed_fp32_ops(obj):
+    """Number of v_pk_{add,mul,fma}_f32 instructions in the gfx950 code object bundled in `obj` (a .o of this build)."""
+    import re
+    import tempfile
+    llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+    with tempfile.TemporaryDirectory() as td:
+        fb, co = os.path.join(td, 'fb.bin'), os.path.join(td, 'dev.co')
+        subprocess.check_call([os.path.join(llvm, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', obj, fb])
+        if os.path.getsize(fb) == 0:         # a translation unit without device code (capi.hip)
+            return 0
+        subprocess.check_call([os.path.join(llvm, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fb,
+                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+        dis = subprocess.check_output([os.path.join(llvm, 'llvm-objdump'), '-d', co], universal_newlines=True)
+    return len(re.findall(r'\bv_pk_(?:add|mul|fma)_f32\b', dis))
 
 
 if __name__ == '__main__':

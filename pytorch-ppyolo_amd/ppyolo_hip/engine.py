@@ -230,13 +230,14 @@ class Builder(object):
 class HipExecutor(object):
     """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
 
-    def __init__(self, plan, device, use_graph=True):
+    def __init__(self, plan, device, use_graph=True, multi_stream=None):
         if torch.device(device).type != 'cuda':
             raise PPYoloHipError('the HIP executor needs a ROCm device (got %s); there is no CPU path' % device)
         self.plan = plan
         self.device = torch.device(device)
         self.use_graph = use_graph
         self.graph = None
+        self._graph_stream = None
         p = plan
         self.bufs = []
         for i, (N, H, W, ld) in enumerate(p.buffers):
@@ -280,13 +281,13 @@ class HipExecutor(object):
         self.ws = None
         self.ws_side = None
         self._size_workspace()
-        # independent branches (projection shortcut, head tip / output convs) on a second stream: neutral while the
-        # convolutions were long (fp32 MFMA era: 923 vs 932 img/s), +3 % now that a kernel boundary (~5 us in the replayed
-        # graph) is a visible fraction of a layer (R50-608 bs8: 1481 -> 1526 img/s).  PPYOLO_HIP_STREAMS=1 disables it.
-        # (small batches are latency-bound and lose on the fork/join: r18vd-320 bs 1 0.483 -> 0.528 ms, so the default is
-        # two streams from batch 4 on)
-        self.multi_stream = os.environ.get('PPYOLO_HIP_STREAMS', '2' if p.N >= 4 else '1') == '2' and any(
-            op.get('stream', 0) for op in p.ops)
+        # Independent branches (projection shortcut, head tip / output convs) on a second stream: OPT-IN
+        # (PPYOLO_HIP_STREAMS=2).  A forked graph gains 3 % for one batch at a time (R50-608 bs8 1481 -> 1526 img/s; small
+        # batches lose on the fork/join), but keeping two batches in flight on two single-branch graphs (runtime.InFlight)
+        # gains 24 % where two forked ones gain 3 %, and a forked hipGraph replayed under another stream than its first
+        # has crashed the ROCm 7.2 runtime -- so the default is one branch, and a forked graph refuses a stream change.
+        want = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' if multi_stream is None else bool(multi_stream)
+        self.multi_stream = want and any(op.get('stream', 0) for op in p.ops)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.multi_stream else None
         self._build_sync_plan()
         with torch.cuda.device(self.device):
@@ -480,6 +481,10 @@ class HipExecutor(object):
             if not self.use_graph:
                 self._launch_all()
                 return
+            cur = torch.cuda.current_stream()
+            if self.graph is not None and self.multi_stream and cur != self._graph_stream:
+                raise PPYoloHipError('PPYOLO_HIP_STREAMS=2: this forked hipGraph was first replayed on another stream; '
+                                     'replaying it here has crashed the ROCm runtime -- stay on one stream, or drop the option')
             if self.graph is None:
                 self._launch_all()                      # warm-up: module load, func attributes
                 torch.cuda.synchronize()
@@ -487,10 +492,12 @@ class HipExecutor(object):
                 with torch.cuda.graph(g):
                     self._launch_all()
                 self.graph = g
+                self._graph_stream = cur
             self.graph.replay()
 
     def invalidate_graph(self):
         self.graph = None
+        self._graph_stream = None
 
     # ---- autotune --------------------------------------------------------------------------
     def autotune(self, iters=3, verbose=False):

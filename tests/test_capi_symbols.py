@@ -46,3 +46,15 @@ def test_pick_is_pure_host_logic(libpath):
     from ppyolo_hip._lib import PPYoloHipError
     with pytest.raises(PPYoloHipError):
         ops.conv2d_pick(8, 19, 19, 30, 512, 1, 1, 1, 0)       # C % 32 != 0
+
+
+def test_no_packed_fp32_ops_in_device_code(libpath):
+    """ppyolo_hip/build.py: v_pk_{add,mul,fma}_f32 of one kernel are corrupted on MI355X while the 16-bit-MFMA
+    convolution kernels of another stream share the CU (tools/pk_hazard_probe.py), so no kernel here may contain them."""
+    from ppyolo_hip import build
+    objdir = os.path.join(os.path.dirname(libpath), 'obj')
+    objs = sorted(f for f in os.listdir(objdir) if f.endswith('.o')) if os.path.isdir(objdir) else []
+    if len(objs) < len(build.SOURCES):
+        pytest.skip('object files of the build are not here (prebuilt library)')
+    for f in objs:
+        assert build.packed_fp32_ops(os.path.join(objdir, f)) == 0, f

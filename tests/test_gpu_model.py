@@ -228,6 +228,91 @@ def test_other_input_sizes_use_heuristic_configs(cfgc, S, N):
     _check_preds(preds, [r[0] for r in ref], keep.clone(), [r[1] for r in ref], box_tol=3e-3)
 
 
+@pytest.mark.parametrize('cfgc,S,N,depth', [(PPYOLO_r18vd_Config, 320, 4, 2), (PPYOLO_2x_Config, 224, 2, 3)])
+def test_in_flight_matches_forward(cfgc, S, N, depth):
+    """runtime.InFlight (several batches on the device at once, one lane each) returns for every batch exactly what
+    model.forward returns for it, in any collect order, and refuses to overwrite an uncollected lane."""
+    from ppyolo_hip._lib import PPYoloHipError
+    cfg = cfgc()
+    model, sd = build_model(cfg, 0, 'cuda')
+    batches = [(synth.synth_images(N, S, seed=300 + i).cuda(), synth.synth_im_size(N).cuda()) for i in range(7)]
+    want = [[p.clone() for p in model(x, ims)] for x, ims in batches]
+    assert any(p.shape[0] > 1 for w in want for p in w)
+    pipe = model.in_flight(depth)
+    tickets, got = [], {}
+    for i, (x, ims) in enumerate(batches):
+        if len(tickets) == depth:
+            with pytest.raises(PPYoloHipError):
+                pipe.submit(x, ims)
+            j, t = tickets.pop(0)
+            got[j] = t.result()
+        tickets.append((i, pipe.submit(x, ims)))
+    for j, t in reversed(tickets):                      # newest first
+        dets, cnt, keep = t.padded()
+        assert int(cnt[0]) == (0 if want[j][0][0, 0] == -1 else want[j][0].shape[0])
+        got[j] = t.result()
+        with pytest.raises(PPYoloHipError):
+            t.result()
+    for j in range(len(batches)):
+        for a, b in zip(got[j], want[j]):
+            assert torch.equal(a, b), 'batch %d differs between InFlight and forward' % j
+    # ... and against the oracle for one batch
+    ref = orc.ppyolo_forward(sd, cfg, batches[3][0].cpu(), batches[3][1].cpu())
+    _check_preds([g.cpu() for g in got[3]], ref, box_tol=3e-3)
+
+
+@pytest.mark.parametrize('math', ['f16x2', 'bf16x3'])
+def test_two_lanes_are_bit_stable(math, monkeypatch):
+    """Two lanes computing different batches at the same time give, in every buffer, what one executor gives alone.
+    (With packed-fp32 VALU ops in the kernels the decode of one lane was corrupted by the other lane's convolutions
+    in 4-40 % of the rounds -- ppyolo_hip/build.py, tools/pk_hazard_probe.py.)"""
+    monkeypatch.setenv('PPYOLO_HIP_MATH', math)
+    cfg = PPYOLO_r18vd_Config()
+    model, _ = build_model(cfg, 0, 'cuda')
+    N, S, NB = 4, 320, 4
+    batches = [(synth.synth_images(N, S, seed=300 + i).cuda(), synth.synth_im_size(N).cuda()) for i in range(NB)]
+    ex0 = model._plans.executor(batches[0][0])
+
+    def snap(e):
+        d = {'head%d' % i: e.view(a).dense().clone() for i, a in enumerate(e.plan.head_outs)}
+        d.update(boxes=e.boxes.clone(), cand_count=e.cand_count.clone(), out_dets=e.out_dets.clone(),
+                 out_count=e.out_count.clone(), out_keep=e.out_keep.clone())
+        return d
+    want = []
+    for x, ims in batches:
+        model(x, ims)
+        want.append(snap(ex0))
+    lanes = model.in_flight(2).lanes(batches[0][0])
+    for r in range(60):
+        pair = [(2 * r) % NB, (2 * r + 1 + r // NB) % NB]
+        for k, (e, st) in enumerate(lanes):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                e.set_inputs(*batches[pair[k]])
+                e.run()
+        torch.cuda.synchronize()
+        for k, (e, _) in enumerate(lanes):
+            for nm, g in snap(e).items():
+                assert torch.equal(g, want[pair[k]][nm]), 'round %d lane %d: %s differs from the solo run' % (r, k, nm)
+
+
+def test_two_branch_plan_is_opt_in_and_same_answer(monkeypatch):
+    """PPYOLO_HIP_STREAMS=2 (independent branches on a second stream; eager here) gives the one-branch results."""
+    cfg = PPYOLO_r18vd_Config()
+    x, ims = synth.synth_images(4, 256, seed=5).cuda(), synth.synth_im_size(4).cuda()
+    model, _ = build_model(cfg, 0, 'cuda')
+    base = [p.clone() for p in model(x, ims)]
+    assert not model._plans.executor(x).multi_stream
+    monkeypatch.setenv('PPYOLO_HIP_STREAMS', '2')
+    monkeypatch.setenv('PPYOLO_HIP_GRAPH', '0')
+    model2, _ = build_model(cfg, 0, 'cuda')
+    model2._plans.use_graph = False
+    got = model2(x, ims)
+    assert model2._plans.executor(x).multi_stream
+    for a, b in zip(got, base):
+        assert torch.equal(a, b)
+
+
 def test_graft_entry_smoke():
     """The driver's round-end smoke check, run as a test so that a regression shows up here first (the library
     once reported PyTorch's own stale hipGetLastError as a launch failure on exactly this path)."""
