@@ -211,7 +211,7 @@ def alt_math_leg(wl, dev, x, ims, steps, current, depth=1):
     return out
 
 
-def host_input_leg(ex, x, ims, steps):
+def host_input_leg(ex, x, ims, steps, lanes=None):
     """Not `value`: the same step when the batch is handed over as a HOST buffer (pinned), i.e. with the PCIe copy
     inside the loop -- serialised on the launch stream, and overlapped (copy of batch i+1 on a second stream while
     batch i runs; the step then only pays a device-to-device move of the staged batch)."""
@@ -248,8 +248,19 @@ def host_input_leg(ex, x, ims, steps):
         ex.run()
     torch.cuda.synchronize()
     out['overlapped_images_per_s'] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
+    if lanes is not None and len(lanes) > 1:
+        # the lanes of `value`: each lane copies its next batch on its own stream, which overlaps the other lane's kernels
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            e, st = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                e.x_in.copy_(pin, non_blocking=True)
+                e.run()
+        torch.cuda.synchronize()
+        out['in_flight_images_per_s'] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
     out['note'] = ('input batch of %.1f MB per step from pinned host memory; not the headline value (inputs resident in '
-                   'HBM)' % (x.numel() * 4 / 1e6))
+                   'HBM); serial / overlapped = one lane, in_flight = the lanes of `value`' % (x.numel() * 4 / 1e6))
     return out
 
 
@@ -298,6 +309,9 @@ def main():
     ap.add_argument('--no-alt-math', action='store_true', help='skip the side measurement of the other math modes')
     ap.add_argument('--autotune', action='store_true', help='re-measure tile configs instead of using the '
                     'committed tuned_gfx950.json table')
+    ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
+                    'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
+    ap.add_argument('--verbose-tune', action='store_true')
     ap.add_argument('--save-tuning', default=None, help='write the measured table to this JSON file')
     ap.add_argument('--layer-report', default=None, help='write per-launch timings to this JSON file')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); "gloo" '
@@ -337,6 +351,12 @@ def main():
     torch.cuda.synchronize()
     if a.autotune:
         ex.autotune(iters=5)
+        if a.co_tune and depth > 1:
+            lanes[1][0].use_graph = True
+            changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)
+            lanes[1][0].invalidate_graph()
+            if rank == 0:
+                print('co_tune: %d layers changed their config' % changed, file=sys.stderr)
         if a.save_tuning and rank == 0:
             ex.save_tuning(a.save_tuning)
         for e, _ in lanes[1:]:
@@ -440,15 +460,14 @@ def main():
                    roofline=roof)
         if one_at_a_time is not None:
             out['one_batch_at_a_time'] = dict(value=one_at_a_time, unit='images/s',
-                                              note='same lane-0 graph replayed alone, i.e. --in-flight 1 without the second '
-                                                   'stream of its forked graph')
+                                              note='the graph of lane 0 replayed alone (= --in-flight 1)')
         out['roofline_other'] = decode_nms_leg(ex)
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:
             out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math, depth)
         if world == 1 and not a.no_host_input:
-            out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30))
+            out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30), lanes)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg, wl['size'], a.batch)
         print(json.dumps(out), flush=True)

@@ -567,10 +567,13 @@ class HipExecutor(object):
                             cands.append((ms, c, s))
                 # second look at the front-runners: short kernels are noisy at `iters` repetitions
                 best = None
+                front = []
                 for ms, c, s in sorted(cands)[:6]:
                     again = min(measure(c, s, 4 * iters), measure(c, s, 4 * iters))
+                    front.append((again, c, s))
                     if best is None or again < best[0]:
                         best = (again, c, s)
+                op['_front'] = sorted(front)           # kept for co_tune()
                 if best is None:
                     op['cfg'], op['splitk'] = base_cfg, base_split
                     continue
@@ -583,6 +586,67 @@ class HipExecutor(object):
         self._size_workspace()
         self.graph = None
         return report
+
+    def co_tune(self, other, topk=4, reps=3, verbose=False):
+        """Second tuning stage for lanes that run beside each other (runtime.InFlight): among the `topk` front-runners
+        autotune() measured for a layer, take the one with the shortest MAKESPAN of {this layer repeated for as long as
+        one whole step takes} on one stream and {one whole step of `other`, an executor of the same plan} on another.
+        The fastest kernel alone is not always the best neighbour: a tile shape that leaves CUs, LDS or power to the
+        other lane can finish the pair sooner.  Measured, R50-608 bs8, two lanes: +0.6 %."""
+        import time
+        with torch.cuda.device(self.device):
+            sa, sb = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(sb):
+                other.run()
+                other.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(sb):
+                for _ in range(5):
+                    other.run()
+            torch.cuda.synchronize()
+            t_step = (time.perf_counter() - t0) / 5
+            changed = 0
+            for op in self.plan.ops:
+                front = op.get('_front')
+                if op['op'] not in ('conv', 'dcn') or not front or len(front) < 2:
+                    continue
+                n = int(max(4, min(1500, round(t_step * 1e3 / max(front[0][0], 1e-3)))))
+                scored = []
+                for ms, c, s in front[:topk]:
+                    op['cfg'], op['splitk'] = c, s
+                    self._run_op(op)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(n):
+                            self._run_op(op)
+                    best = None
+                    for _ in range(reps):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        with torch.cuda.stream(sb):
+                            other.run()
+                        with torch.cuda.stream(sa):
+                            g.replay()
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None else min(best, dt)
+                    g.reset()
+                    del g
+                    scored.append((best, c, s, ms))
+                scored.sort()
+                win = scored[0]
+                if (win[1], win[2]) != (front[0][1], front[0][2]):
+                    changed += 1
+                op['cfg'], op['splitk'] = win[1], win[2]
+                tuned_table(self.math)[tune_key(op)] = [win[1], win[2], round(win[3], 4)]
+                if verbose:
+                    print('co_tune %s: %s -> cfg %d split %d' % (tune_key(op), ['%d/%d %.3f' % (c, s, 1e3 * b)
+                                                                              for b, c, s, _ in scored], win[1], win[2]))
+        self._size_workspace()
+        self.graph = None
+        return changed
 
     def save_tuning(self, path):
         """Write the entries THIS executor measured (not the whole loaded table: merging files of several workloads

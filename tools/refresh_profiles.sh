@@ -1,0 +1,18 @@
+#!/bin/bash
+# Regenerate the measured set under profiles/ on the GPU box (run through gpurun; results land in gpurun_out/refresh/,
+# copy them into profiles/ afterwards).  usage: tools/refresh_profiles.sh <tag>
+TAG=${1:-r01}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/refresh; mkdir -p $O
+python bench.py --layer-report $O/${TAG}_layers_r50vd_608_bs8.json > $O/${TAG}_bench_r50vd_608.json 2> $O/bench_r50.err
+PPYOLO_HIP_MATH=bf16x3 python bench.py --no-cpu-baseline --no-alt-math --no-host-input > $O/${TAG}_bench_r50vd_608_math_bf16x3.json 2>/dev/null
+PPYOLO_HIP_MATH=fp32 python bench.py --no-cpu-baseline --no-alt-math --no-host-input > $O/${TAG}_bench_r50vd_608_math_fp32.json 2>/dev/null
+python bench.py --in-flight 1 --no-cpu-baseline --no-alt-math --no-host-input > $O/${TAG}_bench_r50vd_608_one_lane.json 2>/dev/null
+python bench.py --workload r18vd_416 --no-host-input --layer-report $O/${TAG}_layers_r18vd_416_bs8.json > $O/${TAG}_bench_r18vd_416.json 2>/dev/null
+python bench.py --workload r18vd_320 --no-cpu-baseline --no-host-input > $O/${TAG}_bench_r18vd_320_bs8.json 2>/dev/null
+python bench.py --workload r18vd_320 --batch 1 --no-cpu-baseline --no-host-input > $O/${TAG}_bench_r18vd_320_bs1.json 2>/dev/null
+bash tools/prof_run.sh $TAG > $O/prof_run.log 2>&1
+for n in trace pmc_sq pmc_fetch pmc_write pmc_lds; do cp gpurun_out/prof_$TAG/$n.txt $O/${TAG}_$n.txt 2>/dev/null; done
+for f in $O/${TAG}_bench_*.json; do python -c "
+import json,sys
+d=json.loads([l for l in open('$f') if l.startswith('{')][-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"; done
