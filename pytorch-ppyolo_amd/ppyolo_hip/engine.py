@@ -230,7 +230,7 @@ class Builder(object):
 class HipExecutor(object):
     """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
 
-    def __init__(self, plan, device, use_graph=True, multi_stream=None):
+    def __init__(self, plan, device, use_graph=True, multi_stream=None, share=None):
         if torch.device(device).type != 'cuda':
             raise PPYoloHipError('the HIP executor needs a ROCm device (got %s); there is no CPU path' % device)
         self.plan = plan
@@ -261,15 +261,23 @@ class HipExecutor(object):
             self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
             self.nms_ws = K.matrix_nms_workspace(p.N, self.device)
         self.math = math_mode()
-        self._to_device(p.setup_ops)
-        self._to_device(p.ops)
-        if self.math in ('bf16x3', 'f16x2'):
-            with torch.cuda.device(self.device):
-                for op in p.ops:        # (setup ops -- the CoordConv bias maps -- stay on the exact-fp32 kernel)
-                    if op['op'] in ('conv', 'dcn'):
-                        op['w3'] = K.split_weights_bf16x3(op['w'])
-                        if self.math == 'f16x2':
-                            op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
+        if share is not None and share.math == self.math and len(share.plan.ops) == len(p.ops):
+            # a further lane of the same plan (runtime.InFlight): weights are read-only, one copy in HBM serves all lanes
+            for mine, theirs in ((p.setup_ops, share.plan.setup_ops), (p.ops, share.plan.ops)):
+                for op, src in zip(mine, theirs):
+                    for k in ('w', 'scale', 'shift', 'w3', 'wf16'):
+                        if src.get(k) is not None:
+                            op[k] = src[k]
+        else:
+            self._to_device(p.setup_ops)
+            self._to_device(p.ops)
+            if self.math in ('bf16x3', 'f16x2'):
+                with torch.cuda.device(self.device):
+                    for op in p.ops:        # (setup ops -- the CoordConv bias maps -- stay on the exact-fp32 kernel)
+                        if op['op'] in ('conv', 'dcn'):
+                            op['w3'] = K.split_weights_bf16x3(op['w'])
+                            if self.math == 'f16x2':
+                                op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
         self._assign_amax()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}

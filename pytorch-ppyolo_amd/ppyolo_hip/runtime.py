@@ -50,7 +50,8 @@ class PlanCache(object):
         if ex is None:
             with torch.no_grad():
                 plan = build_plan(self._model, N, H, W, x.device)
-                ex = HipExecutor(plan, x.device, use_graph=self.use_graph, multi_stream=multi_stream)
+                ex = HipExecutor(plan, x.device, use_graph=self.use_graph, multi_stream=multi_stream,
+                                 share=self._ex.get((N, H, W, str(x.device), 0)) if lane else None)
                 if self.autotune:
                     ex.run() if not self.use_graph else ex._launch_all()
                     ex.autotune()
