@@ -110,6 +110,16 @@ int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const 
                                 const float *shift, float *y, int y_ld, int N, int H, int W,
                                 int K, int act, float *amax_out /* NULL or N * PPY_AMAX_FLOATS_PER_IMAGE floats */, void *stream);
 
+/* Image pre-processing in front of the path, reference Decode.process_image
+ * (model/decode_np.py:125-140): BGR->RGB (swap_rb), cv2.resize(fx = S/w, fy = S/h, INTER_CUBIC) on uint8
+ * (tools/transform.py:996-1003; OpenCV's 11-bit fixed-point bicubic, A = -0.75, replicated border), then the numpy
+ * normalisation (transform.py:895-917) given as lut[c][v] = value of grey level v in OUTPUT channel c, and HWC->CHW
+ * (transform.py:1052-1054).  images[i]: device pointer to an h[i] x w[i] x 3 uint8 image with row_stride[i] bytes per
+ * row; the arrays images / h / w / row_stride are HOST arrays of length n.  out: device [n][3][S][S] float32. */
+int ppy_preprocess_u8_f32(int n, const unsigned char *const *images, const int *h, const int *w,
+                          const int *row_stride, int swap_rb, int S, const float *lut /* device [3][256] */,
+                          float *out, void *stream);
+
 /* torch.nn.MaxPool2d(3, 2, 1) of the stem (reference model/resnet_vd.py:103, :136). */
 int ppy_maxpool3x3s2_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W,
                          int C, void *stream);

@@ -1,9 +1,8 @@
 """Host harness boundary -- the part of the reference's `model/decode_np.py` that sits on the
 model boundary: `Decode.predict` (:142-150), `detect_image` (:41-57), `detect_batch`
-(:81-96).  Image pre-processing (`process_image`, cv2 resize/normalise) and drawing are host
-CPU work outside the hot path and are not
-provided; callers pass already pre-processed `pimage` arrays exactly as the reference's
-`predict` receives them."""
+(:81-96), and `process_image` (:125-140) -- the cv2 resize / normalise / permute in front of the
+model, here ONE HIP kernel on the device (ppyolo_hip/csrc/preprocess.hip; SURVEY.md section 8f
+rank 1).  Drawing (cv2) is host-side post-processing outside the path and is not provided."""
 import numpy as np
 import torch
 
@@ -15,10 +14,35 @@ class Decode(object):
         self._yolo = _yolo
         self.use_gpu = use_gpu
         self.cfg = cfg
+        # reference :32-37: eval target size unless for_test
+        self.target_size = (cfg.test_cfg if for_test else cfg.eval_cfg)['target_size']
+        self._pre = None
+
+    def _preprocessor(self):
+        if self._pre is None:
+            from ppyolo_hip.preprocess import Preprocessor
+            self._pre = Preprocessor(self.cfg, self.target_size)
+        return self._pre
+
+    def process_image(self, img, to_numpy=True):
+        """uint8 BGR [h,w,3] -> (pimage [1,3,S,S] float32, im_size [[h, w]] int32), computed on the device.
+        `to_numpy=True` returns numpy arrays like the reference; False keeps pimage on the device (what `predict`
+        wants anyway) and saves the round trip."""
+        pimage, _ = self._preprocessor()([img])
+        im_size = np.array([[img.shape[0], img.shape[1]]]).astype(np.int32)
+        return (pimage.cpu().numpy() if to_numpy else pimage), im_size
+
+    def detect_raw(self, images):
+        """Throughput form of demo.py's loop: raw uint8 BGR images of any sizes -> per image (boxes, scores, classes),
+        pre-processing, forward and Matrix-NMS all on the device."""
+        pimage, im_size = self._preprocessor()(images)
+        preds = self._yolo(pimage, im_size)
+        return [self._split(p.cpu().detach().numpy()) for p in preds]
 
     def predict(self, image, im_size):
         """numpy [N,3,S,S] f32 + numpy [N,2] (h, w) -> list of numpy [K,6] f32."""
-        image = torch.as_tensor(np.asarray(image), dtype=torch.float32)
+        if not isinstance(image, torch.Tensor):
+            image = torch.as_tensor(np.asarray(image), dtype=torch.float32)
         im_size = torch.as_tensor(np.asarray(im_size), dtype=torch.float32)
         if not self.use_gpu:
             raise RuntimeError('the MI355X path has no CPU mode: construct Decode(use_gpu=True)')

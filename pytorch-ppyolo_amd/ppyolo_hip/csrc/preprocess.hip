@@ -1,0 +1,125 @@
+// Image pre-processing in front of the hot path, on the device: the reference's Decode.process_image
+// (model/decode_np.py:125-140) = BGR->RGB, cv2.resize(..., fx=S/w, fy=S/h, INTER_CUBIC) on uint8
+// (tools/transform.py:996-1003), /255, -mean, /std in numpy (transform.py:895-917), HWC->CHW (transform.py:1052-1054)
+// -- one kernel, uint8 HWC in, float32 NCHW out (the layout the stem kernel reads).
+//
+// Resize arithmetic = OpenCV 4.x's 8-bit bicubic (imgproc/src/resize.cpp), integer for integer:
+//   fx = (float)((dx + 0.5) * scale_x - 0.5), sx = floor(fx), fx -= sx        (scale_x = 1 / (S / w), in double)
+//   interpolateCubic(fx) with A = -0.75 in float32, one rounding per operation (fp contraction off below)
+//   weights = cvRound(coef * 2048) as int16; taps sx-1 .. sx+2 with indices clamped to the image (replicated border)
+//   horizontal sums in int32, vertical sum in int32, FixedPtCast: (v + 2^21) >> 22, saturated to uint8.
+// (OpenCV's vectorised vertical pass evaluates the last sum in float and may differ by one grey level on a few pixels
+// in 10^4; cv2 is not available to this build, see oracle/preprocess_oracle.py.)
+// The numpy normalisation is a function of (grey level, channel): the caller passes it as a 3 x 256 float table built
+// with the reference's own numpy expression, so that part is bit-exact by construction.
+// Roofline: HBM-bound by design (source bytes read once through L2, S*S*3 floats written once); at 608x608 the launch
+// is ~10 us of latency.
+#include "common.h"
+
+namespace {
+
+constexpr int PRE_MAX_IMAGES = 16;
+struct PreImage {
+    const unsigned char *src;
+    int h, w, stride;
+    double scale_x, scale_y;
+};
+struct PreArgs {
+    PreImage img[PRE_MAX_IMAGES];
+    const float *lut;       // [3][256]
+    float *out;             // [n][3][S][S]
+    int S, swap_rb;
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void cubic_weights(float x, int (&wgt)[4]) {
+    const float A = -0.75f;
+    const float t = x + 1.0f;
+    float c[4];
+    c[0] = ((A * t - 5.0f * A) * t + 8.0f * A) * t - 4.0f * A;
+    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    const float u = 1.0f - x;
+    c[2] = ((A + 2.0f) * u - (A + 3.0f)) * u * u + 1.0f;
+    c[3] = 1.0f - c[0] - c[1] - c[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v = rintf(c[k] * 2048.0f);                     // cvRound: ties to even
+        wgt[k] = (int)fminf(fmaxf(v, -32768.0f), 32767.0f);        // saturate_cast<short>
+    }
+}
+
+__device__ __forceinline__ int first_tap(int d, double scale, float &frac) {
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const float fl = floorf(f);
+    frac = f - fl;
+    return (int)fl;
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs p) {
+    const PreImage &im = p.img[blockIdx.z];
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= p.S || dy >= p.S) return;
+    float fx, fy;
+    const int sx = first_tap(dx, im.scale_x, fx), sy = first_tap(dy, im.scale_y, fy);
+    int ax[4], ay[4];
+    cubic_weights(fx, ax);
+    cubic_weights(fy, ay);
+    int col[4];
+    const unsigned char *row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        col[k] = min(max(sx - 1 + k, 0), im.w - 1) * 3;
+        row[k] = im.src + (long long)min(max(sy - 1 + k, 0), im.h - 1) * im.stride;
+    }
+    const long long plane = (long long)p.S * p.S;
+    float *o = p.out + (long long)blockIdx.z * 3 * plane + (long long)dy * p.S + dx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int cs = p.swap_rb ? 2 - c : c;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int hs = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hs += (int)row[k][col[j] + cs] * ax[j];
+            acc += hs * ay[k];
+        }
+        int v = (acc + (1 << 21)) >> 22;
+        v = min(max(v, 0), 255);
+        o[c * plane] = p.lut[c * 256 + v];
+    }
+}
+
+}  // namespace
+
+extern "C" int ppy_preprocess_u8_f32(int n, const unsigned char *const *images, const int *h, const int *w,
+                                     const int *row_stride, int swap_rb, int S, const float *lut, float *out,
+                                     void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(n > 0 && images && h && w && row_stride && lut && out && S > 0);
+    for (int base = 0; base < n; base += PRE_MAX_IMAGES) {
+        PreArgs a;
+        const int cnt = n - base < PRE_MAX_IMAGES ? n - base : PRE_MAX_IMAGES;
+        for (int i = 0; i < cnt; ++i) {
+            const int hi = h[base + i], wi = w[base + i];
+            PPY_CHECK_ARG(images[base + i] && hi > 0 && wi > 0 && row_stride[base + i] >= 3 * wi);
+            // cv::resize with dsize = None: inv_scale = fx as passed (S / w in double), dsize = cvRound(w * inv_scale)
+            const double inv_x = (double)S / (double)wi, inv_y = (double)S / (double)hi;
+            PPY_CHECK_ARG((long long)__builtin_rint(wi * inv_x) == S && (long long)__builtin_rint(hi * inv_y) == S);
+            a.img[i].src = images[base + i];
+            a.img[i].h = hi;
+            a.img[i].w = wi;
+            a.img[i].stride = row_stride[base + i];
+            a.img[i].scale_x = 1.0 / inv_x;
+            a.img[i].scale_y = 1.0 / inv_y;
+        }
+        a.lut = lut;
+        a.out = out + (long long)base * 3 * S * S;
+        a.S = S;
+        a.swap_rb = swap_rb;
+        hipLaunchKernelGGL(preprocess_kernel, dim3(ceil_div(S, 64), ceil_div(S, 4), cnt), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    }
+    return ppy_launch_status();
+}

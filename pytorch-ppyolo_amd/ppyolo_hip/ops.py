@@ -144,6 +144,21 @@ def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None):
           'ppy_stem_conv3x3s2_nchw_f32')
 
 
+def preprocess_images(images_u8, target_size, lut, out, swap_rb=True):
+    """Decode.process_image on the device for a list of uint8 HWC device tensors (any sizes) -> out[i] = [3,S,S] float32.
+    lut: device float32 [3,256] (ppyolo_hip.preprocess.normalisation_table)."""
+    n = len(images_u8)
+    _dev(lut, out, *images_u8)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, 3, target_size, target_size)
+    assert lut.dtype == torch.float32 and lut.is_contiguous() and tuple(lut.shape) == (3, 256)
+    for im in images_u8:
+        assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == 3 and im.stride(2) == 1 and im.stride(1) == 3
+    check(lib().ppy_preprocess_u8_f32(
+        n, (ctypes.c_void_p * n)(*[im.data_ptr() for im in images_u8]), (ctypes.c_int * n)(*[im.shape[0] for im in images_u8]),
+        (ctypes.c_int * n)(*[im.shape[1] for im in images_u8]), (ctypes.c_int * n)(*[im.stride(0) for im in images_u8]),
+        int(bool(swap_rb)), int(target_size), lut.data_ptr(), out.data_ptr(), _stream()), 'ppy_preprocess_u8_f32')
+
+
 def maxpool3x3s2(x, y):
     _dev(x.t, y.t)
     check(lib().ppy_maxpool3x3s2_f32(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_maxpool3x3s2_f32')
