@@ -270,6 +270,64 @@ def host_input_leg(ex, x, ims, steps, lanes=None):
     return out
 
 
+def preprocess_leg(cfg, size, batch, lanes, steps, with_cpu):
+    """Not `value` (the step in front of the path): the pre-processing kernel against HBM bandwidth
+    -- algorithmic bytes = the raw uint8 images read once + the float NCHW batch written once -- and the whole job from
+    RAW images (480x640x3 uint8 in pinned host memory -> H2D -> resize/normalise kernel -> forward) on the lanes of
+    `value`; the numpy oracle of Decode.process_image on one host core beside it."""
+    import numpy as np
+    from ppyolo_hip import ops as K
+    from ppyolo_hip.preprocess import Preprocessor
+    dev = lanes[0][0].device
+    pre = Preprocessor(cfg, size, dev)
+    rng = np.random.RandomState(7)
+    raw = [torch.from_numpy(rng.randint(0, 256, size=(480, 640, 3)).astype(np.uint8)).pin_memory() for _ in range(batch)]
+    on_dev = [r.to(dev) for r in raw]
+    out = torch.empty((batch, 3, size, size), dtype=torch.float32, device=dev)
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K.preprocess_images(on_dev, size, pre.lut, out, swap_rb=pre.to_rgb)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    byt = sum(r.numel() for r in raw) + out.numel() * 4
+    gbs = byt / (best * 1e-3) / 1e9
+    res = dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s', frac=round(gbs / 8000.0, 4),
+               bytes_per_launch=byt, us_per_launch=round(best * 1e3, 1),
+               kernel='preprocess_kernel (BGR->RGB, 8-bit bicubic resize 480x640 -> %dx%d, normalise, HWC->CHW; %d images, '
+                      'one launch)' % (size, size, batch))
+    ims = torch.tensor([[480., 640.]] * batch, device=dev)
+    stage = [[torch.empty_like(o) for o in on_dev] for _ in lanes]
+
+    def go(n):
+        for i in range(n):
+            e, st = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                for d, r in zip(stage[i % len(lanes)], raw):
+                    d.copy_(r, non_blocking=True)
+                K.preprocess_images(stage[i % len(lanes)], size, pre.lut, e.x_in, swap_rb=pre.to_rgb)
+                e.im_size.copy_(ims)
+                e.run()
+        torch.cuda.synchronize()
+    go(2 * len(lanes))
+    t0 = time.perf_counter()
+    go(steps)
+    res['from_raw_host_images_per_s'] = round(batch * steps / (time.perf_counter() - t0), 1)
+    if with_cpu:
+        from oracle import preprocess_oracle as orc
+        img = raw[0].numpy()
+        orc.process_image(img, size)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            orc.process_image(img, size)
+        res['cpu_oracle_images_per_s'] = round(3 / (time.perf_counter() - t0), 1)
+        res['cpu_oracle_note'] = 'numpy restatement of Decode.process_image (cv2 is not installed), 1 core'
+    return res
+
+
 def cpu_baseline(sd, cfg, size, batch):
     """Oracle (PyTorch-CPU restatement of the reference forward) on the host cores."""
     from oracle import ppyolo_oracle as orc
@@ -474,6 +532,9 @@ def main():
             out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math, depth)
         if world == 1 and not a.no_host_input:
             out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30), lanes)
+        if world == 1 and not a.no_host_input:
+            out['roofline_other']['preprocess'] = preprocess_leg(cfg, wl['size'], a.batch, lanes, min(a.steps, 30),
+                                                                 not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg, wl['size'], a.batch)
         print(json.dumps(out), flush=True)

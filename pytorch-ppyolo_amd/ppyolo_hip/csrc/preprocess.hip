@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int PRE_MAX_IMAGES = 16;
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
 struct PreImage {
     const unsigned char *src;
     int h, w, stride;
@@ -65,12 +66,35 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs p) {
     int ax[4], ay[4];
     cubic_weights(fx, ax);
     cubic_weights(fy, ay);
-    int col[4];
     const unsigned char *row[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        col[k] = min(max(sx - 1 + k, 0), im.w - 1) * 3;
-        row[k] = im.src + (long long)min(max(sy - 1 + k, 0), im.h - 1) * im.stride;
+    for (int k = 0; k < 4; ++k) row[k] = im.src + (long long)min(max(sy - 1 + k, 0), im.h - 1) * im.stride;
+    // the 4 x 3 bytes of a row's taps: three unaligned dword loads when all four taps are inside the row (one thread
+    // then issues 12 loads instead of 48), byte loads with clamped columns at the left / right border
+    unsigned px[4][3];      // [row][dword]: bytes 0..11 = taps 0..3 x (B, G, R)
+    if (sx >= 1 && sx + 2 <= im.w - 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(row[k] + (sx - 1) * 3);
+            px[k][0] = q[0];
+            px[k][1] = q[1];
+            px[k][2] = q[2];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned char b[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cj = min(max(sx - 1 + j, 0), im.w - 1) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * j + c] = row[k][cj + c];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                px[k][d] = (unsigned)b[4 * d] | ((unsigned)b[4 * d + 1] << 8) | ((unsigned)b[4 * d + 2] << 16) |
+                           ((unsigned)b[4 * d + 3] << 24);
+        }
     }
     const long long plane = (long long)p.S * p.S;
     float *o = p.out + (long long)blockIdx.z * 3 * plane + (long long)dy * p.S + dx;
@@ -82,7 +106,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs p) {
         for (int k = 0; k < 4; ++k) {
             int hs = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hs += (int)row[k][col[j] + cs] * ax[j];
+            for (int j = 0; j < 4; ++j) {
+                const int byte = 3 * j + cs;                       // 0..11 (cs is wave-uniform)
+                hs += (int)((px[k][byte >> 2] >> (8 * (byte & 3))) & 0xffu) * ax[j];
+            }
             acc += hs * ay[k];
         }
         int v = (acc + (1 << 21)) >> 22;
