@@ -48,17 +48,23 @@ def single(steps):
             exs[0][1].run()
 
 
+OFFSET = float(os.environ.get('PROBE_OFFSET', '0'))       # start lane k with a delay of k * OFFSET steps
+
+
 def multi(steps):
     for i in range(steps):
         with torch.cuda.stream(streams[i % D]):
+            if OFFSET > 0 and 0 < i < D:
+                torch.cuda._sleep(int(OFFSET * i * STEP_S * 2.4e9))
             exs[i % D][1].run()
 
 
 K = 60
+STEP_S = timed(single, 10) / 10
 timed(single, 10)
 timed(multi, 10)
 t1 = timed(single, K)
 t2 = timed(multi, K)
-print('%s bs%d streams=%s: one in flight %.1f img/s   %d in flight %.1f img/s  (%+.1f%%)' % (
+print('offset %.2f ' % OFFSET + '%s bs%d streams=%s: one in flight %.1f img/s   %d in flight %.1f img/s  (%+.1f%%)' % (
     sys.argv[1] if len(sys.argv) > 1 else 'r50vd_608', B, os.environ.get('PPYOLO_HIP_STREAMS', 'dflt'), B * K / t1, D,
     B * K / t2, 100 * (t1 / t2 - 1)))
