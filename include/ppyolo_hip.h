@@ -42,6 +42,9 @@ extern "C" {
 
 int ppy_version(void);
 const char *ppy_error_string(int code);
+/* Name of the HIP runtime error behind the last PPY_ERR_LAUNCH on the calling thread (diagnostics). */
+const char *ppy_last_hip_error(void);
+void ppy_note_hip_error(int hip_error);      /* internal: set by the launch paths */
 
 /* ------------------------------------------------------------------------------------
  * Conv2dUnit.forward (reference model/custom_layers.py:243-253): conv(k in {1,3},

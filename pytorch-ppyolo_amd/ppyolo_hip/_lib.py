@@ -24,6 +24,8 @@ _lib = None
 _PROTOS = {
     'ppy_version': (c_int, []),
     'ppy_error_string': (ctypes.c_char_p, [c_int]),
+    'ppy_last_hip_error': (ctypes.c_char_p, []),
+    'ppy_note_hip_error': (None, [c_int]),
     'ppy_conv2d_split_weights_bf16x3': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
     'ppy_conv2d_split_weights_f16x2': (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ppy_conv2d_bn_act_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -71,6 +73,10 @@ def lib():
             raise PPYoloHipError(
                 'libppyolo_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
                 'g.build()"` (hipcc, gfx950). There is no CPU / PyTorch fallback for the HIP path.' % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64; the process must hold ONE HIP runtime, the one torch initialises
+        # (device memory and streams come from torch).  Loading this library first binds it to the system runtime
+        # instead, and its launches then fail with hipErrorNoDevice -- so make sure torch's is mapped before dlopen.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)
@@ -83,4 +89,6 @@ def lib():
 def check(rc, what=''):
     if rc != OK:
         msg = lib().ppy_error_string(rc).decode()
+        if rc == -4:                  # PPY_ERR_LAUNCH: say which HIP error it was
+            msg += ' [%s]' % lib().ppy_last_hip_error().decode()
         raise PPYoloHipError('%s failed: %s (code %d)' % (what or 'libppyolo_hip call', msg, rc))

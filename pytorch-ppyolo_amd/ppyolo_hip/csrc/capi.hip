@@ -13,3 +13,8 @@ extern "C" const char *ppy_error_string(int code) {
     }
     return "unknown error";
 }
+
+// The HIP error behind the last PPY_ERR_LAUNCH of this thread ("hipSuccess" if there was none): diagnostics only.
+static thread_local int g_last_hip_error = 0;
+extern "C" void ppy_note_hip_error(int hip_error) { g_last_hip_error = hip_error; }
+extern "C" const char *ppy_last_hip_error(void) { return hipGetErrorName((hipError_t)g_last_hip_error); }

@@ -17,8 +17,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // host pointers with hipPointerGetAttributes, which fails benignly) would otherwise be reported as ours.
 static inline void ppy_drop_stale_error() { (void)hipGetLastError(); }
 
+extern "C" void ppy_note_hip_error(int hip_error);      // capi.hip: kept per thread for ppy_last_hip_error()
 static inline int ppy_launch_status() {
-    return hipGetLastError() == hipSuccess ? PPY_OK : PPY_ERR_LAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return PPY_OK;
+    ppy_note_hip_error((int)e);
+    return PPY_ERR_LAUNCH;
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -318,3 +318,16 @@ def test_graft_entry_smoke():
     once reported PyTorch's own stale hipGetLastError as a launch failure on exactly this path)."""
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_fresh_process_build_then_smoke():
+    """build() loads the library before anything touched the GPU; smoke() in the same fresh process must still run
+    (the library used to bind to the system HIP runtime instead of torch's when it was loaded first: hipErrorNoDevice
+    at the first launch)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0 and 'smoke ok' in r.stdout, r.stdout[-2000:]
