@@ -505,7 +505,10 @@ def main():
         out = dict(metric='images/sec PPYOLO R50-vd 608x608 bs=8' if a.workload == 'r50vd_608'
                    else 'images/sec %s bs=%d' % (a.workload, a.batch),
                    value=round(value, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
-                   ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
+                   ms_per_step=round(ms_per_step, 3), ms_per_step_note=(
+                       'wall time of the timed region / steps; with %d batches in flight a single batch takes about %d x this '
+                       'from submit to result' % (depth, depth)) if depth > 1 else 'wall time of the timed region / steps',
+                   higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype='f32', data='synthetic (randn images seed 1234, deterministic random weights seed 0)',
                    config=dict(workload='%s %dx%d, %d images per GPU, device-resident input -> padded detections'
                                         % (wl['model'], wl['size'], wl['size'], a.batch),
