@@ -313,6 +313,37 @@ def test_two_branch_plan_is_opt_in_and_same_answer(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('S', [320, 352, 384, 416, 448, 480, 512, 544, 576, 608])
+def test_every_reference_input_size(S):
+    """The reference's multi-scale set (config randomShape sizes, also its eval sizes): r18vd at batch 2 against the
+    oracle at every one of them -- most of these shapes are not in the measured tile tables."""
+    cfg = PPYOLO_r18vd_Config()
+    model, sd = build_model(cfg, 0, 'cuda')
+    x = synth.synth_images(2, S, seed=S)
+    ims = torch.tensor([[480., 640.], [333., 500.]])
+    preds = [p.cpu() for p in model(x.cuda(), ims.cuda())]
+    dets, cnt, keep = model.forward_padded(x.cuda(), ims.cuda())
+    ref = orc.ppyolo_forward(sd, cfg, x, ims, return_index=True)
+    _check_preds(preds, [r[0] for r in ref], keep.clone(), [r[1] for r in ref], box_tol=3e-3)
+
+
+@pytest.mark.parametrize('N', [1, 3, 7, 16])
+def test_batch_sizes(N):
+    """Odd and large batches (row tiles that straddle several images, per-image scales): r18vd-256 vs the oracle on the
+    first and last image, and against the same image run alone (another plan: other tiles / split-K, hence another
+    fp32 summation order -- equal within rounding, not bit for bit; bit-exactness holds within one batch size)."""
+    cfg = PPYOLO_r18vd_Config()
+    model, sd = build_model(cfg, 0, 'cuda')
+    x = synth.synth_images(N, 256, seed=40 + N)
+    ims = synth.synth_im_size(N)
+    preds = [p.cpu() for p in model(x.cuda(), ims.cuda())]
+    for i in sorted({0, N - 1}):
+        ref = orc.ppyolo_forward(sd, cfg, x[i:i + 1], ims[i:i + 1])
+        _check_preds([preds[i]], ref, box_tol=3e-3)
+        alone = model(x[i:i + 1].cuda(), ims[i:i + 1].cuda())[0].cpu()
+        _check_preds([preds[i]], [alone], box_tol=1e-3)
+
+
 def test_graft_entry_smoke():
     """The driver's round-end smoke check, run as a test so that a regression shows up here first (the library
     once reported PyTorch's own stale hipGetLastError as a launch failure on exactly this path)."""
