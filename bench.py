@@ -256,17 +256,22 @@ def host_input_leg(ex, x, ims, steps, lanes=None):
     out['overlapped_images_per_s'] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
     if lanes is not None and len(lanes) > 1:
         # the lanes of `value`: each lane copies its next batch on its own stream, which overlaps the other lane's kernels
+        hd = [torch.empty(e.out_dets.shape, dtype=torch.float32).pin_memory() for e, _ in lanes]
+        hc = [torch.empty(e.out_count.shape, dtype=torch.int32).pin_memory() for e, _ in lanes]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            e, st = lanes[i % len(lanes)]
+            k = i % len(lanes)
+            e, st = lanes[k]
             with torch.cuda.stream(st):
                 e.x_in.copy_(pin, non_blocking=True)
                 e.run()
+                hd[k].copy_(e.out_dets, non_blocking=True)          # D2H of the padded detections (19.2 KB) + counts
+                hc[k].copy_(e.out_count, non_blocking=True)
         torch.cuda.synchronize()
         out['in_flight_images_per_s'] = round(x.shape[0] * steps / (time.perf_counter() - t0), 1)
     out['note'] = ('input batch of %.1f MB per step from pinned host memory; not the headline value (inputs resident in '
-                   'HBM); serial / overlapped = one lane, in_flight = the lanes of `value`' % (x.numel() * 4 / 1e6))
+                   'HBM); serial / overlapped = one lane, H2D only; in_flight = the lanes of `value`, H2D of the batch and D2H of the detections' % (x.numel() * 4 / 1e6))
     return out
 
 
