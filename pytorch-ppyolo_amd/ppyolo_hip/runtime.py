@@ -27,11 +27,13 @@ class PlanCache(object):
     def __init__(self, model):
         self._model = model
         self._ex = {}
+        self.generation = 0
         self.use_graph = os.environ.get('PPYOLO_HIP_GRAPH', '1') != '0'
         self.autotune = os.environ.get('PPYOLO_HIP_AUTOTUNE', '0') == '1'
 
     def clear(self):
         self._ex = {}
+        self.generation += 1          # InFlight lanes built from older executors (older weights) are stale
 
     def executor(self, x, lane=0, multi_stream=None):
         """`lane` > 0 are further executors of the same shape (own activations, scratch and graph) used by InFlight
@@ -119,9 +121,15 @@ class InFlight(object):
         self._model = model
         self.depth = depth
         self._lanes = {}
+        self._generation = model._plans.generation
         self._next = 0
 
     def _lane(self, x, k):
+        if self._generation != self._model._plans.generation:      # load_state_dict / .to(): weights changed
+            if any(lane.ticket is not None for lane in self._lanes.values()):
+                raise PPYoloHipError('the model changed while batches were in flight: collect their tickets first')
+            self._lanes = {}
+            self._generation = self._model._plans.generation
         key = (tuple(x.shape), str(x.device), k)
         lane = self._lanes.get(key)
         if lane is None:

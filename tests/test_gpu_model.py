@@ -296,6 +296,22 @@ def test_two_lanes_are_bit_stable(math, monkeypatch):
                 assert torch.equal(g, want[pair[k]][nm]), 'round %d lane %d: %s differs from the solo run' % (r, k, nm)
 
 
+def test_in_flight_follows_new_weights():
+    """load_state_dict drops the plans; lanes built from them must not keep computing with the old weights."""
+    cfg = PPYOLO_r18vd_Config()
+    model, sd = build_model(cfg, 0, 'cuda')
+    x, ims = synth.synth_images(2, 224, seed=9).cuda(), synth.synth_im_size(2).cuda()
+    pipe = model.in_flight(2)
+    first = pipe.submit(x, ims).result()
+    sd2 = synth.synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1)
+    model.load_state_dict(sd2)
+    want = [p.clone() for p in model(x, ims)]
+    got = pipe.submit(x, ims).result()
+    assert any(a.shape != b.shape or not torch.equal(a, b) for a, b in zip(first, want))      # the weights do matter
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_two_branch_plan_is_opt_in_and_same_answer(monkeypatch):
     """PPYOLO_HIP_STREAMS=2 (independent branches on a second stream; eager here) gives the one-branch results."""
     cfg = PPYOLO_r18vd_Config()
