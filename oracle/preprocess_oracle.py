@@ -10,7 +10,9 @@ Restates `Decode.process_image` of miemie2013/Pytorch-PPYOLO (reference model/de
 Nothing in the product (`pytorch-ppyolo_amd/`) may import this file; allowed importers are `tests/`,
 `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg.
 
-PARITY UNPINNED.  The resize is third-party arithmetic: OpenCV (`cv2.resize`), which is NOT installed in this image and
+PINNING.  NormalizeImage + Permute are pinned to the reference's own classes (fixture tests/golden/g8_preprocess.npz,
+made by tools/make_goldens.py g8 from /root/reference; tests/test_preprocess.py replays it).  The RESIZE IS UNPINNED:
+it is third-party arithmetic, OpenCV (`cv2.resize`), which is NOT installed in this image and
 which the reference pins to no version (requirements: "opencv-python").  What follows restates OpenCV 4.x's published
 algorithm for 8-bit INTER_CUBIC (modules/imgproc/src/resize.cpp: `interpolateCubic` with A = -0.75, the coordinate map
 (dx + 0.5) * scale - 0.5, replicated borders, coefficients rounded to 11-bit fixed point, `HResizeCubic<uchar,int,short>`

@@ -77,6 +77,28 @@ def test_normalisation_table_is_the_numpy_expression():
         assert np.array_equal(lut[c], want[:, 0, c])
 
 
+def test_normalise_permute_pinned_to_reference_golden():
+    """tests/golden/g8_preprocess.npz = the reference's own NormalizeImage + Permute classes on a uint8 image
+    (tools/make_goldens.py g8): the oracle restates them bit for bit, and so does the product's table -- every grey
+    level occurs in every channel of the fixture.  (The cv2.resize in front stays unpinned: no cv2 here.)"""
+    import os
+    from ppyolo_hip.preprocess import normalisation_table
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g8_preprocess.npz'))
+    img, want = g['image'], g['normalized_chw']
+    mean, std = g['mean'].tolist(), g['std'].tolist()
+    got = pre.normalize(img.copy(), mean, std, True)
+    got = np.swapaxes(np.swapaxes(got, 1, 2), 1, 0)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    lut = normalisation_table(mean, std, True)
+    for c in range(3):
+        assert np.array_equal(lut[c][img[:, :, c]], want[c])
+    # the reference configuration the fixture was made with is the one the product configs carry
+    cfg = PPYOLO_2x_Config()
+    assert cfg.normalizeImage['mean'] == mean and cfg.normalizeImage['std'] == std
+    assert int(g['to_rgb']) == int(cfg.decodeImage['to_rgb']) and int(g['interp']) == cfg.resizeImage['interp'] == 2
+    assert int(g['target_size']) == cfg.test_cfg['target_size']
+
+
 def test_process_image_layout():
     img = rand_image(60, 80, 3)
     pimage, im_size = pre.process_image(img, 64)

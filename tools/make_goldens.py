@@ -354,7 +354,33 @@ def g6_g7_models():
         print('   %s: %d candidates, rows %s' % (tag, ncand, [tuple(p.shape) for p in preds]))
 
 
-ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models)
+def g8_preprocess():
+    """NormalizeImage + Permute of the reference's Decode.process_image (model/decode_np.py:136-137), run by the
+    reference's own classes on uint8 images that are ALREADY S x S (the cv2.resize in front cannot run here: cv2 is not
+    installed, a constants-only stub lets tools/transform.py import), plus the resize scale factors ResizeImage computes."""
+    import types
+    stub = types.ModuleType('cv2')
+    for i, k in enumerate(('INTER_NEAREST', 'INTER_LINEAR', 'INTER_CUBIC', 'INTER_AREA', 'INTER_LANCZOS4')):
+        setattr(stub, k, i)
+    stub.COLOR_BGR2RGB = 4
+    sys.modules.setdefault('cv2', stub)
+    tr = _load('ref_transform', os.path.join(REF, 'tools', 'transform.py'))
+    cfg = PPYOLO_2x_Config()
+    norm = tr.NormalizeImage(**cfg.normalizeImage)
+    perm = tr.Permute(**cfg.permute)
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, size=(64, 64, 3)).astype(np.uint8)
+    img[:4, :64, :] = np.arange(256, dtype=np.uint8).reshape(4, 64, 1)         # every grey level in every channel
+    sample = perm(norm({'image': img.copy()}, None), None)
+    out = sample['image']
+    assert out.dtype == np.float32 and out.shape == (3, 64, 64)
+    save('g8_preprocess', image=img, normalized_chw=out, mean=np.array(cfg.normalizeImage['mean']),
+         std=np.array(cfg.normalizeImage['std']), to_rgb=np.array(int(cfg.decodeImage['to_rgb'])),
+         interp=np.array(cfg.resizeImage['interp']), target_size=np.array(cfg.test_cfg['target_size']))
+
+
+ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
+           g8=g8_preprocess)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
