@@ -119,6 +119,28 @@ def test_demo_call_surface():
     assert np.abs(scores - ref[:, 1].numpy()).max() <= 1e-4
 
 
+def test_decode_harness_golden():
+    """The reference's own Decode.detect_image / detect_batch on numpy inputs (tests/golden/g9_decode_harness.npz,
+    made from /root/reference by tools/make_goldens.py g9) against this repo's Decode on the same inputs."""
+    import os
+    from model.decode_np import Decode
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g9_decode_harness.npz'))
+    S, N, wseed, iseed = [int(v) for v in g['meta']]
+    cfg = PPYOLO_r18vd_Config()
+    model, _ = build_model(cfg, wseed, 'cuda')
+    dec = Decode(model, ['c%d' % i for i in range(80)], True, cfg, for_test=True)
+    x = synth.synth_images(N, S, seed=iseed).numpy()
+    ims = g['im_size']
+    image, boxes, scores, classes = dec.detect_image(None, x[:1], ims[:1], draw_image=False)
+    assert image is None and boxes.dtype == np.float32 and scores.dtype == np.float32 and classes.dtype == np.int32
+    assert np.array_equal(classes, g['classes'])
+    assert np.abs(scores - g['scores']).max() <= 1e-4 and np.abs(boxes - g['boxes']).max() <= 1e-3
+    imgs, bb, ss, cc = dec.detect_batch([None] * N, x, ims, draw_image=False)
+    for i in range(N):
+        assert np.array_equal(cc[i], g['b_classes%d' % i])
+        assert np.abs(ss[i] - g['b_scores%d' % i]).max() <= 1e-4 and np.abs(bb[i] - g['b_boxes%d' % i]).max() <= 1e-3
+
+
 def test_empty_result_sentinel():
     """Nothing above the threshold -> the reference's [[-1]*6] row (matrix_nms.py:113)."""
     cfg = PPYOLO_r18vd_Config()

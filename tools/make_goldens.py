@@ -379,8 +379,37 @@ def g8_preprocess():
          interp=np.array(cfg.resizeImage['interp']), target_size=np.array(cfg.test_cfg['target_size']))
 
 
+def _cv2_stub():
+    import types
+    stub = types.ModuleType('cv2')
+    for i, k in enumerate(('INTER_NEAREST', 'INTER_LINEAR', 'INTER_CUBIC', 'INTER_AREA', 'INTER_LANCZOS4')):
+        setattr(stub, k, i)
+    stub.COLOR_BGR2RGB = 4
+    sys.modules.setdefault('cv2', stub)
+
+
+def g9_decode_harness():
+    """The host harness on top of the model -- the reference's Decode.predict / detect_image / detect_batch
+    (model/decode_np.py:41-96, :142-150) on numpy inputs, with the constants-only cv2 stub (nothing is drawn)."""
+    _cv2_stub()
+    from model.decode_np import Decode
+    cfg = PPYOLO_r18vd_Config()
+    m, _ = build_ref(cfg, 0)
+    dec = Decode(m, ['c%d' % i for i in range(80)], False, cfg, for_test=True)
+    x = synth.synth_images(2, 320, seed=1234).numpy()
+    ims = np.array([[480, 640], [375, 500]], dtype=np.int32)
+    with torch.no_grad():
+        image, boxes, scores, classes = dec.detect_image(None, x[:1], ims[:1], draw_image=False)
+        _, bb, ss, cc = dec.detect_batch([None, None], x, ims, draw_image=False)
+    assert boxes.dtype == np.float32 and scores.dtype == np.float32 and classes.dtype == np.int32
+    arrs = dict(meta=np.array([320, 2, 0, 1234]), im_size=ims, boxes=boxes, scores=scores, classes=classes)
+    for i in range(2):
+        arrs['b_boxes%d' % i], arrs['b_scores%d' % i], arrs['b_classes%d' % i] = bb[i], ss[i], cc[i]
+    save('g9_decode_harness', **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess)
+           g8=g8_preprocess, g9=g9_decode_harness)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
