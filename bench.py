@@ -44,6 +44,9 @@ WORKLOADS = {
     'r50vd_608': dict(cfg='PPYOLO_2x_Config', size=608, model='PPYOLO ResNet50-vd (DCNv2, CoordConv, SPP)'),
     'r18vd_416': dict(cfg='PPYOLO_r18vd_Config', size=416, model='PPYOLO_r18vd'),
     'r18vd_320': dict(cfg='PPYOLO_r18vd_Config', size=320, model='PPYOLO_r18vd'),
+    # the other configurations the reference publishes demo FPS for (README.md:13-17), batch 1
+    'r50vd_320': dict(cfg='PPYOLO_2x_Config', size=320, model='PPYOLO ResNet50-vd (DCNv2, CoordConv, SPP)'),
+    'r18vd_608': dict(cfg='PPYOLO_r18vd_Config', size=608, model='PPYOLO_r18vd'),
 }
 
 
