@@ -594,7 +594,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     // CU) is the one that won most layers of the measured tables; narrow / shallow layers stay on the fp32 kernels
     if (cfg < 0 && w_x3 && K >= 48 && g.chunks >= 4) c = kNumCfgs + 4;
     if (cfg < 0 && w_f16x2 && scale_f16x2 && amax_in && (!posbias || posbias_f16x2) && K >= 48 && g.chunks >= 4)
-        c = kNumCfgs + ppy_x3_num_configs() / 2 + 4;      // the same tile on the f16x2 kernel
+        c = kNumCfgs + ppy_x3_f16_base() + 4;      // the same tile on the f16x2 kernel
     if (s > 1) {
         const size_t need = (size_t)s * g.M * K * sizeof(float);
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;
@@ -608,6 +608,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     p.stride = stride; p.pad = pad; p.act = act; p.ups = upsample2x ? 1 : 0;
     p.M = g.M; p.Kred = g.Kred; p.cchunks = C / BK; p.chunks_total = g.chunks;
     p.chunks_per_split = ceil_div(g.chunks, s);
+    p.nstages = 2;
     p.trace = g_trace;
     hipStream_t st = (hipStream_t)stream;
     rc = dispatch_cfg(p, c, s, st);

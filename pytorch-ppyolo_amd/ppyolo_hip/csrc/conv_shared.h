@@ -15,6 +15,7 @@ struct ConvArgs {
     int x_ld, res_ld, y_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
     int M, Kred, cchunks, chunks_total, chunks_per_split;
+    int nstages;                 // conv_x3 kernels: LDS stages (2..4 chunks resident; 2 in every other kernel)
     unsigned long long *trace;   // debug: per-workgroup timeline (ppy_debug_set_trace), NULL in production
 };
 
@@ -24,6 +25,7 @@ struct Geometry {
 
 // conv_x3.hip: configurations of the split-bf16 kernel (ids local to that file)
 int ppy_x3_num_configs();
+int ppy_x3_f16_base();        // first local id of the f16x2 scheme
 int ppy_x3_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
 
 namespace {

@@ -369,8 +369,15 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     if (p.trace) c_loop = __builtin_amdgcn_s_memtime();
     if (nchunks > 0) {
         Frag f0, f1;
-        issue(0);
-        if (nchunks > 1) issue(1);
+        // NS = p.nstages chunks are kept resident / in flight (2..4).  All NS stage slots are requested here, slots past
+        // the end of the reduction as out-of-range dummies, so that the number of outstanding DMA pieces is the same
+        // (NS-1)*G at every mid-chunk wait below.
+        const int NS = p.nstages;
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            issue_begin(sidx, sidx < nchunks);
+#pragma unroll
+            for (int d = 0; d < G; ++d) issue_piece(d);
+        }
         if constexpr (F16) {       // after the first DMA requests, so that this latency (a division, 8 loads) hides behind theirs
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -383,10 +390,13 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                 inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
             }
         }
-        if (nchunks > 1) {
+        // chunk 0 has landed once at most the NS-1 later requests are outstanding
+        if (NS == 2) {
             wait_vmcnt<G>();
+        } else if (NS == 3) {
+            wait_vmcnt<2 * G>();
         } else {
-            wait_vmcnt<0>();
+            wait_vmcnt<3 * G>();
         }
         __builtin_amdgcn_s_barrier();
         {   // operands of (chunk 0, k-step 0): not overlapped with anything
@@ -423,13 +433,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
             step(f0, f1, st, S1(), std::false_type());
             // mid-chunk: every LDS read of chunk k has returned (here and, after the barrier, in all waves)
             // and chunk k+1 -- issued one chunk ago -- has landed: refill this stage with chunk k+2
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (NS == 2) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (NS == 3) {               // chunk k+2 may still be in flight
+                wait_vmcnt<G>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {                            // chunks k+2, k+3
+                wait_vmcnt<2 * G>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
 #if PPY_X3_ABL < 4
             __builtin_amdgcn_s_barrier();
 #endif
-            issue_begin(st, k + 2 < nchunks);
+            issue_begin(st, k + NS < nchunks);
             // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1 (garbage after the last chunk, unused)
-            st ^= 1;
+            st = st + 1 == NS ? 0 : st + 1;
             step(f1, f0, st, S0(), std::true_type());
         }
         // the epilogue reuses the LDS: all reads returned, and the (out-of-range, zero-filling) DMA pieces the
@@ -499,7 +517,7 @@ int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStrea
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+                                160 * 1024) != hipSuccess)      // (the stage count is a launch parameter)
             return PPY_ERR_LAUNCH;
         attr_done = true;
     }
@@ -508,14 +526,19 @@ int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStrea
 }
 
 template <int BM, int BN, int WM, int WN, bool F16>
-int launch_x3(ConvArgs p, int splits, hipStream_t stream) {
+int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     // 32-bit per-lane DMA offsets
     constexpr int NP = F16 ? 2 : 3;
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
     const long long wbytes = (long long)p.K * p.Kred * 2 * NP;
     if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
     constexpr int NW = (BM / WM) * (BN / WN);
-    size_t lds = (size_t)2 * (BM * 128 + NP * BN * 64);
+    // as many LDS stages as asked for, as far as 160 KB of LDS and the 6-bit vmcnt allow (ids of deeper variants of a big
+    // tile then alias the deepest one that fits)
+    constexpr int STAGE_BYTES = BM * 128 + NP * BN * 64, PIECES = BM / (8 * NW) + NP * BN / (16 * NW);
+    while (nstages > 2 && (nstages * STAGE_BYTES > 160 * 1024 || (nstages - 1) * PIECES > 63)) --nstages;
+    size_t lds = (size_t)nstages * STAGE_BYTES;
+    p.nstages = nstages;
     const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
     p.chunks_total = p.R * p.S * (p.C / 32);
@@ -538,17 +561,17 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream) {
 }
 
 template <bool F16>
-int dispatch_scheme(const ConvArgs &p, int c, int s, hipStream_t st) {
+int dispatch_scheme(const ConvArgs &p, int c, int s, hipStream_t st, int ns = 2) {
     switch (c) {
-        case 0: return launch_x3<256, 128, 64, 128, F16>(p, s, st);
-        case 1: return launch_x3<128, 128, 64, 64, F16>(p, s, st);
-        case 2: return launch_x3<128, 128, 32, 128, F16>(p, s, st);
-        case 3: return launch_x3<256, 64, 64, 64, F16>(p, s, st);
-        case 4: return launch_x3<128, 64, 32, 64, F16>(p, s, st);
-        case 5: return launch_x3<256, 128, 64, 64, F16>(p, s, st);
-        case 6: return launch_x3<128, 256, 64, 128, F16>(p, s, st);
-        case 7: return launch_x3<64, 128, 32, 64, F16>(p, s, st);
-        case 8: return launch_x3<64, 64, 32, 32, F16>(p, s, st);
+        case 0: return launch_x3<256, 128, 64, 128, F16>(p, s, st, ns);
+        case 1: return launch_x3<128, 128, 64, 64, F16>(p, s, st, ns);
+        case 2: return launch_x3<128, 128, 32, 128, F16>(p, s, st, ns);
+        case 3: return launch_x3<256, 64, 64, 64, F16>(p, s, st, ns);
+        case 4: return launch_x3<128, 64, 32, 64, F16>(p, s, st, ns);
+        case 5: return launch_x3<256, 128, 64, 64, F16>(p, s, st, ns);
+        case 6: return launch_x3<128, 256, 64, 128, F16>(p, s, st, ns);
+        case 7: return launch_x3<64, 128, 32, 64, F16>(p, s, st, ns);
+        case 8: return launch_x3<64, 64, 32, 32, F16>(p, s, st, ns);
     }
     return PPY_ERR_BAD_ARG;
 }
@@ -584,7 +607,9 @@ __global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, 
 
 }  // namespace
 
-int ppy_x3_num_configs() { return 2 * kNumX3; }      // [0, 9): bf16x3, [9, 18): f16x2
+// local ids: [0, 9) bf16x3, [9, 18) f16x2 (two LDS stages), [18, 27) f16x2 with three stages, [27, 36) with four
+int ppy_x3_num_configs() { return 4 * kNumX3; }
+int ppy_x3_f16_base() { return kNumX3; }
 
 int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (c < kNumX3) {
@@ -597,7 +622,8 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     ConvArgs q = p;
     q.scale = p.scale_f16;
     q.posb = p.posb ? p.posb_f16 : nullptr;
-    return dispatch_scheme<true>(q, c - kNumX3, s, st);
+    const int local = c - kNumX3;
+    return dispatch_scheme<true>(q, local % kNumX3, s, st, 2 + local / kNumX3);
 }
 
 extern "C" int ppy_conv2d_split_weights_f16x2(const float *w_krsc, int K, long long kred, const float *scale,

@@ -46,7 +46,7 @@ _TUNED_PATHS = {'fp32': os.path.join(_HERE, 'tuned_gfx950.json'), 'bf16x3': os.p
                 'f16x2': os.path.join(_HERE, 'tuned_gfx950_f16x2.json')}
 _tuned = {}
 NUM_FP32_CFGS = 31       # tile configuration ids below this are the exact-fp32 MFMA kernels (conv_igemm.hip)
-NUM_X3_CFGS = 9          # then the bf16x3 kernels [31, 40), then the f16x2 kernels [40, 49) (conv_x3.hip)
+NUM_X3_CFGS = 9          # then the bf16x3 kernels [31, 40), then the f16x2 kernels [40, 67): 9 tiles x {2, 3, 4} LDS stages
 
 
 def math_mode():

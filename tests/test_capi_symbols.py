@@ -41,7 +41,7 @@ def test_binding_covers_header(libpath):
 def test_pick_is_pure_host_logic(libpath):
     from ppyolo_hip import ops
     cfg, split = ops.conv2d_pick(8, 19, 19, 2048, 512, 1, 1, 1, 0)
-    assert 0 <= cfg < 49 and split >= 1
+    assert 0 <= cfg < 67 and split >= 1
     # bad geometry is rejected, not crashed on
     from ppyolo_hip._lib import PPYoloHipError
     with pytest.raises(PPYoloHipError):

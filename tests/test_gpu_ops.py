@@ -58,7 +58,7 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-NUM_CFGS = 49      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 (conv_x3.hip)
+NUM_CFGS = 67      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 with 2 LDS stages + 9 with 3 + 9 with 4 (conv_x3.hip)
 
 
 @pytest.mark.parametrize('cfg', range(NUM_CFGS))
