@@ -74,7 +74,9 @@ void ppy_note_hip_error(int hip_error);      /* internal: set by the launch path
  * return PPY_ERR_BAD_ARG.
  * w_f16x2 / scale_f16x2: NULL, or the outputs of ppy_conv2d_split_weights_f16x2: the weights times a per-output-
  * channel power of two as two fp16 planes ([2][K][R][S][C], 4*K*R*S*C bytes) and `scale` with the inverse of that
- * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40): 2-term fp16 split of both operands,
+ * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40; 9 tiles, ids 40-48 with two LDS stages,
+ * 49-57 the same tiles with three and 58-66 with four chunks resident / in flight, as far as 160 KB of LDS allow):
+ * 2-term fp16 split of both operands,
  * 3 partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation; the activations of an image are scaled on the
  * fly by the power of two that puts that image's maximum into [2^13, 2^14), read from `amax_in`.  Error vs fp64 at the level of
  * the exact-fp32 fma chain (tools/probes/f16x2_probe.hip, profiles/r01_f16x2_numerics.txt).  Needs amax_in, and with a

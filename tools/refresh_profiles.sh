@@ -16,3 +16,7 @@ for n in trace pmc_sq pmc_fetch pmc_write pmc_lds; do cp gpurun_out/prof_$TAG/$n
 for f in $O/${TAG}_bench_*.json; do python -c "
 import json,sys
 d=json.loads([l for l in open('$f') if l.startswith('{')][-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"; done
+for spec in "r50vd_608 1" "r50vd_320 1" "r18vd_608 1" "r18vd_416 1"; do
+  set -- $spec
+  python bench.py --workload $1 --batch $2 --no-cpu-baseline --no-alt-math --no-host-input > $O/${TAG}_bench_$1_bs$2.json 2>/dev/null
+done
