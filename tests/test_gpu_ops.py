@@ -101,6 +101,28 @@ def test_conv_every_tile_config(cfg, splitk):
     assert torch.all(yout[..., :8] == -7.0), 'wrote outside the output channel slice'
 
 
+@pytest.mark.parametrize('cfg', range(49, 67))
+def test_deep_stage_variants_on_short_reductions(cfg):
+    """3- and 4-stage f16x2 variants when the reduction has fewer chunks than stages (1, 2, 3 chunks; split-K leaving one
+    chunk per split): the unused stage slots are requested as out-of-range dummies and must not leak into the result."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(500 + cfg)
+    for C, R, splitk in ((32, 1, 1), (64, 1, 1), (96, 1, 1), (64, 1, 2), (32, 3, 9), (160, 1, 2)):
+        N, H, W, K = 2, 17, 9, 72
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(K, C, R, R, generator=g) * 0.1
+        sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+        ref = F.relu(F.conv2d(x, w, None, 1, (R - 1) // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        y = torch.full((N, H, W, K), 9.0).cuda()
+        ws = torch.empty(1 << 20).cuda()
+        ops.conv2d_bn_act(ops.View(xd), wk, sc.cuda(), sh.cuda(), ops.View(y), 1, (R - 1) // 2, 'relu', cfg=cfg, splitk=splitk,
+                          ws=ws, w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
+        torch.cuda.synchronize()
+        close(nchw(y), ref, what='cfg %d C%d R%d split %d' % (cfg, C, R, splitk))
+
+
 def test_conv_stride2_upsample_1x1():
     from ppyolo_hip import ops
     g = torch.Generator().manual_seed(7)
