@@ -3,6 +3,8 @@ rows=json.load(open(sys.argv[1]))
 X3={40:'f16 256x128',41:'f16 128x128a',42:'f16 128x128b',43:'f16 256x64',44:'f16 128x64',45:'f16 256x128w8',46:'f16 128x256',47:'f16 64x128',48:'f16 64x64',39:'x3 64x64',31:'x3 256x128',32:'x3 128x128a',33:'x3 128x128b',34:'x3 256x64',35:'x3 128x64',36:'x3 256x128w8',37:'x3 128x256',38:'x3 64x128'}
 def nm(c):
     if c is None: return ''
+    if c is not None and c >= 49:            # f16x2 tiles with 3 (49..57) / 4 (58..66) LDS stages
+        return X3.get(40 + (c - 49) % 9, '?') + '/%d' % (3 + (c - 49) // 9)
     return X3.get(c, 'f32 cfg%d' % c)
 agg={}
 for r in rows:
