@@ -73,7 +73,8 @@ void ppy_note_hip_error(int hip_error);      /* internal: set by the launch path
  * profiles/r01_bf16x3_numerics.txt), 6/16 of the fp32-MFMA cost.  Without w_x3 those ids
  * return PPY_ERR_BAD_ARG.
  * w_f16x2 / scale_f16x2: NULL, or the outputs of ppy_conv2d_split_weights_f16x2: the weights times a per-output-
- * channel power of two as two fp16 planes ([2][K][R][S][C], 4*K*R*S*C bytes) and `scale` with the inverse of that
+ * channel power of two as two fp16 planes (4*K*R*S*C bytes; opaque layout [2][R*S*C/32][K][32]: the 32-deep reduction chunk is
+ * the outer index, so that the 16 weight rows one DMA instruction fetches are one contiguous KB) and `scale` with the inverse of that
  * power folded in.  They make the "f16x2" kernels selectable (cfg ids >= 40; 9 tiles, ids 40-48 with two LDS stages,
  * 49-57 the same tiles with three and 58-66 with four chunks resident / in flight, as far as 160 KB of LDS allow):
  * 2-term fp16 split of both operands,

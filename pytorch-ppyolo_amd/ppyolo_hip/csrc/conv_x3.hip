@@ -32,6 +32,9 @@
 
 #include <type_traits>
 
+#ifndef PPY_X3_BBLOCK
+#define PPY_X3_BBLOCK 1   // f16x2 weight planes in [chunk][K][32] order (0 = [K][Kred], for A/B rebuilds)
+#endif
 #ifndef PPY_X3_XCD
 #define PPY_X3_XCD 1      // XCD-contiguous tile order (0 = plain blockIdx order, for A/B rebuilds: +1.3 % on the R50 step)
 #endif
@@ -196,7 +199,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
             const int plane = rb / BN, nrow = rb - plane * BN;
             const int scol = dslot ^ ((rb >> 2) & 3);
             const int k = min(n0 + nrow, p.K - 1);             // rows >= K are masked at store
-            b_off[j] = (unsigned)(plane * plane_bytes + (long long)k * p.Kred * 2 + scol * 16);
+            b_off[j] = (F16 && PPY_X3_BBLOCK) ? (unsigned)(plane * plane_bytes + (long long)k * 64 + scol * 16)      // [chunk][K][32] planes
+                           : (unsigned)(plane * plane_bytes + (long long)k * p.Kred * 2 + scol * 16);
         }
     }
 
@@ -215,7 +219,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     bool cur_have = false;
     auto issue_begin = [&](int stage, bool have) {
         const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
-        const long long b_uni = ((long long)l_tap * p.C + l_cc * 32) * 2;
+        const long long b_uni = (F16 && PPY_X3_BBLOCK) ? ((long long)l_tap * (p.C / 32) + l_cc) * p.K * 64
+                                    : ((long long)l_tap * p.C + l_cc * 32) * 2;
         cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
         cur_rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? b_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
         cur_tapbit = have ? (1u << l_tap) : 0u;
@@ -615,8 +620,11 @@ __global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, 
         const float v = row[i] * sw;
         const _Float16 h0 = (_Float16)v;
         const _Float16 h1 = (_Float16)(v - (float)h0);
-        out[(long long)k * kred + i] = __builtin_bit_cast(unsigned short, h0);
-        out[n + (long long)k * kred + i] = __builtin_bit_cast(unsigned short, h1);
+        // plane layout [chunk][K][32]: the 16 rows x 64 B that one DMA instruction of the conv kernel fetches are one
+        // contiguous KB (8 whole cache lines instead of 16 half lines of rows that are kred*2 bytes apart)
+        const long long o = PPY_X3_BBLOCK ? ((i >> 5) * K + k) * 32 + (i & 31) : (long long)k * kred + i;
+        out[o] = __builtin_bit_cast(unsigned short, h0);
+        out[n + o] = __builtin_bit_cast(unsigned short, h1);
     }
     if (tid == 0) scale_out[k] = scale[k] * inv;
 }
