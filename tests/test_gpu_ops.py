@@ -123,6 +123,27 @@ def test_deep_stage_variants_on_short_reductions(cfg):
         close(nchw(y), ref, what='cfg %d C%d R%d split %d' % (cfg, C, R, splitk))
 
 
+def test_f16x2_weight_planes_layout_and_exactness():
+    """ppy_conv2d_split_weights_f16x2: planes are chunk-major [2][Kred/32][K][32] (include/ppyolo_hip.h), every channel is
+    scaled by its own power of two, hi + lo reproduces w * s to 2^-22 relative, and scale_out = scale / s."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(21)
+    K, R, C = 40, 3, 64
+    w = (torch.randn(K, R, R, C, generator=g) * torch.exp(2 * torch.randn(K, 1, 1, 1, generator=g))).cuda()
+    scale = (torch.rand(K, generator=g) + 0.5).cuda()
+    planes, sc = ops.split_weights_f16x2(w, scale)
+    kred = R * R * C
+    pl = planes.view(torch.float16).view(2, kred // 32, K, 32).permute(0, 2, 1, 3).reshape(2, K, kred).double()
+    s_w = (scale.double() / sc.double())                               # the per-channel power of two
+    assert torch.equal(torch.log2(s_w), torch.log2(s_w).round()), 'weight scales are not powers of two'
+    mx = w.reshape(K, -1).abs().amax(dim=1).double() * s_w
+    assert (mx >= 2.0 ** 13).all() and (mx < 2.0 ** 14).all()
+    want = w.reshape(K, kred).double() * s_w[:, None]
+    err = (pl[0] + pl[1] - want).abs()
+    assert (err <= want.abs() * 2.0 ** -22 + 2.0 ** -25).all()
+    assert (pl[1].abs() <= pl[0].abs() * 2.0 ** -10 + 2.0 ** -24).all()       # lo is the rounding residual of hi
+
+
 def test_conv_stride2_upsample_1x1():
     from ppyolo_hip import ops
     g = torch.Generator().manual_seed(7)
