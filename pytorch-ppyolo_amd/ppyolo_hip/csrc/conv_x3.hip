@@ -39,7 +39,10 @@
 #define PPY_X3_XCD 1      // XCD-contiguous tile order (0 = plain blockIdx order, for A/B rebuilds: +1.3 % on the R50 step)
 #endif
 #ifndef PPY_X3_ABL
-#define PPY_X3_ABL 0      // ablation switch for experiments (tools/x3_ablate.sh): 1 = no DMA in the loop, 2 = no split
+#define PPY_X3_ABL 0      // ablation switch for experiments (tools/x3_ablate.sh; results are garbage, only the timing means something):
+                          // 1 = no DMA in the loop, 2 = no split, 3 = neither, 4 = no mid-chunk barrier either, 5 = MFMA only,
+                          // 6 = everything, but every DMA piece out of range (no memory traffic), 7 = operand delivery only (DMA +
+                          // barriers), 8 = 7 with the weight pieces only, 9 = 7 with the activation pieces only.  DESIGN.md 8 item 1.
 #endif
 
 namespace {
@@ -218,6 +221,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     unsigned cur_tapbit = 0, cur_lds = 0;
     bool cur_have = false;
     auto issue_begin = [&](int stage, bool have) {
+        if (PPY_X3_ABL == 6) have = false;       // ablation: every piece out of range (issue + LDS zero-fill cost, no memory traffic)
         const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
         const long long b_uni = (F16 && PPY_X3_BBLOCK) ? ((long long)l_tap * (p.C / 32) + l_cc) * p.K * 64
                                     : ((long long)l_tap * p.C + l_cc * 32) * 2;
@@ -233,9 +237,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     };
     auto issue_piece = [&](int d) {       // d in [0, G): compile-time after unrolling
         if (d < A_PASS) {
+            if (PPY_X3_ABL == 8) return;                    // (ablation: weight pieces only)
             const unsigned off = (a_ok[d] & cur_tapbit) ? a_off[d] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
         } else {
+            if (PPY_X3_ABL == 9) return;                    // (ablation: activation pieces only)
             const int j = d - A_PASS;
             const unsigned off = cur_have ? b_off[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rb, (lds_ptr)(smem + cur_lds + A_BYTES + j * NW * 1024), 16, off, 0,
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         float ra[TM][4], rb[TM][4];
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            {   // MFMA m, term-major: consecutive MFMAs use different accumulators
+            if (PPY_X3_ABL < 7) {   // MFMA m, term-major: consecutive MFMAs use different accumulators
                 const int t = T0 + m / (TM * TN), i = (m / TN) % TM, j = m % TN;
                 if constexpr (F16)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][ta[t]]),
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
             for (int u = 0; u < RPS; ++u) {
                 const int r = m * RPS + u;
-                if (PPY_X3_ABL >= 5 || r >= NR) {
+                if ((PPY_X3_ABL >= 5 && PPY_X3_ABL != 6) || r >= NR) {
                 } else if (r < NRA) {
                     raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
                 } else {
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                     nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
                 }
             }
-            if (DMA && PPY_X3_ABL != 1 && PPY_X3_ABL < 3 && m % DSTRIDE == DSTRIDE - 1 && m / DSTRIDE < ND) {
+            if (DMA && PPY_X3_ABL != 1 && (PPY_X3_ABL < 3 || PPY_X3_ABL >= 6) && m % DSTRIDE == DSTRIDE - 1 && m / DSTRIDE < ND) {
 #pragma unroll
                 for (int u = 0; u < DPS; ++u)
                     if ((m / DSTRIDE) * DPS + u < G) issue_piece((m / DSTRIDE) * DPS + u);
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
                 for (int u = 0; u < PER; ++u) {
                     const int sl = (m - LEAD) * PER + u;
-                    if (sl < NSL && PPY_X3_ABL != 2 && PPY_X3_ABL < 3) {
+                    if (sl < NSL && PPY_X3_ABL != 2 && (PPY_X3_ABL < 3 || PPY_X3_ABL == 6)) {
                         const int st = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q = pr % 4;
                         const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
                         if constexpr (F16) {
