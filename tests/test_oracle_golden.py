@@ -105,3 +105,22 @@ def test_g7_end_to_end(golden, tag, cfgc, model_shapes):
         ref = T(g['pred%d' % i])
         assert p.shape == ref.shape
         assert torch.equal(p, ref)
+
+
+def test_g9_decode_harness(golden, model_shapes):
+    """The reference's Decode.detect_image / detect_batch (numpy in, (boxes, scores, classes) out) = the oracle's
+    forward split the same way (model/decode_np.py:41-96)."""
+    g = golden('g9_decode_harness')
+    S, N, seed, iseed = [int(v) for v in g['meta']]
+    cfg = PPYOLO_r18vd_Config()
+    sd = synth.synth_state_dict(model_shapes(cfg), seed=seed)
+    x = synth.synth_images(N, S, seed=iseed)
+    ims = T(g['im_size']).float()
+    one = orc.ppyolo_forward(sd, cfg, x[:1], ims[:1])[0].numpy()
+    assert np.array_equal(one[:, 2:], g['boxes']) and np.array_equal(one[:, 1], g['scores'])
+    assert np.array_equal(one[:, 0].astype(np.int32), g['classes'])
+    both = orc.ppyolo_forward(sd, cfg, x, ims)
+    for i, p in enumerate(both):
+        p = p.numpy()
+        assert np.array_equal(p[:, 2:], g['b_boxes%d' % i]) and np.array_equal(p[:, 1], g['b_scores%d' % i])
+        assert np.array_equal(p[:, 0].astype(np.int32), g['b_classes%d' % i])
