@@ -21,8 +21,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-res
 # that CU (two batches in flight on two streams) intermittently return a wrong HIGH half for one 16-lane pass -- the
 # decode kernel's y0/y1 came out as the box centre in 4-40 % of the steps, bit-exactly reproducible with
 # tools/pk_hazard_probe.py, never with one stream, never with the scalar forms (0 mismatches in tools/lane_soak.py).
-# The scalar forms are also not slower here (R50-608 bs8, two lanes: 1826 vs 1790 img/s).  tests/test_build.py checks
-# the built code objects.
+# The scalar forms are also not slower here (R50-608 bs8, two lanes: 1826 vs 1790 img/s).
+# tests/test_capi_symbols.py::test_no_packed_fp32_ops_in_device_code disassembles the code objects of the shipped .so.
 NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 if os.environ.get('PPY_ALLOW_PACKED_FP32', '0') != '1':          # (the probe's reproducer builds with packed ops)
     FLAGS += NO_PACKED_FP32
@@ -76,20 +76,46 @@ def build(force=False, verbose=True, out=None):
     return LIB
 
 
-def packed_fp32_ops(obj):
-    """Number of v_pk_{add,mul,fma}_f32 instructions in the gfx950 code object bundled in `obj` (a .o of this build)."""
+def device_code_objects(path):
+    """The gfx950 code objects embedded in an ELF of this build -- a .o (one offload bundle) or the linked .so (one
+    bundle per translation unit, concatenated in .hip_fatbin).  Bundle layout (clang-offload-bundler, uncompressed):
+    24-byte magic, u64 entry count, then per entry u64 offset, u64 size, u64 triple length, triple."""
+    import struct
+    import tempfile
+    llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    with tempfile.TemporaryDirectory() as td:
+        fb = os.path.join(td, 'fb.bin')
+        subprocess.check_call([os.path.join(llvm, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', path, fb])
+        blob = open(fb, 'rb').read()
+    out, pos = [], blob.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from('<Q', blob, pos + 24)
+        q = pos + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if 'gfx950' in triple and size:
+                out.append(blob[pos + off:pos + off + size])
+        pos = blob.find(magic, pos + 1)
+    return out
+
+
+def packed_fp32_ops(path):
+    """Number of v_pk_{add,mul,fma}_f32 instructions in the gfx950 device code of `path` (a .o of this build or the .so)."""
     import re
     import tempfile
     llvm = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+    total = 0
     with tempfile.TemporaryDirectory() as td:
-        fb, co = os.path.join(td, 'fb.bin'), os.path.join(td, 'dev.co')
-        subprocess.check_call([os.path.join(llvm, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', obj, fb])
-        if os.path.getsize(fb) == 0:         # a translation unit without device code (capi.hip)
-            return 0
-        subprocess.check_call([os.path.join(llvm, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fb,
-                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
-        dis = subprocess.check_output([os.path.join(llvm, 'llvm-objdump'), '-d', co], universal_newlines=True)
-    return len(re.findall(r'\bv_pk_(?:add|mul|fma)_f32\b', dis))
+        for i, co in enumerate(device_code_objects(path)):
+            f = os.path.join(td, 'dev%d.co' % i)
+            with open(f, 'wb') as fh:
+                fh.write(co)
+            dis = subprocess.check_output([os.path.join(llvm, 'llvm-objdump'), '-d', f], universal_newlines=True)
+            total += len(re.findall(r'\bv_pk_(?:add|mul|fma)_f32\b', dis))
+    return total
 
 
 if __name__ == '__main__':

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../../include/ppyolo_hip.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -26,6 +28,21 @@ static inline int ppy_launch_status() {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel PER DEVICE: remember, per kernel, on which device
+// ordinals it has been raised (one bit each; set atomically -- launches come from several lane threads).
+struct PpyLdsAttr {
+    std::atomic<unsigned long long> done{0};
+};
+static inline int ppy_lds_attr(PpyLdsAttr &st, const void *kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PPY_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (st.done.load(std::memory_order_acquire) & bit) return PPY_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return PPY_ERR_LAUNCH;
+    st.done.fetch_or(bit, std::memory_order_release);
+    return PPY_OK;
+}
 
 __device__ __forceinline__ float ppy_apply_act(float v, int act) {
     if (act == PPY_ACT_RELU) return v > 0.f ? v : 0.f;      // torch relu: max(v, 0)

@@ -416,13 +416,8 @@ constexpr int kNumCfgs = 14 + kNumGlds;
 template <int BM, int BN, int WM, int WN, bool SPLIT, bool VEC>
 int launch_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
     auto k = conv_igemm_kernel<BM, BN, WM, WN, SPLIT, VEC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;      // (the LDS size is a function of the template parameters)
+    if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
     return PPY_OK;
 }
@@ -449,13 +444,8 @@ int launch_cfg(const ConvArgs &p, int splits, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN, int STAGES, int BKT, bool SPLIT, bool VEC>
 int launch_glds_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
     auto k = conv_igemm_glds_kernel<BM, BN, WM, WN, STAGES, BKT, SPLIT, VEC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;      // (the LDS size is a function of the template parameters)
+    if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
     return PPY_OK;
 }

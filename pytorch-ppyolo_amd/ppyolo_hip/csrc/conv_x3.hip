@@ -541,13 +541,8 @@ constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC>
 int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
     auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)      // (the stage count is a launch parameter)
-            return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;      // (the stage count is a launch parameter: allow the whole LDS)
+    if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
     return PPY_OK;
 }

@@ -641,11 +641,8 @@ static int decode_pack(DecodeArgs &p, const float *head_out, int head_ld, int N,
 }
 
 template <typename Kern>
-static int decode_attr(Kern k) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) ==
-                   hipSuccess
-               ? PPY_OK
-               : PPY_ERR_LAUNCH;
+static int decode_attr(PpyLdsAttr &st, Kern k) {
+    return ppy_lds_attr(st, reinterpret_cast<const void *>(k), 96 * 1024);
 }
 
 extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, int S, int A, int num_classes,
@@ -661,11 +658,8 @@ extern "C" int ppy_yolo_decode_f32(const float *head_out, int head_ld, int N, in
                          iou_aware_factor, clip_bbox, im_size, boxes, M_total, box_offset, score_threshold, cand_key,
                          cand_idx, cand_count, cand_cap, scores_dense, &lds);
     if (rc != PPY_OK) return rc;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (decode_attr(yolo_decode_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;
+    if (decode_attr(attr, yolo_decode_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((S * S + DEC_CELLS - 1) / DEC_CELLS), N), dim3(256), lds,
                        (hipStream_t)stream, p);
     return ppy_launch_status();
@@ -694,11 +688,8 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
         m.nb[l] = (S[l] * S[l] + DEC_CELLS - 1) / DEC_CELLS;
         blocks += (unsigned)m.nb[l];
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (decode_attr(yolo_decode_multi_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;
+    if (decode_attr(attr, yolo_decode_multi_kernel) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(yolo_decode_multi_kernel, dim3(blocks, N), dim3(256), lds, (hipStream_t)stream, m);
     return ppy_launch_status();
 }
@@ -740,13 +731,8 @@ extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_class
     p.M_total = M_total; p.C = num_classes; p.cand_cap = cand_cap; p.top_k = nms_top_k; p.keep_k = keep_top_k;
     p.gaussian = use_gaussian ? 1 : 0; p.idx_bits = ib; p.post_thr = post_threshold; p.sigma = gaussian_sigma;
     p.ws = (char *)ws;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nms_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                CCAP * 8) != hipSuccess)
-            return PPY_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static PpyLdsAttr attr;
+    if (ppy_lds_attr(attr, reinterpret_cast<const void *>(nms_select_kernel), CCAP * 8) != PPY_OK) return PPY_ERR_LAUNCH;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_select_kernel, dim3(N), dim3(NT), CCAP * 8, st, p);
     hipLaunchKernelGGL(nms_colmax_kernel, dim3(NMS_G, N), dim3(NT), 0, st, p);

@@ -36,8 +36,10 @@ class PlanCache(object):
         self.generation += 1          # InFlight lanes built from older executors (older weights) are stale
 
     def executor(self, x, lane=0, multi_stream=None):
-        """`lane` > 0 are further executors of the same shape (own activations, scratch and graph) used by InFlight
-        to keep several batches on the device at once."""
+        """Lane 0 belongs to `PPYOLO.forward` / `forward_padded`; lanes > 0 are further executors of the same shape (own
+        activations, scratch and graph) that InFlight uses to keep several batches on the device at once -- InFlight never
+        touches lane 0, so a plain `model(x)` call cannot overwrite a batch that is still in flight.  Whichever executor
+        of a shape is built first holds the folded / split weights; the others share them (read-only)."""
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise PPYoloHipError('PPYOLO.forward needs a ROCm device tensor [N,3,H,W]; the MI355X path has no '
                                  'CPU fallback (got %s)' % (getattr(x, 'device', type(x)),))
@@ -52,8 +54,8 @@ class PlanCache(object):
         if ex is None:
             with torch.no_grad():
                 plan = build_plan(self._model, N, H, W, x.device)
-                ex = HipExecutor(plan, x.device, use_graph=self.use_graph, multi_stream=multi_stream,
-                                 share=self._ex.get((N, H, W, str(x.device), 0)) if lane else None)
+                owner = next((e for k, e in self._ex.items() if k[:4] == key[:4]), None)
+                ex = HipExecutor(plan, x.device, use_graph=self.use_graph, multi_stream=multi_stream, share=owner)
                 if self.autotune:
                     ex.run() if not self.use_graph else ex._launch_all()
                     ex.autotune()
@@ -134,7 +136,8 @@ class InFlight(object):
         lane = self._lanes.get(key)
         if lane is None:
             # one executor alone keeps its forked graph; executors that overlap each other run single-branch graphs
-            ex = self._model._plans.executor(x, lane=k, multi_stream=None if self.depth == 1 else False)
+            # lanes 1..depth: lane 0 is the executor of model.forward, which must stay free to be called beside open tickets
+            ex = self._model._plans.executor(x, lane=k + 1, multi_stream=None if self.depth == 1 else False)
             lane = _Lane(ex, x.device)
             self._lanes[key] = lane
         return lane
@@ -158,7 +161,8 @@ class InFlight(object):
 
     def lanes(self, x):
         """The (executor, stream) pairs for this input shape -- for callers that keep their inputs resident in the
-        executors and drive the replay themselves (bench.py)."""
+        executors and drive the replay themselves (bench.py).  These executors are InFlight's own (never the one
+        `model.forward` uses)."""
         return [(self._lane(x, k).ex, self._lane(x, k).stream) for k in range(self.depth)]
 
 

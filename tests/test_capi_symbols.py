@@ -50,11 +50,21 @@ def test_pick_is_pure_host_logic(libpath):
 
 def test_no_packed_fp32_ops_in_device_code(libpath):
     """ppyolo_hip/build.py: v_pk_{add,mul,fma}_f32 of one kernel are corrupted on MI355X while the 16-bit-MFMA
-    convolution kernels of another stream share the CU (tools/pk_hazard_probe.py), so no kernel here may contain them."""
+    convolution kernels of another stream share the CU (tools/pk_hazard_probe.py), so no kernel here may contain them.
+    Checked on the code objects embedded in the SHIPPED .so (it is the file that travels to the GPU box), so this runs
+    wherever the library is -- it needs no build directory."""
     from ppyolo_hip import build
-    objdir = os.path.join(os.path.dirname(libpath), 'obj')
-    objs = sorted(f for f in os.listdir(objdir) if f.endswith('.o')) if os.path.isdir(objdir) else []
-    if len(objs) < len(build.SOURCES):
-        pytest.skip('object files of the build are not here (prebuilt library)')
-    for f in objs:
-        assert build.packed_fp32_ops(os.path.join(objdir, f)) == 0, f
+    cos = build.device_code_objects(libpath)
+    assert len(cos) >= len(build.SOURCES) - 1, 'expected one gfx950 code object per translation unit with kernels'
+    assert sum(len(c) for c in cos) > 1 << 20
+    assert build.packed_fp32_ops(libpath) == 0
+
+
+@pytest.mark.gpu
+def test_no_packed_fp32_ops_in_loaded_library():
+    """The same check on the GPU box, against the very file the process has mapped."""
+    from ppyolo_hip import _lib, build
+    _lib.lib()
+    mapped = [ln.split()[-1] for ln in open('/proc/self/maps') if ln.rstrip().endswith('libppyolo_hip.so')]
+    assert mapped and os.path.samefile(mapped[0], _lib.LIB_PATH)
+    assert build.packed_fp32_ops(mapped[0]) == 0

@@ -529,3 +529,52 @@ def test_f16x2_images_are_independent():
     assert torch.equal(both[0], alone[0]), 'image 0 depends on the other image of the batch'
     ref = F.conv2d(F.relu(F.conv2d(x1.double(), w1.double())), w2.double(), None, 1, 1)
     assert ((nchw(both[1:]).double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('case', ['constant', 'low_bits_set', 'same_sign_residuals', 'cancelling', 'wide_range'])
+def test_f16x2_adversarial_max_error(case):
+    """Worst-case (not rms) error of the f16x2 scheme on the longest reduction of the model (K = 9*512 = 4608) with
+    operands built so that the representation errors of the 2-term fp16 split do NOT average out: identical values,
+    every dropped mantissa bit set, residuals of one sign, exact cancellation, and activations spread over 2^20 within one
+    image.  Compared by MAXIMUM error relative to sum|a*b| against float64, next to the exact-fp32 MFMA kernel on the same
+    data (a k-ordered fma chain with one rounding per product).  Analytic bound of the split itself: |a*s - a0 - a1| <=
+    2^-24 |a*s| per operand plus the dropped a1*b1 <= 2^-24 |ab|, i.e. <= 3 * 2^-24 = 1.8e-7 of sum|ab| even when every
+    error has the same sign; the accumulation (one fp32 rounding per 16 products instead of per product) adds less than
+    the fp32 chain's own."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(23)
+    N, H, W, C, K = 1, 16, 16, 512, 64
+    if case == 'constant':
+        x = torch.full((N, C, H, W), 1.9999999)             # 0x3FFFFFFF: every mantissa bit set
+        w = torch.full((K, C, 3, 3), 0.33333334)
+    elif case == 'low_bits_set':
+        x = (torch.randn(N, C, H, W, generator=g).abs() + 0.5).view(torch.int32).bitwise_or(0x1FFF).view(torch.float32)
+        w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).view(torch.int32).bitwise_or(0x1FFF).view(torch.float32)
+    elif case == 'same_sign_residuals':
+        # values just above an fp16 grid point of the scaled operand: the first residual is always +, never rounds to even
+        x = (torch.randint(1024, 2048, (N, C, H, W), generator=g).float() + 0.2499) / 128.0
+        w = (torch.randint(1024, 2048, (K, C, 3, 3), generator=g).float() + 0.2499) / 65536.0
+    elif case == 'cancelling':
+        x = torch.full((N, C, H, W), 1.2345678)
+        w = torch.full((K, C, 3, 3), 0.7654321)
+        w[:, 1::2] *= -1.0                                  # the exact sum is 0 at interior pixels
+    else:
+        x = torch.exp2(-20.0 * torch.rand(N, C, H, W, generator=g)) * 1000.0
+        w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    xd = nhwc(x).cuda()
+    one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    errs = {}
+    for name, cfg in (('fp32', 19), ('f16x2 128x64', 44), ('f16x2 128x128', 41), ('f16x2 256x128 3 stages', 49),
+                      ('f16x2 64x64 4 stages', 66)):
+        y = torch.full((N, H, W, K), 7.0).cuda()
+        ops.conv2d_bn_act(ops.View(xd), wk, one, zero, ops.View(y), 1, 1, None, cfg=cfg, splitk=1,
+                          w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(xd))
+        torch.cuda.synchronize()
+        errs[name] = ((nchw(y).cpu().double() - ref).abs() / mag).max().item()
+    print(case, {k: '%.3e' % v for k, v in errs.items()})
+    for k, v in errs.items():
+        if k != 'fp32':
+            assert v <= max(1.5 * errs['fp32'], 3 * 2.0 ** -24), (case, errs)
