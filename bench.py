@@ -366,6 +366,31 @@ def cpu_baseline(sd, cfg, size, batch):
                        % (n_batches, batch, size, size, cores))
 
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(('127.0.0.1', 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def launcher_argv(gpus, argv, port=None):
+    """`python bench.py --gpus N` from a bare shell (no torchrun environment): the command this process replaces itself
+    with -- one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr',
+            '127.0.0.1', '--master-port', str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(gpus, env):
+    """--gpus must equal the number of ranks actually running; returns WORLD_SIZE or raises SystemExit."""
+    world = int(env.get('WORLD_SIZE', '1'))
+    if world != gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus %d`, which starts the '
+                         'ranks itself, or torch.distributed.run --nproc-per-node %d)' % (gpus, world, gpus, gpus))
+    return world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -389,18 +414,29 @@ def main():
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); "gloo" '
                     'together with --share-gpu lets the N>1 code path be smoke-tested on a 1-GPU box')
     ap.add_argument('--share-gpu', action='store_true', help='all ranks use cuda:0 (smoke test only)')
+    ap.add_argument('--seed-offset', type=int, default=0, help='added to the image seed (a single-rank run with offset r '
+                    'computes the batch rank r computes in a multi-rank run; tests)')
+    ap.add_argument('--dump-dets', default=None, help='rank 0 writes the gathered detection records of one extra step '
+                    '([world*batch, keep_top_k+1, 6]) to this .npy file (tests)')
+    ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state running before the timed K steps and '
+                    'length of the `sustained` measurement (the board is power-managed: DESIGN.md 4.1)')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU)
+        cmd = launcher_argv(a.gpus, sys.argv[1:])
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
+    check_world(a.gpus, os.environ)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the HIP path has no CPU fallback)')
     from ppyolo_hip import dist as pd
-    if a.share_gpu:
-        os.environ['LOCAL_RANK_REAL'] = os.environ.get('LOCAL_RANK', '0')
     rank, world, local = pd.init_from_env(a.backend if not a.share_gpu else (a.backend or 'gloo'))
     if a.share_gpu:
         local = 0
-    if world != a.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm device (the HIP path has no CPU fallback)')
+    elif local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d needs cuda:%d but this node shows %d device(s) (--share-gpu puts all ranks on '
+                         'cuda:0 for a smoke test)' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     wl = WORKLOADS[a.workload]
@@ -410,14 +446,14 @@ def main():
     ge.build()
     model, sd, cfg = build_model(wl['cfg'], dev)
     from ppyolo_hip import synth
-    x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank).to(dev)
+    x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank + a.seed_offset).to(dev)
     ims = synth.synth_im_size(a.batch).to(dev)
     depth = max(1, a.in_flight)
     lanes = model.in_flight(depth).lanes(x)            # [(executor, stream)]; depth 1 = the plain forward's executor
     ex = lanes[0][0]
     for k, (e, _) in enumerate(lanes):
         # inputs resident in HBM before the timed region (every lane holds its own batch)
-        e.set_inputs(x if k == 0 else synth.synth_images(a.batch, wl['size'], seed=1234 + rank + 100 * k).to(dev), ims)
+        e.set_inputs(x if k == 0 else synth.synth_images(a.batch, wl['size'], seed=1234 + rank + a.seed_offset + 100 * k).to(dev), ims)
         e.use_graph = False
         e.run()
     torch.cuda.synchronize()
@@ -450,13 +486,28 @@ def main():
             if world > 1:
                 gats[k].gather(e.out_dets, e.out_count)
 
-    for _ in range(max(a.warmup, depth)):
-        step()
-
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, depth)):
+        step()
+    # Untimed steady-state running before the clock starts: under dense 16-bit MFMA the board sits at its power cap and
+    # the governor needs a moment to settle the shader clock -- K timed steps of 4 ms right after a cold
+    # start would be measured at a clock the board does not sustain.  Every rank runs the same number of steps.
+    barrier()
+    settle_steps, t_settle = 0, time.perf_counter()
+    while a.min_seconds > 0:
+        for _ in range(2 * depth):
+            step()
+        settle_steps += 2 * depth
+        torch.cuda.synchronize()
+        go_on = torch.tensor([1.0 if time.perf_counter() - t_settle < a.min_seconds else 0.0], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(go_on, op=torch.distributed.ReduceOp.MAX)
+        if go_on.item() == 0.0:
+            break
 
     barrier()
     t0 = time.perf_counter()
@@ -469,17 +520,51 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # `sustained`: the same loop over at least --min-seconds (a multiple of K steps), timed the same way
+    sustained = None
+    if a.min_seconds > 0:
+        n_sus = a.steps * max(1, int(a.min_seconds / max(dt, 1e-6)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        barrier()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dts], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dts = float(t.item())
+        sustained = dict(value=round(world * a.batch * n_sus / dts, 2), unit='images/s', steps=n_sus, seconds=round(dts, 3),
+                         note='same loop, same timing, over >= %.1f s; `value` above is the K = %d steps of the contract, '
+                              'timed after %d untimed steady-state steps' % (a.min_seconds, a.steps, settle_steps))
+
+    if a.dump_dets:
+        e0, st0 = lanes[0]
+        with torch.cuda.stream(st0):
+            e0.run()
+            packed = gats[0].gather(e0.out_dets, e0.out_count)
+        st0.synchronize()
+        if rank == 0:
+            import numpy as np
+            np.save(a.dump_dets, packed.cpu().numpy())
+
     ms_per_step = dt / a.steps * 1e3
     value = world * a.batch * a.steps / dt
     one_at_a_time = None
     if depth > 1 and world == 1:              # not `value`: the same steps with one batch on the device at a time
         torch.cuda.synchronize()
+        n1, dt1 = min(a.steps, 30), 0.0
         with torch.cuda.stream(lanes[0][1]):
-            t1 = time.perf_counter()
-            for _ in range(min(a.steps, 30)):
-                ex.run()
-        torch.cuda.synchronize()
-        one_at_a_time = round(a.batch * min(a.steps, 30) / (time.perf_counter() - t1), 1)
+            while True:
+                t1 = time.perf_counter()
+                for _ in range(n1):
+                    ex.run()
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                if dt1 >= min(a.min_seconds, 1.0) or n1 >= 4096:
+                    break
+                n1 *= 4
+        one_at_a_time = round(a.batch * n1 / dt1, 1)
 
     if rank == 0:
         total_flops, per_op = conv_flops(ex.plan)
@@ -488,15 +573,20 @@ def main():
         peak = covered / ideal_s / 1e12        # flop-weighted peak of the kernel mix of this step
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
         # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if a.workload == 'r50vd_608' and a.batch == 8 and os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = round(json.load(fh)['hbm_bytes_per_step'] / nconv)
+        traffic, traffic_src = None, None
+        if a.workload == 'r50vd_608' and a.batch == 8:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+            if files:
+                with open(files[-1]) as fh:
+                    rec = json.load(fh)
+                traffic = round(rec['hbm_bytes_per_step'] / nconv)
+                traffic_src = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured', 'round 1'),
+                                   note='NOT measured by this run: rocprofv3 PMC passes need their own processes '
+                                        '(tools/prof_run.sh -> tools/pmc_traffic.py); committed summary of the named date')
         roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
-                    frac=round(achieved / peak, 4), traffic=traffic,
-                    traffic_unit='bytes per launch (mean over the conv launches of a step; PMC '
-                                 '2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)',
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                    traffic_unit='bytes per launch (mean over the conv launches of a step; PMC 2*FETCH_SIZE+WRITE_SIZE)',
                     kernel='conv_igemm_x3_kernel<*> (fp32-in/fp32-out implicit GEMM on the 16-bit MFMA: f16x2 = 3 x '
                            'v_mfma_f32_32x32x16_f16 per product after a 2-term fp16 split, bf16x3 = 6 x ..._bf16 after a 3-term '
                            'bf16 split) / conv_igemm_glds_kernel<*> (v_mfma_f32_32x32x2_f32), %d launches/step' % nconv,
@@ -533,6 +623,8 @@ def main():
                                                 }.get(ex.math, ''),
                                tile_table='re-measured' if a.autotune else os.path.basename(_tuned_path(ex.math))),
                    roofline=roof)
+        if sustained is not None:
+            out['sustained'] = sustained
         if one_at_a_time is not None:
             out['one_batch_at_a_time'] = dict(value=one_at_a_time, unit='images/s',
                                               note='the graph of lane 0 replayed alone (= --in-flight 1)')

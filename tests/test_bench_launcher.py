@@ -1,0 +1,82 @@
+"""bench.py's N>1 entry: `python bench.py --gpus N` from a bare shell starts the N ranks itself (torch.distributed.run,
+127.0.0.1 rendezvous) and refuses to run when --gpus and the number of ranks disagree.  The CPU tests check the host
+logic; the `gpu` test runs the real 2-rank path on one GPU (--share-gpu, gloo) and compares the all-gathered detection
+records with two single-rank runs, bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=timeout)
+
+
+def test_launcher_command_and_world_check():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_argv(4, ['--gpus', '4', '--steps', '7'], port=23456)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '7'] and cmd[-5] == BENCH
+    assert bench.check_world(2, {'WORLD_SIZE': '2'}) == 2 and bench.check_world(1, {}) == 1
+    for gpus, env in ((8, {}), (8, {'WORLD_SIZE': '1'}), (2, {'WORLD_SIZE': '4'}), (1, {'WORLD_SIZE': '2'})):
+        with pytest.raises(SystemExit):
+            bench.check_world(gpus, env)
+
+
+def test_mismatch_fails_loudly():
+    r = _run(['--gpus', '4'], env={'WORLD_SIZE': '2', 'RANK': '0'})
+    assert r.returncode != 0 and '--gpus 4 but WORLD_SIZE=2' in r.stderr
+
+
+@pytest.mark.skipif(__import__('torch').cuda.is_available(), reason='CPU-box behaviour')
+def test_bare_gpus2_starts_two_ranks():
+    """On this GPU-less box the two ranks the launcher starts each stop at 'needs a ROCm device' -- which shows that two
+    ranks were started with WORLD_SIZE=2 (a single process would have passed the world check only with --gpus 1)."""
+    r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'], timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs a ROCm device') == 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_two_single_runs(tmp_path):
+    common = ['--workload', 'r18vd_320', '--steps', '3', '--warmup', '1', '--min-seconds', '0', '--no-cpu-baseline',
+              '--no-alt-math', '--no-host-input']
+    two = str(tmp_path / 'two.npy')
+    r = _run(['--gpus', '2', '--share-gpu', '--dump-dets', two] + common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16 and line['scaling'] == 'weak'
+    singles = []
+    for off in (0, 1):
+        f = str(tmp_path / ('one%d.npy' % off))
+        r1 = _run(['--gpus', '1', '--seed-offset', str(off), '--dump-dets', f] + common)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        singles.append(np.load(f))
+        if off == 0:
+            plain = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith('{')][-1])
+            assert plain['n_gpus'] == 1
+    got = np.load(two)
+    assert got.shape == (16, 101, 6)
+    assert np.array_equal(got, np.concatenate(singles, 0)), 'all-gathered records differ from the single-rank runs'
+    assert (got[:, 100, 0] > 0).all(), 'every image should have detections with the synthetic head biases'
+    # --gpus 1 under the launcher == the plain run
+    f = str(tmp_path / 'launched1.npy')
+    e = dict(os.environ)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29631', BENCH, '--gpus', '1', '--dump-dets', f] + common
+    r2 = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert np.array_equal(np.load(f), singles[0])

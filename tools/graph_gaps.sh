@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-trace of the hipGraph replay: busy time vs wall time per step (inter-kernel gaps).  usage: tools/graph_gaps.sh [bench args]
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/gg && rocprofv3 --kernel-trace --output-format csv -d /tmp/gg -o t -- python /root/repo/bench.py --no-cpu-baseline --no-alt-math --no-host-input --steps 20 --warmup 5 "$@" > /tmp/gg.log 2>&1
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/gg && rocprofv3 --kernel-trace --output-format csv -d /tmp/gg -o t -- python /root/repo/bench.py --no-cpu-baseline --no-alt-math --no-host-input --min-seconds 0 --steps 20 --warmup 5 "$@" > /tmp/gg.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/gg/**/*kernel_trace.csv', recursive=True)[0]

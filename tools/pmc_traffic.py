@@ -6,6 +6,7 @@ import json
 import os
 import re
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FETCH_CORRECTION = 2.0     # gfx950: FETCH_SIZE counts half of a 16 B/lane streaming read (MI355X_MICROARCH.md)
@@ -41,6 +42,7 @@ def main():
     launches = sum(c for k, (c, _) in fetch.items() if 'conv_igemm' in k) / runs
     rec = {
         'source': 'profiles/%s_pmc_fetch.txt, profiles/%s_pmc_write.txt (rocprofv3 --pmc, separate passes)' % (tag, tag),
+        'measured': time.strftime('%Y-%m-%d') + ' (' + tag + ')',
         'conv_runs_profiled': runs,
         'conv_launches_per_step': launches,
         'fetch_size_kb_per_step': f_kb,
