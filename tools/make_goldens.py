@@ -408,8 +408,38 @@ def g9_decode_harness():
     save('g9_decode_harness', **arrs)
 
 
+def g10_coco_records():
+    """The eval harness's on-disk record format: the reference's own writer, tools/cocotools.py:159-191
+    (`multi_thread_write_json`), on detection arrays of the types `Decode.detect_batch` returns -- the g9 harness output
+    plus hand-made rows on the rounding edges (x.x5 in float32, -0.0 from the x0 clip, sub-pixel and 4-digit boxes)."""
+    import json
+    import tempfile
+    _cv2_stub()
+    coco = _load('ref_cocotools', os.path.join(REF, 'tools', 'cocotools.py'))
+    g9 = np.load(os.path.join(OUT, 'g9_decode_harness.npz'))
+    edge = np.array([[-0.0, 0.05, 10.05, 20.15], [0.25, 0.35, 0.45, 0.55], [1234.5678, 987.65, 1919.95, 1079.949],
+                     [3.14159, 2.71828, 3.14159, 2.71828], [100.04999, 100.05, 100.15, 100.25], [7.5, 8.5, 9.5, 10.5]],
+                    dtype=np.float32)
+    cases = [(g9['b_boxes0'], g9['b_scores0'], g9['b_classes0'], 139, '000000000139.jpg'),
+             (g9['b_boxes1'], g9['b_scores1'], g9['b_classes1'], 285, '000000000285.jpg'),
+             (edge, np.array([0.99999994, 0.5, 0.010000001, 1e-8, 0.123456789, 0.75], dtype=np.float32),
+              np.array([0, 11, 79, 24, 60, 1], dtype=np.int32), 724, 'edge.case.png'),
+             (np.array([]), np.array([]), np.array([]), 7, 'empty.jpg')]
+    arrs = dict(ncases=np.array(len(cases)), clsid2catid=np.array([coco.clsid2catid[i] for i in range(80)]))
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, 'bbox'))
+        for j, (b, sc, cl, im_id, name) in enumerate(cases):
+            coco.multi_thread_write_json(0, [None], [b], [sc], [cl], [im_id], [name], coco.clsid2catid, False, td)
+            text = open(os.path.join(td, 'bbox', name.split('.')[0] + '.json')).read()
+            json.loads(text)
+            arrs.update({'boxes%d' % j: b, 'scores%d' % j: sc, 'classes%d' % j: cl, 'im_id%d' % j: np.array(im_id),
+                         'name%d' % j: np.frombuffer(name.encode(), dtype=np.uint8),
+                         'json%d' % j: np.frombuffer(text.encode(), dtype=np.uint8)})
+    save('g10_coco_records', **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
