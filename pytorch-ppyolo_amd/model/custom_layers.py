@@ -79,7 +79,8 @@ class Conv2dUnit(torch.nn.Module):
         if res is not None:
             assert act is None
             act = post_act
-        scale, shift = self.folded(b.device)
+        skel = getattr(b, 'skeleton', False)      # shape-only plan: the executor takes the folded weights from their owner
+        scale, shift = (None, None) if skel else self.folded(b.device)
         if x is None:
             # first backbone conv: reads the plan's NCHW input directly (3 -> K, 3x3, stride 2)
             assert (self.conv.in_channels, self.filter_size, self.stride) == (3, 3, 2) and not self.use_dcn
@@ -87,8 +88,8 @@ class Conv2dUnit(torch.nn.Module):
         if self.use_dcn:
             assert res is None and out is None and not ups and not coord
             co = self.conv.conv_offset
-            one = torch.ones(27, dtype=torch.float32, device=b.device)
-            om = b.conv(x, co.weight, one, co.bias.detach().float().clone(), stride=self.stride, act=None)
+            one = None if skel else torch.ones(27, dtype=torch.float32, device=b.device)
+            om = b.conv(x, co.weight, one, None if skel else co.bias.detach().float().clone(), stride=self.stride, act=None)
             return b.dcn(x, om, self.conv.dcn_weight, scale, shift, self.stride, self.act_name)
         return b.conv(x, self.conv.weight, scale, shift, stride=self.stride, act=act, res=res, out=out,
                       ups=ups, coord=coord)

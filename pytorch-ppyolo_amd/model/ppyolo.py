@@ -39,6 +39,28 @@ class PPYOLO(torch.nn.Module):
         at once -- see ppyolo_hip.runtime.InFlight."""
         return InFlight(self, depth)
 
+    # ---- native weight blob (SURVEY.md section 8f rank 3; ppyolo_hip/blob.py) ----
+    def save_native_blob(self, path):
+        """Write the folded / re-laid / pre-split weights of the CURRENT parameters, in the current PPYOLO_HIP_MATH mode,
+        to `path` (the model must be on a ROCm device, in eval mode).  Returns the file size."""
+        from ppyolo_hip import blob
+        dev = next(self.parameters()).device
+        ex = next(iter(self._plans._ex.values()), None)
+        if ex is None:      # any input shape yields the same weights: a small one
+            ex = self._plans.executor(torch.zeros((1, 3, 64, 64), dtype=torch.float32, device=dev))
+        return blob.save(ex, path, blob.fingerprint(self.state_dict()))
+
+    def load_native_blob(self, path, verify=True):
+        """After `load_state_dict` (the blob is a cache of what is derived from the checkpoint, checked against the
+        parameters the model holds unless verify=False): executors built from now on upload nothing but this file's data
+        region and build their plans shape-only."""
+        from ppyolo_hip import blob
+        dev = next(self.parameters()).device
+        own = blob.load(path, dev, blob.fingerprint(self.state_dict()) if verify else None)
+        self._plans.clear()
+        self._plans.blob = own
+        return own.nbytes
+
     # any change of parameters / device invalidates the folded weights held by the plans
     def load_state_dict(self, *a, **k):
         r = super(PPYOLO, self).load_state_dict(*a, **k)

@@ -101,10 +101,18 @@ class Plan(object):
         self.decode = None       # decode / NMS parameters
 
 
+def _meta(*shape):
+    return torch.empty(shape, dtype=torch.float32, device='meta')
+
+
 class Builder(object):
-    def __init__(self, N, H, W, device):
+    def __init__(self, N, H, W, device, skeleton=False):
+        """`skeleton`: record the plan WITHOUT touching parameter data -- weight-carrying ops get shape-only placeholders
+        (meta tensors) that the executor replaces by the tensors of a weight owner: another executor of the same model
+        (any input shape; folded / split weights do not depend on it) or a native blob (ppyolo_hip/blob.py)."""
         self.plan = Plan(N, H, W)
         self.device = device
+        self.skeleton = skeleton
         self._coord_cache = {}
         self._stream = 0
 
@@ -145,7 +153,8 @@ class Builder(object):
         p = self.plan
         Ho, Wo = K.conv_out_hw(p.H, p.W, 3, 3, 2, 1)
         y = self.new_act(p.N, Ho, Wo, weight.shape[0])
-        self._emit(dict(op='stem', y=y, w=weight.detach().float().contiguous(), scale=scale, shift=shift, act=act))
+        w = _meta(*weight.shape) if self.skeleton else weight.detach().float().contiguous()
+        self._emit(dict(op='stem', y=y, w=w, scale=scale, shift=shift, act=act))
         return y
 
     def conv(self, x, weight, scale, shift, stride=1, act=None, res=None, out=None, ups=False, coord=False,
@@ -153,7 +162,7 @@ class Builder(object):
         """weight: [K, C(+2 if coord), R, S] in the reference's KCRS layout."""
         Kout, Cin, R, S = weight.shape
         pad = (R - 1) // 2
-        w = weight.detach().float()
+        w = weight if self.skeleton else weight.detach().float()
         posb = None
         if coord:
             assert Cin == x.C + 2
@@ -161,7 +170,7 @@ class Builder(object):
             w = w[:, :x.C]
         else:
             assert Cin == x.C, (Cin, x.C)
-        w_krsc = w.permute(0, 2, 3, 1).contiguous()
+        w_krsc = _meta(Kout, R, S, x.C) if self.skeleton else w.permute(0, 2, 3, 1).contiguous()
         Ho, Wo = K.conv_out_hw(x.H, x.W, R, S, stride, pad)
         if out is None:
             out = self.new_act(x.N, Ho * (2 if ups else 1), Wo * (2 if ups else 1), Kout)
@@ -190,10 +199,13 @@ class Builder(object):
             self._coord_cache[key] = g
         g = self._coord_cache[key]
         Kout, two, R, S = w_coord.shape
-        w32 = torch.zeros((Kout, 32, R, S), dtype=torch.float32, device=self.device)
-        w32[:, :2] = w_coord
-        one = torch.ones(Kout, dtype=torch.float32, device=self.device)
-        zero = torch.zeros(Kout, dtype=torch.float32, device=self.device)
+        if self.skeleton:
+            w32, one, zero = _meta(Kout, 32, R, S), None, None
+        else:
+            w32 = torch.zeros((Kout, 32, R, S), dtype=torch.float32, device=self.device)
+            w32[:, :2] = w_coord
+            one = torch.ones(Kout, dtype=torch.float32, device=self.device)
+            zero = torch.zeros(Kout, dtype=torch.float32, device=self.device)
         out = self.conv(g, w32, one, zero, stride=stride, act=None, setup=True)
         return out          # A of shape [1,Ho,Wo,K]; bound to its tensor by the executor
 
@@ -217,7 +229,8 @@ class Builder(object):
 
     def dcn(self, x, om, weight, scale, shift, stride, act):
         Kout = weight.shape[0]
-        w_krsc = weight.detach().float().permute(0, 2, 3, 1).contiguous()
+        w_krsc = (_meta(Kout, weight.shape[2], weight.shape[3], weight.shape[1]) if self.skeleton
+                  else weight.detach().float().permute(0, 2, 3, 1).contiguous())
         Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
         assert (om.H, om.W, om.C) == (Ho, Wo, 27)
         y = self.new_act(x.N, Ho, Wo, Kout)
@@ -261,14 +274,21 @@ class HipExecutor(object):
             self.out_keep = torch.zeros((p.N, kk), dtype=torch.int32, device=self.device)
             self.nms_ws = K.matrix_nms_workspace(p.N, self.device)
         self.math = math_mode()
-        if share is not None and share.math == self.math and len(share.plan.ops) == len(p.ops):
-            # a further lane of the same plan (runtime.InFlight): weights are read-only, one copy in HBM serves all lanes
+        placeholders = any(op.get('w') is not None and op['w'].is_meta for op in p.setup_ops + p.ops)
+        if share is not None and share.math == self.math and len(share.plan.ops) == len(p.ops) \
+                and len(share.plan.setup_ops) == len(p.setup_ops):
+            # weights are read-only and do not depend on the input shape: one copy in HBM serves every executor of the
+            # model -- further lanes (runtime.InFlight), other input shapes, or the tensors of a native blob
             for mine, theirs in ((p.setup_ops, share.plan.setup_ops), (p.ops, share.plan.ops)):
                 for op, src in zip(mine, theirs):
+                    assert (op.get('w') is None) == (src.get('w') is None) and (op.get('w') is None or
+                                                                              tuple(op['w'].shape) == tuple(src['w'].shape))
                     for k in ('w', 'scale', 'shift', 'w3', 'wf16'):
                         if src.get(k) is not None:
                             op[k] = src[k]
         else:
+            if placeholders:
+                raise PPYoloHipError('skeleton plan without a matching weight owner (math mode %s)' % self.math)
             self._to_device(p.setup_ops)
             self._to_device(p.ops)
             if self.math in ('bf16x3', 'f16x2'):

@@ -7,9 +7,10 @@ from .engine import Builder, HipExecutor
 from ._lib import PPYoloHipError
 
 
-def build_plan(model, N, H, W, device, with_head=True):
-    """Walk `model` (a model.ppyolo.PPYOLO) into a kernel plan for inputs [N,3,H,W]."""
-    b = Builder(N, H, W, device)
+def build_plan(model, N, H, W, device, with_head=True, skeleton=False):
+    """Walk `model` (a model.ppyolo.PPYOLO) into a kernel plan for inputs [N,3,H,W].  `skeleton`: shapes only, parameter
+    data untouched (engine.Builder)."""
+    b = Builder(N, H, W, device, skeleton=skeleton)
     head = model.head if with_head else None
     slots = head.make_out_slots(model.backbone.feature_maps) if head is not None else None
     feats = model.backbone.emit(b, slots)
@@ -27,12 +28,14 @@ class PlanCache(object):
     def __init__(self, model):
         self._model = model
         self._ex = {}
+        self.blob = None               # weight owner loaded from a native blob (ppyolo_hip/blob.py), if any
         self.generation = 0
         self.use_graph = os.environ.get('PPYOLO_HIP_GRAPH', '1') != '0'
         self.autotune = os.environ.get('PPYOLO_HIP_AUTOTUNE', '0') == '1'
 
     def clear(self):
         self._ex = {}
+        self.blob = None
         self.generation += 1          # InFlight lanes built from older executors (older weights) are stale
 
     def executor(self, x, lane=0, multi_stream=None):
@@ -52,9 +55,15 @@ class PlanCache(object):
         key = (N, H, W, str(x.device), lane)
         ex = self._ex.get(key)
         if ex is None:
+            from .engine import math_mode
             with torch.no_grad():
-                plan = build_plan(self._model, N, H, W, x.device)
-                owner = next((e for k, e in self._ex.items() if k[:4] == key[:4]), None)
+                # the folded / split weights are the same for every input shape and lane: the first executor on a device
+                # (or a loaded blob) owns them, all others are built from a shape-only plan and share its tensors
+                owner = next((e for k, e in self._ex.items() if k[3] == key[3] and e.math == math_mode()), None)
+                if owner is None and self.blob is not None and self.blob.math == math_mode() \
+                        and str(self.blob.device) == str(x.device):
+                    owner = self.blob
+                plan = build_plan(self._model, N, H, W, x.device, skeleton=owner is not None)
                 ex = HipExecutor(plan, x.device, use_graph=self.use_graph, multi_stream=multi_stream, share=owner)
                 if self.autotune:
                     ex.run() if not self.use_graph else ex._launch_all()

@@ -438,8 +438,24 @@ def g10_coco_records():
     save('g10_coco_records', **arrs)
 
 
+def g11_state_dict_layout():
+    """Checkpoint layout: key names (in order), shapes and dtypes of the REFERENCE modules' state_dict
+    -- what `torch.save(ppyolo.state_dict(), ...)` (reference 1_ppyolo_2x_2pytorch.py:321) puts into a .pt file."""
+    arrs = {}
+    for tag, C in (('r18vd', PPYOLO_r18vd_Config), ('r50vd', PPYOLO_2x_Config)):
+        m, _ = build_ref(C(), 0)
+        sd = m.state_dict()
+        keys = list(sd.keys())
+        arrs[tag + '_keys'] = np.frombuffer(''.join(keys).encode(), dtype=np.uint8)
+        arrs[tag + '_keylens'] = np.array([len(k) for k in keys])
+        arrs[tag + '_shapes'] = np.array([d for k in keys for d in sd[k].shape], dtype=np.int64)
+        arrs[tag + '_ranks'] = np.array([sd[k].dim() for k in keys])
+        arrs[tag + '_dtypes'] = np.array([str(sd[k].dtype).ljust(16).encode() for k in keys], dtype='S16')
+    save('g11_state_dict_layout', **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
