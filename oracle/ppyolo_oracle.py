@@ -25,6 +25,25 @@ import torch
 import torch.nn.functional as F
 
 
+# Training-mode switch, used by oracle/train_oracle.py only.  The reference trains in nn.Module's default training mode
+# (train.py never calls .eval() before its loop; `backbone.freeze()` only stops gradients): every BatchNorm2d then
+# normalises with BATCH statistics and updates its running statistics (momentum 0.1), and DropBlock draws a mask.
+TRAIN_MODE = [False]
+
+
+def drop_block_train(x, block_size=3, keep_prob=0.9):
+    """DropBlock.__call__ with is_test=False -- reference model/custom_layers.py:303-342: gamma = H^2 (1-keep) /
+    (bs^2 (H-bs+1)^2) from the HEIGHT only; seeds = rand(shape) < gamma; mask = 1 - max_pool(seeds, bs, stride 1, pad 1);
+    out = x * mask * numel / mask.sum().  Draws from torch's global RNG exactly once, like the reference."""
+    h = torch.tensor([float(x.shape[2])], dtype=torch.float32).reshape(1, 1, 1, 1)
+    bs = torch.zeros((1, 1, 1, 1), dtype=torch.float32) + block_size
+    gamma = (torch.pow(h, 2) * (1 - keep_prob)) / (torch.pow(bs, 2) * torch.pow(h - bs + 1, 2))
+    p = gamma.repeat(x.shape)
+    seeds = (torch.rand(x.shape) < p).float()
+    mask = 1.0 - F.max_pool2d(seeds, (block_size, block_size), stride=1, padding=1)
+    return x * mask * float(x.numel()) / mask.sum()
+
+
 # ----------------------------------------------------------------------------
 # layer primitives
 # ----------------------------------------------------------------------------
@@ -43,7 +62,7 @@ def conv_unit(sd, prefix, x, stride=1, act=None):
     if prefix + '.bn.weight' in sd:
         y = F.batch_norm(y, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'],
                          sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'],
-                         False, 0.1, 1e-5)
+                         TRAIN_MODE[0], 0.1, 1e-5)
     if act == 'relu':
         y = F.relu(y)
     elif act == 'leaky':
@@ -243,8 +262,12 @@ def detection_block(sd, p, x, conv_block_num, is_first, coord, use_spp, drop_blo
             idx += 1
         if drop_block and j == 0 and not is_first:
             idx += 1                       # DropBlock(is_test) == identity (custom_layers.py:304-305)
+            if TRAIN_MODE[0]:
+                x = drop_block_train(x)
     if drop_block and is_first:
         idx += 1
+        if TRAIN_MODE[0]:
+            x = drop_block_train(x)
     route = conv_unit(sd, '%s.layers.%d' % (p, idx + 1), cc(x), 1, 'leaky')
     tip = conv_unit(sd, '%s.tip_layers.1' % p, cc(route), 1, 'leaky')
     return route, tip

@@ -38,6 +38,16 @@ class PPYOLO_2x_Config(object):
                          coord_conv=True, iou_aware=True, iou_aware_factor=0.4,
                          scale_x_y=1.05, spp=True, drop_block=True, keep_prob=0.9,
                          downsample=[32, 16, 8], in_channels=[2048, 1024, 512])
+        # training step -- reference: config/ppyolo_2x.py:47-67, :123-142
+        self.iou_loss_type = 'IouLoss'
+        self.iou_loss = dict(loss_weight=2.5, max_height=608, max_width=608, ciou_term=False)
+        self.iou_aware_loss_type = 'IouAwareLoss'
+        self.iou_aware_loss = dict(loss_weight=1.0, max_height=608, max_width=608)
+        self.yolo_loss_type = 'YOLOv3Loss'
+        self.yolo_loss = dict(ignore_thresh=0.7, scale_x_y=1.05, label_smooth=False, use_fine_grained_loss=True)
+        self.learningRate = dict(base_lr=0.0001, PiecewiseDecay=dict(gamma=0.1, milestones=[400000, 450000]),
+                                 LinearWarmup=dict(start_factor=0., steps=4000))
+        self.optimizerBuilder = dict(optimizer=dict(momentum=0.9, type='Momentum'), regularizer=dict(factor=0.0005, type='L2'))
         self.nms_cfg = _matrix_nms_defaults()
         # pre-processing constants the harness (decode_np.Decode) reads
         self.context = {'fields': ['image']}

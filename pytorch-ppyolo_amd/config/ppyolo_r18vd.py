@@ -26,6 +26,14 @@ class PPYOLO_r18vd_Config(object):
                          coord_conv=False, iou_aware=False, iou_aware_factor=0.4,
                          scale_x_y=1.05, spp=False, drop_block=True, keep_prob=0.9,
                          downsample=[32, 16], in_channels=[512, 256])
+        # training step -- reference: config/ppyolo_r18vd.py:46-66, :122-134
+        self.iou_loss_type = 'IouLoss'
+        self.iou_loss = dict(loss_weight=2.5, max_height=608, max_width=608, ciou_term=False)
+        self.yolo_loss_type = 'YOLOv3Loss'
+        self.yolo_loss = dict(ignore_thresh=0.7, scale_x_y=1.05, label_smooth=False, use_fine_grained_loss=True)
+        self.learningRate = dict(base_lr=0.0001, PiecewiseDecay=dict(gamma=0.1, milestones=[150000, 200000]),
+                                 LinearWarmup=dict(start_factor=0., steps=4000))
+        self.optimizerBuilder = dict(optimizer=dict(momentum=0.9, type='Momentum'), regularizer=dict(factor=0.0005, type='L2'))
         self.nms_cfg = _matrix_nms_defaults()
         self.context = {'fields': ['image']}
         self.decodeImage = dict(to_rgb=True)

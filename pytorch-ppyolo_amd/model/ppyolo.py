@@ -56,7 +56,19 @@ class PPYOLO(torch.nn.Module):
         region and build their plans shape-only."""
         from ppyolo_hip import blob
         dev = next(self.parameters()).device
+        if dev.type == 'meta':
+            raise RuntimeError('a model built on the meta device has no parameters to verify against: use attach_native_blob')
         own = blob.load(path, dev, blob.fingerprint(self.state_dict()) if verify else None)
+        self._plans.clear()
+        self._plans.blob = own
+        return own.nbytes
+
+    def attach_native_blob(self, path, device='cuda'):
+        """Inference-only start WITHOUT the checkpoint: a model whose modules were constructed under
+        `torch.device('meta')` (shapes only, no initialisation, no .pt read) takes all its weights from the blob.  Its
+        `state_dict()` holds no data -- use `load_state_dict` + `load_native_blob` when the parameters themselves are needed."""
+        from ppyolo_hip import blob
+        own = blob.load(path, device, None)
         self._plans.clear()
         self._plans.blob = own
         return own.nbytes

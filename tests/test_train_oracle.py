@@ -1,0 +1,82 @@
+"""Training step (BASELINE config 5): the CPU oracle of one forward + backward
+(oracle/train_oracle.py) against what the REFERENCE computed for the same inputs (tests/golden/g12_train_*.npz, made from
+/root/reference by tools/make_goldens.py g12): loss terms, training-mode head outputs, d loss / d head outputs, digests of
+every parameter gradient, updated BatchNorm statistics."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_model
+from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+from oracle import train_oracle as trn
+from ppyolo_hip import synth
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _step(golden, tag, cfgc):
+    g = golden('g12_train_' + tag)
+    S, N, wseed, iseed, rseed = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    _, sd = build_model(cfg, wseed, 'cpu')
+    x = synth.synth_images(N, S, seed=iseed)
+    L = len(cfg.head['anchor_masks'])
+    targets = [T(g['target%d' % i]) for i in range(L)]
+    torch.set_num_threads(8)
+    r = trn.train_step(sd, cfg, x, T(g['gt_bbox']), targets, rng_seed=rseed)
+    return g, cfg, sd, r
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_96', PPYOLO_r18vd_Config), ('r50vd_96', PPYOLO_2x_Config)])
+def test_train_step_matches_reference(golden, tag, cfgc):
+    g, cfg, sd, r = _step(golden, tag, cfgc)
+    names = [str(n) for n in g['loss_names']]
+    assert names == list(r['losses'].keys())
+    got = np.array([float(r['losses'][k]) for k in names], np.float32)
+    assert np.array_equal(got, g['loss_values']), (got, g['loss_values'])
+    assert float(r['all_loss']) == float(g['all_loss'])
+    for i, (o, d) in enumerate(zip(r['outs'], r['douts'])):
+        assert torch.equal(o.detach(), T(g['out%d' % i])), 'training-mode head output %d' % i
+        assert torch.equal(d, T(g['dout%d' % i])), 'd loss / d head output %d' % i
+    gnames = [str(n) for n in g['grad_names']]
+    assert gnames == [k for k in r['grads']] and set(gnames) == set(trn.trainable_keys(sd))
+    for k, dig, smp in zip(gnames, g['grad_digest'], g['grad_samples']):
+        d = r['grads'][k].double().reshape(-1)
+        mine = np.array([d.sum().item(), d.abs().sum().item(), d.pow(2).sum().sqrt().item()])
+        assert np.allclose(mine, dig, rtol=1e-12, atol=0), k
+        step = max(1, d.numel() // 64)
+        assert np.array_equal(d[::step][:64].float().numpy(), smp[:len(d[::step][:64])]), k
+    for i in range(len(r['outs'])):
+        assert torch.equal(r['grads']['head.yolo_output_convs.%d.conv.weight' % i], T(g['gw_out%d' % i]))
+        assert torch.equal(r['grads']['head.yolo_output_convs.%d.conv.bias' % i], T(g['gb_out%d' % i]))
+    # BatchNorm buffers moved (momentum 0.1, batch statistics), frozen or not
+    for k in ('backbone.stage1_conv1_1.bn.running_mean', 'backbone.stage1_conv1_1.bn.running_var'):
+        assert torch.equal(r['state'][k], T(g['after.' + k])) and not torch.equal(r['state'][k], sd[k])
+    assert torch.equal(r['state'][str(g['after_name'])], T(g['after_value']))
+    assert all(int(v) == 1 for k, v in r['state'].items() if k.endswith('num_batches_tracked'))
+
+
+def test_loss_pieces_have_the_documented_shape_quirks():
+    """The IoU-aware term is summed over grid x and broadcast back (reference model/iou_losses.py:241-242); the ignore mask
+    uses boxes in (anchor, h, w) order with IoU computed without eps (model/losses.py:56-60, model/matrix_nms.py:31-47)."""
+    g = torch.Generator().manual_seed(3)
+    N, A, S = 2, 3, 4
+    x, y, w, h = [torch.randn(N, A, S, S, generator=g) * 0.3 for _ in range(4)]
+    tx, ty = torch.rand(N, A, S, S, generator=g), torch.rand(N, A, S, S, generator=g)
+    tw, th = torch.randn(N, A, S, S, generator=g) * 0.2, torch.randn(N, A, S, S, generator=g) * 0.2
+    ioup = torch.rand(N, A, S, S, generator=g)
+    anchors = [10, 13, 16, 30, 33, 23]
+    la = trn.iou_aware_loss(ioup, x, y, w, h, tx, ty, tw, th, anchors, 8, 1.05)
+    assert tuple(la.shape) == (N, A, S, 1)
+    k = trn.iou_pairs(trn.bbox_transform(x, y, w, h, anchors, 8, False, 1.05), trn.bbox_transform(tx, ty, tw, th, anchors, 8, True, 1.05))
+    assert torch.allclose(la[..., 0], (k * -torch.log(ioup + 1e-9)).sum(-1))
+    out = torch.randn(N, A * 85, S, S, generator=g)
+    b = trn.train_boxes(out, np.array(anchors, np.float32).reshape(-1, 2), 8, 80, 1.05)
+    assert tuple(b.shape) == (N, A * S * S, 4)
+    o = out.reshape(N, A, 85, S, S)
+    a, hh, ww = 2, 1, 3                                        # box index = (a*S + h)*S + w
+    cx = (1.05 * torch.sigmoid(o[0, a, 0, hh, ww]) + ww - 0.025) * 8
+    bw = torch.exp(o[0, a, 2, hh, ww]) * anchors[2 * a]
+    assert torch.allclose(b[0, (a * S + hh) * S + ww, 0], (cx - bw / 2) / S / 8)

@@ -133,6 +133,17 @@ def test_pt_round_trip_and_blob_give_the_same_forward(cfgc, S, tmp_path):
     ref2 = model(x2, synth.synth_im_size(1).cuda())
     got2 = m3(x2, synth.synth_im_size(1).cuda())
     assert all(torch.equal(a, b) for a, b in zip(got2, ref2))
+    # (3b) inference-only start without the checkpoint: modules on the meta device, every weight from the blob
+    from config import select_backbone, select_head
+    from model.ppyolo import PPYOLO
+    with torch.device('meta'):
+        m4 = PPYOLO(select_backbone(cfg.backbone_type)(**cfg.backbone),
+                    select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head))
+    m4.eval()
+    m4.head.set_dropblock(is_test=True)
+    m4.attach_native_blob(bp)
+    got = m4(x, ims)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
     # (4) new parameters drop the blob
     m3.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=2))
     assert m3._plans.blob is None

@@ -454,8 +454,114 @@ def g11_state_dict_layout():
     save('g11_state_dict_layout', **arrs)
 
 
+def build_ref_train(cfg, seed=0):
+    """The model exactly as reference train.py:238-264 builds it: losses, Head(is_train=True), backbone.freeze(); left in
+    nn.Module's default training mode (train.py never calls .eval() before the loop)."""
+    from config import select_loss
+    bb = select_backbone(cfg.backbone_type)(**cfg.backbone)
+    iou_loss = select_loss(cfg.iou_loss_type)(**cfg.iou_loss)
+    iou_aware = select_loss(cfg.iou_aware_loss_type)(**cfg.iou_aware_loss) if cfg.head['iou_aware'] else None
+    yolo_loss = select_loss(cfg.yolo_loss_type)(iou_loss=iou_loss, iou_aware_loss=iou_aware, **cfg.yolo_loss)
+    hd = select_head(cfg.head_type)(yolo_loss=yolo_loss, is_train=True, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes, seed=seed), strict=True)
+    bb.freeze()
+    return m
+
+
+def synth_gt(N, S, cfg, seed):
+    """Deterministic ground truth in the reader's format (normalised cx, cy, w, h; 50 slots per image, zero padded) and
+    the YOLO targets made from it by the REFERENCE's own Gt2YoloTarget (tools/transform.py:1211-1316)."""
+    _cv2_stub()
+    from tools.transform import Gt2YoloTarget
+    rng = np.random.RandomState(seed)
+    samples = []
+    for n in range(N):
+        k = 3 + n
+        gt_bbox = np.zeros((50, 4), np.float32)
+        gt_class = np.zeros((50,), np.int32)
+        gt_score = np.zeros((50,), np.float32)
+        wh = rng.uniform(0.08, 0.7, size=(k, 2))
+        c = rng.uniform(0.15, 0.85, size=(k, 2))
+        gt_bbox[:k] = np.concatenate([c, wh], 1)
+        gt_class[:k] = rng.randint(0, 80, size=k)
+        gt_score[:k] = np.where(rng.rand(k) < 0.3, rng.uniform(0.3, 0.9, size=k), 1.0)       # mixup leaves scores < 1
+        samples.append(dict(image=np.zeros((3, S, S), np.float32), gt_bbox=gt_bbox, gt_class=gt_class, gt_score=gt_score))
+    op = Gt2YoloTarget(anchors=cfg.head['anchors'], anchor_masks=cfg.head['anchor_masks'],
+                       downsample_ratios=cfg.head['downsample'], num_classes=80)
+    samples = op(samples)
+    L = len(cfg.head['anchor_masks'])
+    targets = [np.stack([smp['target%d' % i] for smp in samples]) for i in range(L)]
+    return (np.stack([smp['gt_bbox'] for smp in samples]), np.stack([smp['gt_class'] for smp in samples]),
+            np.stack([smp['gt_score'] for smp in samples]), targets)
+
+
+def grad_digest(g):
+    """[sum, sum|.|, l2] in float64 + 64 strided samples: pins a gradient tensor without storing all of it."""
+    d = g.detach().double().reshape(-1)
+    step = max(1, d.numel() // 64)
+    return np.array([d.sum().item(), d.abs().sum().item(), d.pow(2).sum().sqrt().item()]), d[::step][:64].float().numpy()
+
+
+def g12_train_step():
+    """Config (5), SURVEY 8f rank 2: ONE training forward + backward of the reference (train.py:416-443 up to
+    all_loss.backward()): the loss terms, the raw head outputs of the training-mode forward (BatchNorm on batch
+    statistics everywhere -- backbone.freeze() only stops gradients --, DropBlock drawing from torch's global RNG),
+    d loss / d head outputs, digests of every parameter gradient, and the BatchNorm running statistics after the step."""
+    for tag, C, S, N, seed in (('r18vd_96', PPYOLO_r18vd_Config, 96, 2, 0), ('r50vd_96', PPYOLO_2x_Config, 96, 2, 0)):
+        cfg = C()
+        m = build_ref_train(cfg, seed)
+        assert m.training
+        x = synth.synth_images(N, S, seed=1234)
+        gt_bbox, gt_class, gt_score, targets = synth_gt(N, S, cfg, seed=77)
+        assert all(t[:, :, 5].sum() > 0 for t in targets[-2:])
+        torch.manual_seed(4321)                                  # DropBlock's torch.rand
+        feats = m.backbone(x)
+        outs = m.head._get_outputs(feats)
+        for o in outs:
+            o.retain_grad()
+        hd = m.head
+        losses = hd.yolo_loss(outs, torch.from_numpy(gt_bbox), torch.from_numpy(gt_class), torch.from_numpy(gt_score),
+                              [torch.from_numpy(t) for t in targets], hd.anchors, hd.anchor_masks, hd.mask_anchors, hd.num_classes)
+        all_loss = 0.0
+        for k in losses:
+            all_loss = all_loss + losses[k]
+        all_loss.backward()
+        arrs = dict(meta=np.array([S, N, seed, 1234, 4321]), gt_bbox=gt_bbox, gt_class=gt_class, gt_score=gt_score,
+                    loss_names=np.array(list(losses.keys())), loss_values=np.array([float(losses[k]) for k in losses], np.float32),
+                    all_loss=np.array(float(all_loss), np.float32))
+        for i, t in enumerate(targets):
+            arrs['target%d' % i] = t
+        for i, o in enumerate(outs):
+            arrs['out%d' % i] = o.detach()
+            arrs['dout%d' % i] = o.grad
+        names, digs, samples = [], [], []
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                assert not p.requires_grad and k.startswith('backbone.'), k
+                continue
+            a, b = grad_digest(p.grad)
+            names.append(k); digs.append(a); samples.append(np.pad(b, (0, 64 - len(b))))
+        assert all(n.startswith('head.') for n in names)
+        arrs.update(grad_names=np.array(names), grad_digest=np.stack(digs), grad_samples=np.stack(samples))
+        sd = m.state_dict()
+        for k in ('backbone.stage1_conv1_1.bn.running_mean', 'backbone.stage1_conv1_1.bn.running_var',
+                  'head.yolo_output_convs.0.conv.bias'):
+            arrs['after.' + k] = sd[k]
+        bnk = [k for k in sd if k.startswith('head.') and k.endswith('running_var')][-1]
+        arrs['after_name'] = np.array(bnk)
+        arrs['after_value'] = sd[bnk]
+        # full gradients of the small tensors: the three output convolutions
+        for i in range(len(outs)):
+            arrs['gw_out%d' % i] = getattr(m.head.yolo_output_convs[i].conv.weight, 'grad')
+            arrs['gb_out%d' % i] = getattr(m.head.yolo_output_convs[i].conv.bias, 'grad')
+        print(tag, {k: float(losses[k]) for k in losses}, 'trainable tensors', len(names))
+        save('g12_train_' + tag, **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

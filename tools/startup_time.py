@@ -32,6 +32,26 @@ def child(which, S, N, mode):
     t0 = time.perf_counter()
     from config import select_backbone, select_head
     from model.ppyolo import PPYOLO
+    if mode == 'blob_only':          # no checkpoint at all: modules on the meta device, every weight from the blob
+        with torch.device('meta'):
+            m = PPYOLO(select_backbone(cfg.backbone_type)(**cfg.backbone),
+                       select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head))
+        m.eval()
+        m.head.set_dropblock(is_test=True)
+        t1 = time.perf_counter()
+        m.attach_native_blob(bp)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out = m(x, ims)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        m(x, ims)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        print(json.dumps(dict(mode=mode, construct_s=round(t1 - t0, 3), blob_s=round(t2 - t1, 3), first_forward_s=round(t3 - t2, 3),
+                              second_forward_s=round(t4 - t3, 4), total_to_first_result_s=round(t3 - t0, 3),
+                              detections=[int(o.shape[0]) for o in out])))
+        return
     m = PPYOLO(select_backbone(cfg.backbone_type)(**cfg.backbone),
                select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head))
     m.load_state_dict(torch.load(pt))
@@ -60,7 +80,7 @@ if __name__ == '__main__':
         child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     else:
         which, S, N = (sys.argv[1:] + ['r50', '608', '8'])[:3]
-        for mode in ('prepare', 'plain', 'blob', 'plain', 'blob'):
+        for mode in ('prepare', 'plain', 'blob', 'blob_only', 'plain', 'blob', 'blob_only'):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', which, S, N, mode], stdout=subprocess.PIPE,
                                universal_newlines=True)
             print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED rc %d' % r.returncode)
