@@ -108,6 +108,27 @@ int ppy_conv2d_num_configs(void);
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);
 
+/* ------------------------------------------------------------------------------------
+ * Backward of the convolution -- training step, SURVEY 8f rank 2 / BASELINE config 5: what torch autograd computes for
+ * the F.conv2d inside Conv2dUnit.forward (reference model/custom_layers.py:243-253) when train.py:441 calls
+ * all_loss.backward().  Same tensors and layouts as ppy_conv2d_bn_act_f32: x [N,H,W,C] (ld x_ld), w [K][R][S][C],
+ * dy = d loss / d conv output [N,Ho,Wo,K] (ld dy_ld; the BN / activation backward is the caller's, upstream of dy).
+ *   ppy_conv2d_dgrad_f32: dx[n,h,w,c] = sum_{k,r,s} dy[n,h+pad-r,w+pad-s,k] * w[k,r,s,c]  (written, not accumulated).
+ *     stride 1 only (PPY_ERR_UNSUPPORTED otherwise: with the reference's freeze_at = 5 only the head trains and it has
+ *     no strided convolution).  Runs the forward implicit-GEMM kernels on the flipped / transposed weights; K need not
+ *     be a multiple of 32 (the 258-channel output convolutions are zero-padded in the workspace).
+ *   ppy_conv2d_wgrad_f32: dw[k,r,s,c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
+ *     (written, not accumulated; any stride / C / K).  Exact fp32 MFMA; pixel slices are combined in a fixed order, so
+ *     results are run-to-run identical.
+ * ws: ppy_conv2d_{dgrad,wgrad}_workspace_bytes() bytes, 256-byte aligned.
+ */
+int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H, int W,
+                         int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
+size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
+                         int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
+size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+
 /* First backbone conv, `stage1_conv1_1` (reference model/resnet_vd.py:100, :133): 3x3
  * stride-2 conv C_in=3 -> K (K % 4 == 0, K <= 64) + BN affine + ReLU, reading the
  * caller's NCHW input directly and writing NHWC (fuses the layout change).

@@ -1,0 +1,277 @@
+// Backward of the convolution for the training step (BASELINE config 5): what torch
+// autograd computes for the F.conv2d of Conv2dUnit.forward (reference model/custom_layers.py:243-253) under
+// all_loss.backward() (reference train.py:441).  With the reference's freeze_at = 5 only the head trains, and every head
+// convolution is 1x1 or 3x3 with stride 1 (model/head.py:146-231, :334-364).
+//
+//   dgrad:  dx[n,h,w,c] = sum_{k,r,s} dy[n, h+pad-r, w+pad-s, k] * w[k,r,s,c]
+//           = the FORWARD convolution of dy with the flipped / transposed weights w'[c][r'][s'][k] = w[k][R-1-r'][S-1-s'][c]
+//           and pad' = R-1-pad: one re-layout kernel (weights change every step, so it is per call), then the implicit-GEMM
+//           kernels of conv_igemm.hip / conv_x3.hip (exact bf16x3 split of w', done here as well) do the work.
+//   wgrad:  dw[k,r,s,c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride+r-pad, wo*stride+s-pad, c]
+//           a GEMM whose REDUCTION index is the pixel: both operands are pixel-major in HBM (NHWC), which is exactly the
+//           operand order of v_mfma_f32_32x32x2_f32 -- lane l supplies A[i = l%32][kk = l/32] = dy[pixel kk][k0 + i] and
+//           B[kk][j = l%32] = x[pixel kk'][c0 + j]: the 32 lanes of a half-wave read 128 contiguous bytes, no
+//           transposition anywhere.  One workgroup = one 128x128 (k, c) tile of ONE tap over a slice of the pixels;
+//           the slices are combined in a fixed order by a second kernel (deterministic, no atomics).  Exact fp32.
+#include "conv_shared.h"
+
+namespace {
+
+// w[K][R][S][C] -> wt[C][R][S][Kp] with both taps flipped and zero rows for k in [K, Kp); also ones[C], zeros[C]
+__global__ void __launch_bounds__(256) dgrad_weights_kernel(const float *w, float *wt, float *ones, float *zeros, int K, int Kp,
+                                                            int R, int S, int C) {
+    const long long total = (long long)C * R * S * Kp;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < C) {
+        ones[i] = 1.0f;
+        zeros[i] = 0.0f;
+    }
+    if (i >= total) return;
+    const int k = (int)(i % Kp);
+    long long t = i / Kp;
+    const int s = (int)(t % S);
+    t /= S;
+    const int r = (int)(t % R);
+    const int c = (int)(t / R);
+    wt[i] = k < K ? w[(((long long)k * R + (R - 1 - r)) * S + (S - 1 - s)) * C + c] : 0.0f;
+}
+
+// dy [P][ld] -> padded [P][Kp] (zero channels beyond K): only when K % 32 != 0 (the 258-channel output convolutions)
+__global__ void __launch_bounds__(256) pad_channels_kernel(const float *src, int ld, float *dst, int K, int Kp, long long P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * Kp) return;
+    const int k = (int)(i % Kp);
+    const long long p = i / Kp;
+    dst[i] = k < K ? src[p * ld + k] : 0.0f;
+}
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *out;              // dw (one slice) or the partial sums [slices][K][R][S][C]
+    int x_ld, dy_ld;
+    int N, H, W, C, Ho, Wo, K, R, S, stride, pad;
+    int P, pix_per_slice, tiles_c;
+};
+
+constexpr int WG_TK = 128, WG_TC = 128;       // workgroup tile: output channels x input channels
+constexpr int PIX = 16;                       // pixels per pipeline step (8 MFMA depths of 2)
+
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wk = wave >> 1, wc = wave & 1;                   // 2 x 2 waves, 64 x 64 each
+    const int tile = blockIdx.x;
+    const int tk = tile / p.tiles_c, tc = tile - tk * p.tiles_c;
+    const int tap = blockIdx.y, r = tap / p.S, s = tap - r * p.S;
+    const int k_base = tk * WG_TK + wk * 64, c_base = tc * WG_TC + wc * 64;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int p_begin = blockIdx.z * p.pix_per_slice;
+    const int p_end = min(p_begin + p.pix_per_slice, p.P);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const bool kok[2] = {k_base + l32 < p.K, k_base + 32 + l32 < p.K};
+    const bool cok[2] = {c_base + l32 < p.C, c_base + 32 + l32 < p.C};
+    const int hw = p.Ho * p.Wo;
+    // this lane walks the pixels p_begin + half, +2, +4, ...: (n, ho, wo) kept incrementally
+    int pix = p_begin + half;
+    int n = pix / hw, rem = pix - n * hw;
+    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+
+    float a[2][PIX / 2], b[2][PIX / 2];
+    auto fetch = [&](float (&fa)[2][PIX / 2], float (&fb)[2][PIX / 2]) {
+#pragma unroll
+        for (int q = 0; q < PIX / 2; ++q) {
+            const bool pok = pix < p_end;
+            const int hi = ho * p.stride + r - p.pad, wi = wo * p.stride + s - p.pad;
+            const bool inside = pok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float *dyp = p.dy + (long long)pix * p.dy_ld + k_base + l32;
+            const float *xp = p.x + (((long long)n * p.H + hi) * p.W + wi) * p.x_ld + c_base + l32;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i][q] = (pok && kok[i]) ? dyp[32 * i] : 0.0f;
+                fb[i][q] = (inside && cok[i]) ? xp[32 * i] : 0.0f;
+            }
+            pix += 2;
+            wo += 2;
+            while (wo >= p.Wo) {
+                wo -= p.Wo;
+                if (++ho == p.Ho) {
+                    ho = 0;
+                    ++n;
+                }
+            }
+        }
+    };
+    fetch(a, b);
+    for (int p0 = p_begin; p0 < p_end; p0 += PIX) {
+        float na[2][PIX / 2], nb[2][PIX / 2];
+        fetch(na, nb);                                      // next step's operands in flight under this step's MFMAs
+#pragma unroll
+        for (int q = 0; q < PIX / 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PIX / 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][q] = na[i][q];
+                b[i][q] = nb[i][q];
+            }
+    }
+    // accumulator element e of tile (i, j): row k = (e&3) + 8*(e>>2) + 4*half, column c = l32
+    float *out = p.out + (long long)blockIdx.z * p.K * p.R * p.S * p.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c_base + 32 * j + l32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k_base + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (k < p.K && c < p.C) out[(((long long)k * p.R + r) * p.S + s) * p.C + c] = acc[i][j][e];
+            }
+        }
+#endif
+}
+
+// dw[i] = sum over the slices in index order (a fixed summation order: run-to-run identical results)
+__global__ void __launch_bounds__(256) wgrad_combine_kernel(const float *part, float *dw, long long n, int slices) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if ((n & 3) == 0) {       // (n % 4 == 0 whenever C % 4 == 0: slices stay 16-byte aligned)
+        floatx4 v = *reinterpret_cast<const floatx4 *>(part + i);
+        for (int sl = 1; sl < slices; ++sl) {
+            const floatx4 u = *reinterpret_cast<const floatx4 *>(part + sl * n + i);
+            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+        *reinterpret_cast<floatx4 *>(dw + i) = v;
+    } else {
+        for (long long t = i; t < min(i + 4, n); ++t) {
+            float v = part[t];
+            for (int sl = 1; sl < slices; ++sl) v += part[sl * n + t];
+            dw[t] = v;
+        }
+    }
+}
+
+static int wgrad_slices(int K, int C, int R, int S, int P) {
+    // enough workgroups for ~3 rounds over the 256 CUs, at least 256 pixels per slice
+    const int tiles = ceil_div(K, WG_TK) * ceil_div(C, WG_TC) * R * S;
+    int sl = ceil_div(768, tiles);
+    const int maxsl = P / 256 > 0 ? P / 256 : 1;
+    if (sl > maxsl) sl = maxsl;
+    if (sl > 64) sl = 64;
+    return sl < 1 ? 1 : sl;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    Geometry g;
+    if (stride != 1 || !conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
+    const int Kp = (K + 31) / 32 * 32;
+    size_t b = align256((size_t)C * R * S * Kp * 4) + align256((size_t)C * 4) * 2;      // w', ones, zeros
+    b += align256((size_t)C * R * S * Kp * 6);                                          // three bf16 planes of w'
+    if (Kp != K) b += align256((size_t)g.M * Kp * 4);                                   // channel-padded dy
+    return b + align256(ppy_conv2d_workspace_bytes(N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, -1, 0));
+}
+
+extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H,
+                                    int W, int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes,
+                                    void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && w_krsc && dx && N > 0 && C > 0 && K > 0 && dy_ld >= K && dx_ld >= C);
+    if (stride != 1) return PPY_ERR_UNSUPPORTED;           // (the trainable head has no strided convolution)
+    Geometry g;
+    if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
+    PPY_CHECK_ARG(dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0 && R - 1 - pad >= 0);
+    const size_t need = ppy_conv2d_dgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 255) != 0) return PPY_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Kp = (K + 31) / 32 * 32;
+    char *base = (char *)ws;
+    float *wt = (float *)base;
+    base += align256((size_t)C * R * S * Kp * 4);
+    float *ones = (float *)base;
+    base += align256((size_t)C * 4);
+    float *zeros = (float *)base;
+    base += align256((size_t)C * 4);
+    void *planes = base;
+    base += align256((size_t)C * R * S * Kp * 6);
+    const long long total = (long long)C * R * S * Kp;
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_krsc, wt, ones, zeros,
+                       K, Kp, R, S, C);
+    int rc = ppy_launch_status();
+    if (rc != PPY_OK) return rc;
+    rc = ppy_conv2d_split_weights_bf16x3(wt, total, planes, stream);
+    if (rc != PPY_OK) return rc;
+    const float *src = dy;
+    int src_ld = dy_ld;
+    if (Kp != K) {
+        float *padded = (float *)base;
+        base += align256((size_t)g.M * Kp * 4);
+        const long long n = (long long)g.M * Kp;
+        hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, dy_ld, padded, K, Kp,
+                           (long long)g.M);
+        rc = ppy_launch_status();
+        if (rc != PPY_OK) return rc;
+        src = padded;
+        src_ld = Kp;
+    }
+    const size_t rest = ws_bytes - (size_t)(base - (char *)ws);
+    // dy is [N, Ho, Wo, K]; for stride 1 the forward convolution with pad' = R-1-pad maps it back onto [N, H, W, C]
+    return ppy_conv2d_bn_act_f32(src, src_ld, wt, planes, nullptr, ones, nullptr, zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N,
+                                 g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, -1, 0, nullptr, nullptr, base, rest,
+                                 stream);
+}
+
+extern "C" size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0) return 0;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const int sl = wgrad_slices(K, C, R, S, N * Ho * Wo);
+    return sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
+}
+
+extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
+                                    int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && dy && dw_krsc && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
+    PPY_CHECK_ARG(x_ld >= C && dy_ld >= K);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    PPY_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1LL << 31));
+    WgradArgs p;
+    p.x = x; p.dy = dy; p.x_ld = x_ld; p.dy_ld = dy_ld;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.P = N * Ho * Wo;
+    const int sl = wgrad_slices(K, C, R, S, p.P);
+    const size_t need = sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
+    if (need && (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0)) return PPY_ERR_WORKSPACE;
+    p.pix_per_slice = ceil_div(ceil_div(p.P, sl), PIX) * PIX;
+    const int slices = ceil_div(p.P, p.pix_per_slice);
+    p.tiles_c = ceil_div(C, WG_TC);
+    p.out = slices > 1 ? (float *)ws : dw_krsc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(ceil_div(K, WG_TK) * p.tiles_c, R * S, slices), dim3(256), 0, st, p);
+    int rc = ppy_launch_status();
+    if (rc != PPY_OK) return rc;
+    if (slices > 1) {
+        const long long n = (long long)K * R * S * C;
+        hipLaunchKernelGGL(wgrad_combine_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, (const float *)ws, dw_krsc,
+                           n, slices);
+        rc = ppy_launch_status();
+    }
+    return rc;
+}

@@ -135,6 +135,37 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
+def _bwd_ws(nbytes, device):
+    return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device)
+
+
+def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None):
+    """dy: View [N,Ho,Wo,K]; w_krsc [K,R,S,C]; dx: View [N,H,W,C] (written).  See ppy_conv2d_dgrad_f32."""
+    _dev(dy.t, w_krsc, dx.t)
+    K, R, S, C = w_krsc.shape
+    assert K == dy.C and C == dx.C and w_krsc.is_contiguous()
+    need = int(lib().ppy_conv2d_dgrad_workspace_bytes(dx.N, dx.H, dx.W, C, K, R, S, stride, pad))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = _bwd_ws(need, dx.t.device)
+    check(lib().ppy_conv2d_dgrad_f32(dy.ptr, dy.ld, w_krsc.data_ptr(), dx.ptr, dx.ld, dx.N, dx.H, dx.W, C, K, R, S, stride, pad,
+                                     ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_conv2d_dgrad_f32')
+    return ws
+
+
+def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None):
+    """x: View [N,H,W,C]; dy: View [N,Ho,Wo,K]; dw_krsc [K,R,S,C] (written).  See ppy_conv2d_wgrad_f32."""
+    _dev(x.t, dy.t, dw_krsc)
+    K, R, S, C = dw_krsc.shape
+    assert K == dy.C and C == x.C and dw_krsc.is_contiguous() and dw_krsc.dtype == torch.float32
+    need = int(lib().ppy_conv2d_wgrad_workspace_bytes(x.N, x.H, x.W, C, K, R, S, stride, pad))
+    if need and (ws is None or ws.numel() * ws.element_size() < need):
+        ws = _bwd_ws(need, x.t.device)
+    check(lib().ppy_conv2d_wgrad_f32(x.ptr, x.ld, dy.ptr, dy.ld, dw_krsc.data_ptr(), x.N, x.H, x.W, C, K, R, S, stride, pad,
+                                     _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream()),
+          'ppy_conv2d_wgrad_f32')
+    return ws
+
+
 def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None):
     _dev(x_nchw, w_kcrs, scale, shift, y.t)
     N, C, H, W = x_nchw.shape

@@ -1,0 +1,130 @@
+"""Backward kernels of the training step: ppy_conv2d_dgrad_f32 / ppy_conv2d_wgrad_f32 through
+the C ABI against torch autograd of F.conv2d on the CPU (the reference's backward IS torch autograd: train.py:441), on the
+head's layer shapes, on ragged shapes, and on the gradients the REFERENCE produced in its own training step (golden g12:
+the three output convolutions' weight gradients and d loss / d head outputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _ref(x, w, dy, stride, pad):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad)
+    y.backward(dy)
+    return x.grad, w.grad
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [  # N, H, W, C, K, R, stride: head layer shapes at small maps + ragged ones
+    (2, 19, 19, 512, 1024, 3, 1), (2, 19, 19, 1024, 512, 1, 1), (2, 19, 19, 1024, 258, 1, 1), (1, 38, 38, 256, 512, 3, 1),
+    (2, 12, 12, 128, 258, 1, 1), (3, 7, 5, 64, 96, 3, 1), (1, 9, 9, 32, 40, 3, 1), (2, 6, 6, 96, 255, 1, 1), (1, 1, 1, 64, 64, 1, 1),
+    (2, 11, 3, 160, 33, 3, 1), (5, 2, 2, 32, 130, 3, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_dgrad_and_wgrad_vs_autograd(case):
+    from ppyolo_hip import ops
+    N, H, W, C, K, R, stride = case
+    pad = (R - 1) // 2
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, K, Ho, Wo, generator=g) * torch.exp(torch.randn(N, K, Ho, Wo, generator=g))
+    dx_ref, dw_ref = _ref(x, w, dy, stride, pad)
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.full((N, H, W, C), 7.0).cuda()
+    dw = torch.full((K, R, R, C), 7.0).cuda()
+    ops.conv2d_dgrad(ops.View(dyd), wk, ops.View(dx), stride, pad)
+    ops.conv2d_wgrad(ops.View(xd), ops.View(dyd), dw, stride, pad)
+    torch.cuda.synchronize()
+    e_dx, e_dw = _rel(dx.cpu().permute(0, 3, 1, 2), dx_ref), _rel(dw.cpu().permute(0, 3, 1, 2), dw_ref)
+    assert e_dx <= 2e-5 and e_dw <= 2e-5, (case, e_dx, e_dw)
+    # run-to-run identical (fixed summation order of the pixel slices)
+    dw2 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(ops.View(xd), ops.View(dyd), dw2, stride, pad)
+    assert torch.equal(dw, dw2)
+
+
+def test_wgrad_strided_and_channel_slices():
+    """wgrad with stride 2 and operands that are channel slices of wider buffers (ld > C), as concat buffers are."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(7)
+    N, H, W, C, K, R, stride, pad = 2, 13, 10, 64, 48, 3, 2, 1
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * 0.05
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, K, Ho, Wo, generator=g)
+    _, dw_ref = _ref(x, w, dy, stride, pad)
+    xwide = torch.randn(N, H, W, C + 32, generator=g).cuda()
+    xwide[..., 16:16 + C] = nhwc(x).cuda()
+    dywide = torch.randn(N, Ho, Wo, K + 16, generator=g).cuda()
+    dywide[..., 8:8 + K] = nhwc(dy).cuda()
+    dw = torch.zeros(K, R, R, C).cuda()
+    ops.conv2d_wgrad(ops.View(xwide, 16, C), ops.View(dywide, 8, K), dw, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu().permute(0, 3, 1, 2), dw_ref) <= 2e-5
+
+
+def test_dgrad_refuses_stride2():
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import PPYoloHipError
+    dy = torch.zeros(1, 4, 4, 32).cuda()
+    with pytest.raises(PPYoloHipError, match='outside what the kernels implement|unsupported'):
+        ops.conv2d_dgrad(ops.View(dy), torch.zeros(32, 3, 3, 32).cuda(), ops.View(torch.zeros(1, 8, 8, 32).cuda()), 2, 1)
+
+
+@pytest.mark.parametrize('tag', ['r18vd_96', 'r50vd_96'])
+def test_output_conv_gradients_of_the_reference_step(golden, tag):
+    """The reference's own training step (g12): d loss / d head outputs -> weight gradient of each output convolution,
+    given the tip activations recomputed by the oracle's training-mode forward."""
+    from conftest import build_model
+    from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+    from oracle import ppyolo_oracle as orc, train_oracle as trn
+    from ppyolo_hip import ops, synth
+    g = golden('g12_train_' + tag)
+    S, N, wseed, iseed, rseed = [int(v) for v in g['meta']]
+    cfg = {'r18vd_96': PPYOLO_r18vd_Config, 'r50vd_96': PPYOLO_2x_Config}[tag]()
+    _, sd = build_model(cfg, wseed, 'cpu')
+    x = synth.synth_images(N, S, seed=iseed)
+    # tip activations (inputs of the output convolutions) of the training-mode forward, captured from the oracle
+    tips = []
+    real = orc.conv_unit
+
+    def spy(sdx, prefix, t, stride=1, act=None):
+        if prefix.startswith('head.yolo_output_convs.'):
+            tips.append(t.detach())
+        return real(sdx, prefix, t, stride, act)
+    orc.conv_unit = spy
+    try:
+        torch.manual_seed(rseed)
+        outs, _ = trn.forward_train(sd, cfg, x)
+    finally:
+        orc.conv_unit = real
+    for i, (tip, out) in enumerate(zip(tips, outs)):
+        assert torch.equal(out.detach(), torch.from_numpy(g['out%d' % i]))
+        dout = torch.from_numpy(g['dout%d' % i])
+        w = sd['head.yolo_output_convs.%d.conv.weight' % i]
+        K, C = w.shape[0], w.shape[1]
+        dw = torch.zeros(K, 1, 1, C).cuda()
+        ops.conv2d_wgrad(ops.View(nhwc(tip).cuda()), ops.View(nhwc(dout).cuda()), dw, 1, 0)
+        dx = torch.zeros(N, tip.shape[2], tip.shape[3], C).cuda()
+        ops.conv2d_dgrad(ops.View(nhwc(dout).cuda()), w.permute(0, 2, 3, 1).contiguous().cuda(), ops.View(dx), 1, 0)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(g['gw_out%d' % i])
+        assert _rel(dw.cpu().permute(0, 3, 1, 2), want) <= 2e-5, 'output conv %d weight gradient' % i
+        dx_ref = F.conv_transpose2d(dout, w)
+        assert _rel(dx.cpu().permute(0, 3, 1, 2), dx_ref) <= 2e-5
