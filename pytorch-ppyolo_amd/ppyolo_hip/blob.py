@@ -149,6 +149,8 @@ def load(path, device, expect_fingerprint=None):
     device = torch.device(device)
     if device.type != 'cuda':
         raise PPYoloHipError('a weight blob is loaded onto a ROCm device (got %s); there is no CPU path' % device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
     hdr, host = read(path, expect_fingerprint)
     dev = torch.empty(hdr['data_bytes'], dtype=torch.uint8, device=device)
     dev.copy_(host)

@@ -196,11 +196,11 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     if (stride != 1) return PPY_ERR_UNSUPPORTED;           // (the trainable head has no strided convolution)
     Geometry g;
     if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
-    PPY_CHECK_ARG(dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0 && R - 1 - pad >= 0);
+    const int Kp = (K + 31) / 32 * 32;
+    PPY_CHECK_ARG(R - 1 - pad >= 0 && (Kp != K || (dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0)));      // (a padded copy is aligned by construction)
     const size_t need = ppy_conv2d_dgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255) != 0) return PPY_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int Kp = (K + 31) / 32 * 32;
     char *base = (char *)ws;
     float *wt = (float *)base;
     base += align256((size_t)C * R * S * Kp * 4);

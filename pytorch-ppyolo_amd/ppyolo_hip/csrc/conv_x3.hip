@@ -111,7 +111,14 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long
 // F16 = false: "bf16x3" (3 bf16 pieces, 6 products).  F16 = true: "f16x2" -- 2 fp16 pieces of the operands pre-scaled
 // by powers of two into the fp16 range (weights per output channel at plan time, activations by the producer-tracked
 // maximum of the input tensor), 3 products on v_mfma_f32_32x32x16_f16; see the file header.
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC>
+// SLAB = true ("slab reuse", 3x3 / stride 1 / pad 1 layers, f16x2 only): the three taps (r, 0..2) of an output tile of BM
+// consecutive pixels read the BM + 2 consecutive input pixels  m0 - 1 + (r-1)*W ... , so ONE slab of BM + 8 rows per
+// (channel chunk, r) is DMA'd instead of three BM-row tiles (A bytes / 2.8, all operand bytes -32 % on a 128x128 tile);
+// the fragment of tap s is the slab read at row offset s, and a (pixel, tap) pair that falls into the padding is zeroed by
+// selecting 0 instead of the activation scale in the operand split of that lane.  Two slabs alternate; the pieces of the
+// next slab ride in the DMA groups of the first two chunks of a super-chunk (the third carries out-of-range dummies so
+// that every group has the same G pieces and the counted vmcnt waits stay what they are).
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -121,10 +128,16 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     constexpr int NP = F16 ? 2 : 3;                    // pieces per operand = weight planes
     constexpr int B_ROWS = NP * BN;
     static_assert(BM % (8 * NW) == 0 && B_ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
-    constexpr int A_PASS = BM / (8 * NW), B_PASS = B_ROWS / (16 * NW);
+    static_assert(!SLAB || F16, "the slab variant zeroes padding taps through the f16x2 activation scale");
+    constexpr int SLAB_PIECES = BM / 8 + 1;                        // slab rows 0 .. BM+7 (BM + 2 are used)
+    constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
+    constexpr int SP_W = (SLAB_PIECES + NW - 1) / NW;              // slab pieces per wave per super-chunk
+    constexpr int AS = (SP_W + 1) / 2;                             // ... carried by each of two DMA groups
+    constexpr int A_PASS = SLAB ? AS : BM / (8 * NW), B_PASS = B_ROWS / (16 * NW);
     constexpr int G = A_PASS + B_PASS;                 // DMA instructions per wave per chunk
-    constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64;
+    constexpr int A_BYTES = SLAB ? 0 : BM * 128, B_BYTES = B_ROWS * 64;      // (slab variant: stages hold the weights only)
     constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int STAGE_BASE = SLAB ? 2 * SLAB_BYTES + NW * 1024 : 0;        // two slabs + 1 KB per wave for the dummy pieces
     typedef __attribute__((address_space(3))) void *lds_ptr;
 
     extern __shared__ __attribute__((aligned(16))) char smem_x3[];
@@ -164,7 +177,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     const unsigned OOB = 0xFFFFFFF0u;
     const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
     unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
-    {
+    if constexpr (!SLAB) {
         const int drow = lane >> 3, dslot = lane & 7;
         // (n, ho, wo) of the first row by division, of the following rows (8*NW further each) incrementally
         const int step_rows = 8 * NW;
@@ -220,16 +233,57 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     __amdgpu_buffer_rsrc_t cur_ra, cur_rb;
     unsigned cur_tapbit = 0, cur_lds = 0;
     bool cur_have = false;
+    // slab variant: the group issued at mid-chunk k (k = -1 for the last group of the prologue when three stages are in
+    // flight) carries the pieces of the slab of super-chunk  (k + L) / 3 + 1  at position  (k + L) % 3,  L = NS - 2
+    const int Mpix = p.N * p.H * p.W;
+    int sl_q = -2;                               // q = k + L of the group being issued; the prologue groups are k = -NS .. -1, i.e. q = -2 ..
+    int sl_pos = 2, sl_pb = 0, sl_dst = 0;       // position in the super-chunk, first pixel of the slab, LDS offset of the slab
+    bool sl_have = false;
+    const int drow8 = lane >> 3, dslot8 = lane & 7;
+    auto slab_begin = [&]() {                    // (called from issue_begin)
+        sl_have = false;
+        sl_pos = 2;
+        if (sl_q >= 0) {
+            const int sc = sl_q / 3 + 1;         // target super-chunk, local to this split
+            sl_pos = sl_q - (sc - 1) * 3;
+            if (sl_pos < 2 && sc * 3 < nchunks) {
+                const int kc = kc_begin + sc * 3;
+                const int cc = kc / 9, r = (kc - cc * 9) / 3;
+                sl_pb = m0 - 1 + (r - 1) * p.W;
+                sl_dst = (sc & 1) * SLAB_BYTES;
+                cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(p.x) + (long long)cc * 128), 0,
+                                                           0xFFFFFF00u, 0x00020000);
+                sl_have = true;
+            }
+        }
+        ++sl_q;
+    };
+    auto slab_piece = [&](int d) {               // d in [0, AS)
+        const int idx = (sl_pos * AS + d) * NW + wave;           // piece of the slab = 8 rows
+        const bool real = sl_have && sl_pos < 2 && idx < SLAB_PIECES;
+        const int t = idx * 8 + drow8;
+        const int pix = sl_pb + t;
+        const unsigned off = (real && (unsigned)pix < (unsigned)Mpix)
+                                 ? (unsigned)pix * (unsigned)(p.x_ld * 4) + (unsigned)((dslot8 ^ ((t >> 1) & 7)) << 4)
+                                 : OOB;
+        const unsigned dst = real ? (unsigned)(sl_dst + idx * 1024) : (unsigned)(2 * SLAB_BYTES + wave * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + dst), 16, off, 0, 0, 0);
+    };
     auto issue_begin = [&](int stage, bool have) {
         if (PPY_X3_ABL == 6) have = false;       // ablation: every piece out of range (issue + LDS zero-fill cost, no memory traffic)
         const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
         const long long b_uni = (F16 && PPY_X3_BBLOCK) ? ((long long)l_tap * (p.C / 32) + l_cc) * p.K * 64
                                     : ((long long)l_tap * p.C + l_cc * 32) * 2;
-        cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+        if constexpr (SLAB) {
+            cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, 0xFFFFFF00u, 0x00020000);
+            slab_begin();
+        } else {
+            cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+        }
         cur_rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? b_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
         cur_tapbit = have ? (1u << l_tap) : 0u;
         cur_have = have;
-        cur_lds = (unsigned)(stage * STAGE + wave * 1024);
+        cur_lds = (unsigned)(STAGE_BASE + stage * STAGE + wave * 1024);
         ++l_tap;
         ++l_s;
         if (l_s == p.S) { l_s = 0; ++l_r; }
@@ -238,6 +292,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     auto issue_piece = [&](int d) {       // d in [0, G): compile-time after unrolling
         if (d < A_PASS) {
             if (PPY_X3_ABL == 8) return;                    // (ablation: weight pieces only)
+            if constexpr (SLAB) {
+                slab_piece(d);
+                return;
+            }
             const unsigned off = (a_ok[d] & cur_tapbit) ? a_off[d] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
         } else {
@@ -280,6 +338,28 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     float sa[TM], inv_sa[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) sa[i] = inv_sa[i] = 1.0f;
+    // slab variant, "fetch context" of the chunk whose operands are being read: taps inside the image for each of this
+    // lane's fragment rows (bit r*3 + s), the scale with the padding taps zeroed, the slab and the tap's row shift
+    unsigned f_ok[TM];
+    float f_sa[TM];
+    int f_slab = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        f_ok[i] = 0;
+        f_sa[i] = 0.0f;
+    }
+    auto fetch_ctx = [&](int kc) {               // kc: chunk index in the whole reduction (tap = kc % 9)
+        const int tap = kc % 9, s_tap = tap % 3;
+        f_slab = ((kc - kc_begin) / 3 & 1) * SLAB_BYTES;
+        const int t0 = frow + s_tap, sw = (t0 >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_foff[ks][0] = t0 * 128 + (((4 * ks + 2 * fkh) ^ sw) << 4);
+            a_foff[ks][1] = t0 * 128 + (((4 * ks + 2 * fkh + 1) ^ sw) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f_sa[i] = ((f_ok[i] >> tap) & 1u) ? sa[i] : 0.0f;
+    };
 
     // One "k-step" = 16 reduction elements = one MFMA depth; a 32-deep chunk is two k-steps.
     // The wave is software-pipelined over k-steps BY HAND: the instruction stream of a step is a
@@ -315,8 +395,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         // partial products (piece of A, piece of B), smallest first; f16x2 uses the last three with pieces {0,1}
         constexpr int ta[6] = {2, 1, 0, 1, 0, 0}, tb[6] = {0, 1, 2, 0, 1, 0};
         constexpr int T0 = 6 - NPROD;
-        const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
-        const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
+        const char *a_ptr = SLAB ? smem + f_slab + wm * WM * 128 : smem + stage * STAGE + wm * WM * 128;
+        const char *b_ptr = smem + STAGE_BASE + stage * STAGE + A_BYTES + wn * WN * 64;
         floatx4 raw[TM][2];
         float ra[TM][4], rb[TM][4];
 #pragma unroll
@@ -354,12 +434,13 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                         const int st = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q = pr % 4;
                         const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
                         if constexpr (F16) {
+                            const float sc_i = SLAB ? f_sa[i] : sa[i];
                             if (st == 0) {
-                                nxt.a[i][0][q] = cvt_pk_f16(xa * sa[i], xb * sa[i]);
+                                nxt.a[i][0][q] = cvt_pk_f16(xa * sc_i, xb * sc_i);
                             } else if (st == 1) {     // residual of the SCALED value: fma(x, sa, -a0) is exact
                                 const unsigned P = nxt.a[i][0][q];
-                                ra[i][q] = fmaf(xa, sa[i], -f16_lo(P));
-                                rb[i][q] = fmaf(xb, sa[i], -f16_hi(P));
+                                ra[i][q] = fmaf(xa, sc_i, -f16_lo(P));
+                                rb[i][q] = fmaf(xb, sc_i, -f16_hi(P));
                             } else {
                                 nxt.a[i][1][q] = cvt_pk_f16(ra[i][q], rb[i][q]);
                             }
@@ -400,6 +481,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         // the end of the reduction as out-of-range dummies, so that the number of outstanding DMA pieces is the same
         // (NS-1)*G at every mid-chunk wait below.
         const int NS = p.nstages;
+        if constexpr (SLAB) {      // the first slab, in front of (= older than) the NS weight groups
+            const int cc = kc_begin / 9, r = (kc_begin - cc * 9) / 3;
+            cur_ra = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(p.x) + (long long)cc * 128), 0,
+                                                       0xFFFFFF00u, 0x00020000);
+            sl_have = true;
+            sl_pb = m0 - 1 + (r - 1) * p.W;
+            sl_dst = 0;
+#pragma unroll
+            for (int pos = 0; pos < 2; ++pos) {
+                sl_pos = pos;
+#pragma unroll
+                for (int d = 0; d < AS; ++d) slab_piece(d);
+            }
+            sl_q = -2;                 // = (k + L) of the first prologue group: k = -NS, L = NS - 2
+        }
         for (int sidx = 0; sidx < NS; ++sidx) {
             issue_begin(sidx, sidx < nchunks);
 #pragma unroll
@@ -415,7 +511,19 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                 f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite
                 sa[i] = __uint_as_float((unsigned)f << 23);
                 inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
+                if constexpr (SLAB) {          // taps of this fragment row that lie inside the image
+                    const int mr = m0 + wm * WM + i * 32 + (lane & 31);
+                    const int n = mrow / hw, rem = mrow - n * hw;
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    unsigned colmask = 0, okb = 0;
+                    for (int s2 = 0; s2 < 3; ++s2)
+                        if ((unsigned)(wo - 1 + s2) < (unsigned)p.W) colmask |= 1u << s2;
+                    for (int r = 0; r < 3; ++r)
+                        if ((unsigned)(ho - 1 + r) < (unsigned)p.H) okb |= colmask << (r * 3);
+                    f_ok[i] = mr < p.M ? okb : 0u;
+                }
             }
+            if constexpr (SLAB) fetch_ctx(kc_begin);
         }
         // chunk 0 has landed once at most the NS-1 later requests are outstanding
         if (NS == 2) {
@@ -427,8 +535,8 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         }
         __builtin_amdgcn_s_barrier();
         {   // operands of (chunk 0, k-step 0): not overlapped with anything
-            const char *a_ptr = smem + wm * WM * 128;
-            const char *b_ptr = smem + A_BYTES + wn * WN * 64;
+            const char *a_ptr = smem + wm * WM * 128;          // (slab variant: slab 0 starts at 0 as well)
+            const char *b_ptr = smem + STAGE_BASE + A_BYTES + wn * WN * 64;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
@@ -437,9 +545,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float xa = q < 2 ? lo[2 * q] : hi[2 * q - 4], xb = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
-                        const unsigned P0 = cvt_pk_f16(xa * sa[i], xb * sa[i]);
+                        const float sc_i = SLAB ? f_sa[i] : sa[i];
+                        const unsigned P0 = cvt_pk_f16(xa * sc_i, xb * sc_i);
                         f0.a[i][0][q] = P0;
-                        f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sa[i], -f16_lo(P0)), fmaf(xb, sa[i], -f16_hi(P0)));
+                        f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sc_i, -f16_lo(P0)), fmaf(xb, sc_i, -f16_hi(P0)));
                     }
                 } else {
                     bf16x8 t3[3];
@@ -475,6 +584,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
             issue_begin(st, k + NS < nchunks);
             // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1 (garbage after the last chunk, unused)
             st = st + 1 == NS ? 0 : st + 1;
+            if constexpr (SLAB) fetch_ctx(kc_begin + k + 1);
             step(f1, f0, st, S0(), std::true_type());
         }
         // the epilogue reuses the LDS: all reads returned, and the (out-of-range, zero-filling) DMA pieces the
@@ -538,16 +648,16 @@ constexpr X3Cfg kX3[] = {     // the same nine tiles for both schemes (LDS sizes
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC>
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false>
 int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC>;
+    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB>;
     static PpyLdsAttr attr;      // (the stage count is a launch parameter: allow the whole LDS)
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
     return PPY_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool F16>
+template <int BM, int BN, int WM, int WN, bool F16, bool SLAB = false>
 int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     // 32-bit per-lane DMA offsets
     constexpr int NP = F16 ? 2 : 3;
@@ -557,29 +667,54 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     constexpr int NW = (BM / WM) * (BN / WN);
     // as many LDS stages as asked for, as far as 160 KB of LDS and the 6-bit vmcnt allow (ids of deeper variants of a big
     // tile then alias the deepest one that fits)
-    constexpr int STAGE_BYTES = BM * 128 + NP * BN * 64, PIECES = BM / (8 * NW) + NP * BN / (16 * NW);
-    while (nstages > 2 && (nstages * STAGE_BYTES > 160 * 1024 || (nstages - 1) * PIECES > 63)) --nstages;
-    size_t lds = (size_t)nstages * STAGE_BYTES;
+    constexpr int SLAB_PIECES = BM / 8 + 1, AS = ((SLAB_PIECES + NW - 1) / NW + 1) / 2;
+    constexpr int FIXED = SLAB ? 2 * SLAB_PIECES * 1024 + NW * 1024 : 0;        // two slabs + the dummy pieces' landing strip
+    constexpr int STAGE_BYTES = (SLAB ? 0 : BM * 128) + NP * BN * 64, PIECES = (SLAB ? AS : BM / (8 * NW)) + NP * BN / (16 * NW);
+    if (SLAB) {
+        // slab reuse: 3x3 / stride 1 / pad 1 ("same") layers only; two slabs alternate, which covers 2 or 3 stages
+        // (BAD_ARG, not UNSUPPORTED: the caller of an explicit slab id gets an error instead of the fp32 fallback kernel)
+        if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W) return PPY_ERR_BAD_ARG;
+        if (nstages > 3) nstages = 3;
+    }
+    while (nstages > 2 && (FIXED + nstages * STAGE_BYTES > 160 * 1024 || (nstages - 1) * PIECES + (SLAB ? 2 * AS : 0) > 63)) --nstages;
+    if (FIXED + nstages * STAGE_BYTES > 160 * 1024) return PPY_ERR_UNSUPPORTED;
+    size_t lds = (size_t)FIXED + (size_t)nstages * STAGE_BYTES;
     p.nstages = nstages;
     const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
     p.chunks_total = p.R * p.S * (p.C / 32);
     p.chunks_per_split = ceil_div(p.chunks_total, splits);
+    if (SLAB) p.chunks_per_split = ceil_div(p.chunks_per_split, 3) * 3;      // a split starts on a (channel chunk, r) boundary
     splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
     const bool vec = vec_epilogue_ok(p);
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, F16, true, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, F16, true, false, SLAB>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, false, true>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, F16, false, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, false, true, SLAB>(p, splits, lds, tiles, stream)
+                 : launch_x3_one<BM, BN, WM, WN, F16, false, false, SLAB>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
+}
+
+int dispatch_slab(const ConvArgs &p, int c, int s, hipStream_t st, int ns) {
+    switch (c) {
+        case 0: return launch_x3<256, 128, 64, 128, true, true>(p, s, st, ns);
+        case 1: return launch_x3<128, 128, 64, 64, true, true>(p, s, st, ns);
+        case 2: return launch_x3<128, 128, 32, 128, true, true>(p, s, st, ns);
+        case 3: return launch_x3<256, 64, 64, 64, true, true>(p, s, st, ns);
+        case 4: return launch_x3<128, 64, 32, 64, true, true>(p, s, st, ns);
+        case 5: return launch_x3<256, 128, 64, 64, true, true>(p, s, st, ns);
+        case 6: return launch_x3<128, 256, 64, 128, true, true>(p, s, st, ns);
+        case 7: return launch_x3<64, 128, 32, 64, true, true>(p, s, st, ns);
+        case 8: return launch_x3<64, 64, 32, 32, true, true>(p, s, st, ns);
+    }
+    return PPY_ERR_BAD_ARG;
 }
 
 template <bool F16>
@@ -632,8 +767,9 @@ __global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, 
 
 }  // namespace
 
-// local ids: [0, 9) bf16x3, [9, 18) f16x2 (two LDS stages), [18, 27) f16x2 with three stages, [27, 36) with four
-int ppy_x3_num_configs() { return 4 * kNumX3; }
+// local ids: [0, 9) bf16x3, [9, 18) f16x2 (two LDS stages), [18, 27) f16x2 with three stages, [27, 36) with four,
+// [36, 45) f16x2 with slab reuse (3x3 / stride 1 / pad 1 layers) and two stages, [45, 54) the same with three
+int ppy_x3_num_configs() { return 6 * kNumX3; }
 int ppy_x3_f16_base() { return kNumX3; }
 
 int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
@@ -648,6 +784,7 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     q.scale = p.scale_f16;
     q.posb = p.posb ? p.posb_f16 : nullptr;
     const int local = c - kNumX3;
+    if (local >= 3 * kNumX3) return dispatch_slab(q, local % kNumX3, s, st, 2 + (local / kNumX3 - 3));
     return dispatch_scheme<true>(q, local % kNumX3, s, st, 2 + local / kNumX3);
 }
 

@@ -88,9 +88,12 @@ def test_dgrad_refuses_stride2():
 
 
 @pytest.mark.parametrize('tag', ['r18vd_96', 'r50vd_96'])
-def test_output_conv_gradients_of_the_reference_step(golden, tag):
-    """The reference's own training step (g12): d loss / d head outputs -> weight gradient of each output convolution,
-    given the tip activations recomputed by the oracle's training-mode forward."""
+def test_head_conv_gradients_of_a_training_step(golden, tag):
+    """One whole training step of the oracle on the g12 inputs (its bit-equality with the REFERENCE's step is asserted on
+    the build box by tests/test_train_oracle.py; across CPU models the training-mode BatchNorm of 3x3 maps amplifies
+    MKLDNN rounding differences, so here the oracle run of THIS box supplies activations, d loss / d outputs and the
+    expected gradients): weight gradients of all output convolutions and of the 3x3 tip convolutions, and the input
+    gradient of the output convolutions, from the HIP kernels."""
     from conftest import build_model
     from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
     from oracle import ppyolo_oracle as orc, train_oracle as trn
@@ -100,31 +103,45 @@ def test_output_conv_gradients_of_the_reference_step(golden, tag):
     cfg = {'r18vd_96': PPYOLO_r18vd_Config, 'r50vd_96': PPYOLO_2x_Config}[tag]()
     _, sd = build_model(cfg, wseed, 'cpu')
     x = synth.synth_images(N, S, seed=iseed)
-    # tip activations (inputs of the output convolutions) of the training-mode forward, captured from the oracle
-    tips = []
-    real = orc.conv_unit
+    L = len(cfg.head['anchor_masks'])
+    seen = {}
+    real_conv2d = F.conv2d
 
-    def spy(sdx, prefix, t, stride=1, act=None):
-        if prefix.startswith('head.yolo_output_convs.'):
-            tips.append(t.detach())
-        return real(sdx, prefix, t, stride, act)
-    orc.conv_unit = spy
+    def spy(inp, weight, bias=None, stride=1, padding=0, *a, **k):        # every convolution of the step: (input, output)
+        out = real_conv2d(inp, weight, bias, stride, padding, *a, **k)
+        if weight.requires_grad:
+            out.retain_grad()
+            seen[id(weight)] = (inp.detach(), out, stride if isinstance(stride, int) else stride[0],
+                                padding if isinstance(padding, int) else padding[0], weight)
+        return out
+    orc.F.conv2d = spy
     try:
-        torch.manual_seed(rseed)
-        outs, _ = trn.forward_train(sd, cfg, x)
+        r = trn.train_step(sd, cfg, x, torch.from_numpy(g['gt_bbox']), [torch.from_numpy(g['target%d' % i]) for i in range(L)],
+                           rng_seed=rseed)
     finally:
-        orc.conv_unit = real
-    for i, (tip, out) in enumerate(zip(tips, outs)):
-        assert torch.equal(out.detach(), torch.from_numpy(g['out%d' % i]))
-        dout = torch.from_numpy(g['dout%d' % i])
-        w = sd['head.yolo_output_convs.%d.conv.weight' % i]
-        K, C = w.shape[0], w.shape[1]
-        dw = torch.zeros(K, 1, 1, C).cuda()
-        ops.conv2d_wgrad(ops.View(nhwc(tip).cuda()), ops.View(nhwc(dout).cuda()), dw, 1, 0)
-        dx = torch.zeros(N, tip.shape[2], tip.shape[3], C).cuda()
-        ops.conv2d_dgrad(ops.View(nhwc(dout).cuda()), w.permute(0, 2, 3, 1).contiguous().cuda(), ops.View(dx), 1, 0)
+        orc.F.conv2d = real_conv2d
+    want_loss = float(g['all_loss'])
+    assert abs(float(r['all_loss']) - want_loss) <= 2e-2 * want_loss           # same step as the reference's, up to BN noise
+    checked = 0
+    leaves = {k: v for k, v in r['grads'].items() if k.endswith('conv.weight')}
+    by_grad = {v.data_ptr(): k for k, v in leaves.items()}                    # a conv call's weight leaf -> its state_dict key
+    assert len(seen) == len(leaves)
+    for inp, out, stride, pad, wleaf in seen.values():
+        key = by_grad[wleaf.grad.data_ptr()]
+        w = sd[key]
+        K, Cin, R, _ = w.shape
+        assert tuple(out.shape[1:2]) == (K,) and inp.shape[1] == Cin, key
+        dy = out.grad
+        dw = torch.zeros(K, R, R, Cin).cuda()
+        ops.conv2d_wgrad(ops.View(nhwc(inp).cuda()), ops.View(nhwc(dy).cuda()), dw, stride, pad)
         torch.cuda.synchronize()
-        want = torch.from_numpy(g['gw_out%d' % i])
-        assert _rel(dw.cpu().permute(0, 3, 1, 2), want) <= 2e-5, 'output conv %d weight gradient' % i
-        dx_ref = F.conv_transpose2d(dout, w)
-        assert _rel(dx.cpu().permute(0, 3, 1, 2), dx_ref) <= 2e-5
+        e = _rel(dw.cpu().permute(0, 3, 1, 2), leaves[key])
+        assert e <= 3e-5, (key, e)
+        if 'yolo_output_convs' in key or 'tip_layers' in key:
+            dx = torch.zeros(inp.shape[0], inp.shape[2], inp.shape[3], Cin).cuda()
+            ops.conv2d_dgrad(ops.View(nhwc(dy).cuda()), w.permute(0, 2, 3, 1).contiguous().cuda(), ops.View(dx), stride, pad)
+            torch.cuda.synchronize()
+            dx_ref = F.conv_transpose2d(dy, w, None, stride, pad)
+            assert _rel(dx.cpu().permute(0, 3, 1, 2), dx_ref) <= 3e-5, key
+        checked += 1
+    assert checked == len(leaves) >= 7

@@ -58,7 +58,9 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-NUM_CFGS = 67      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 with 2 LDS stages + 9 with 3 + 9 with 4 (conv_x3.hip)
+NUM_CFGS = 85      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 with 2 LDS stages + 9 with 3 + 9 with 4
+                   # + 9 + 9 f16x2 with slab reuse (3x3 / stride 1 / pad 1 only) and 2 / 3 stages (conv_x3.hip)
+SLAB0 = 67
 
 
 @pytest.mark.parametrize('cfg', range(NUM_CFGS))
@@ -384,7 +386,7 @@ def test_conv_random_shapes_all_kernels():
     ncfg = lib().ppy_conv2d_num_configs()
     g = torch.Generator().manual_seed(99)
     ws = torch.empty(8 << 20).cuda()
-    for case in range(90):
+    for case in range(120):
         N = rnd.choice([1, 2, 3])
         C = rnd.choice([32, 64, 96, 160])
         K = rnd.choice([5, 27, 32, 64, 100, 258, 300])
@@ -408,10 +410,17 @@ def test_conv_random_shapes_all_kernels():
         y = torch.full((N, Ho, Wo, K), 123.0).cuda()
         wk = w.permute(0, 2, 3, 1).contiguous().cuda()
         xd = nhwc(x).cuda()
-        ops.conv2d_bn_act(ops.View(xd), wk, sc.cuda(), sh.cuda(),
-                          ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
-                          cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk),
-                          w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
+        def run():
+            ops.conv2d_bn_act(ops.View(xd), wk, sc.cuda(), sh.cuda(),
+                              ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
+                              cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk),
+                              w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
+        if cfg >= SLAB0 and not (R == 3 and stride == 1):        # slab reuse exists for 3x3 / stride 1 / pad 1 only: refused loudly
+            from ppyolo_hip._lib import PPYoloHipError
+            with pytest.raises(PPYoloHipError):
+                run()
+            continue
+        run()
         torch.cuda.synchronize()
         close(nchw(y), ref, what='case %d: N%d C%d K%d R%d s%d %dx%d cfg%d split%d' % (case, N, C, K, R, stride, H, W, cfg,
                                                                                  splitk))
@@ -578,3 +587,33 @@ def test_f16x2_adversarial_max_error(case):
     for k, v in errs.items():
         if k != 'fp32':
             assert v <= max(1.5 * errs['fp32'], 3 * 2.0 ** -24), (case, errs)
+
+
+@pytest.mark.parametrize('cfg', range(SLAB0, NUM_CFGS))
+def test_slab_reuse_edge_shapes(cfg):
+    """The slab variants of the f16x2 kernels (one BM+8-row slab per (channel chunk, r) serves the taps s = 0..2): maps one
+    pixel wide / high, tiles that straddle several images, M far below a tile, one chunk of channels (9 chunks, splits that
+    do not divide them), reductions shorter than the stage count, and padding taps zeroed through the activation scale --
+    against F.conv2d; plus bit-identity with the plain f16x2 kernel of the same tile (same products, same order)."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(900 + cfg)
+    ws = torch.empty(4 << 20).cuda()
+    for N, H, W, C, K, splitk in ((1, 1, 1, 32, 40, 1), (3, 1, 7, 64, 72, 2), (2, 9, 1, 32, 100, 1), (5, 2, 2, 96, 64, 4),
+                                  (2, 19, 19, 64, 136, 1), (1, 33, 31, 32, 258, 2), (4, 6, 5, 160, 48, 5), (2, 13, 11, 32, 64, 9)):
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)
+        sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+        ref = F.leaky_relu(F.conv2d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.1)
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc.cuda())
+        outs = []
+        for c in (cfg, cfg - 27):                       # the slab variant and the plain f16x2 kernel of the same tile / stage count
+            y = torch.full((N, H, W, K), 9.0).cuda()
+            ops.conv2d_bn_act(ops.View(xd), wk, sc.cuda(), sh.cuda(), ops.View(y), 1, 1, 'leaky', cfg=c, splitk=splitk, ws=ws,
+                              w_f16=wf, amax_in=ops.amax_slots(xd))
+            torch.cuda.synchronize()
+            outs.append(y)
+        close(nchw(outs[0]), ref, what='slab cfg %d: N%d %dx%d C%d K%d split %d' % (cfg, N, H, W, C, K, splitk))
+        if splitk == 1:
+            assert torch.equal(outs[0], outs[1]), 'slab cfg %d differs from the plain kernel (N%d %dx%d C%d K%d)' % (cfg, N, H, W, C, K)
