@@ -176,11 +176,19 @@ static int wgrad_slices(int K, int C, int R, int S, int P) {
 
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+static bool bwd_geometry(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, Geometry *g) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return false;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || (long long)N * Ho * Wo > 0x7fffffffLL / 4) return false;
+    g->Ho = Ho; g->Wo = Wo; g->M = N * Ho * Wo; g->Kred = R * S * C; g->chunks = 0;
+    return true;
+}
+
 }  // namespace
 
 extern "C" size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
-    Geometry g;
-    if (stride != 1 || !conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
+    Geometry g;          // (of the layer itself: C need not be a multiple of 32 here -- CoordConv layers have C = 514 -- K is padded)
+    if (stride != 1 || !bwd_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
     const int Kp = (K + 31) / 32 * 32;
     size_t b = align256((size_t)C * R * S * Kp * 4) + align256((size_t)C * 4) * 2;      // w', ones, zeros
     b += align256((size_t)C * R * S * Kp * 6);                                          // three bf16 planes of w'
@@ -195,7 +203,7 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     PPY_CHECK_ARG(dy && w_krsc && dx && N > 0 && C > 0 && K > 0 && dy_ld >= K && dx_ld >= C);
     if (stride != 1) return PPY_ERR_UNSUPPORTED;           // (the trainable head has no strided convolution)
     Geometry g;
-    if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
+    if (!bwd_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
     const int Kp = (K + 31) / 32 * 32;
     PPY_CHECK_ARG(R - 1 - pad >= 0 && (Kp != K || (dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0)));      // (a padded copy is aligned by construction)
     const size_t need = ppy_conv2d_dgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad);

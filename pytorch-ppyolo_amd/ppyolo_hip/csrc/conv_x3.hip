@@ -717,6 +717,19 @@ int dispatch_slab(const ConvArgs &p, int c, int s, hipStream_t st, int ns) {
     return PPY_ERR_BAD_ARG;
 }
 
+// f16x2 tiles with 96 / 192 rows (three 32-row MFMA tiles per wave): the grids of the layers are small against 256 CUs, and a
+// tile height of 1.5x fills the last round of workgroups where 128 / 256 rows leave 30-40 % of the slots empty
+// (e.g. M = 46208: 361 x 2 tiles of 128x128 on 512 slots = 1.41 rounds; 241 x 2 tiles of 192x128 = 0.94).
+int dispatch_extra(const ConvArgs &p, int c, int s, hipStream_t st, int ns) {
+    switch (c) {
+        case 0: return launch_x3<192, 128, 96, 64, true>(p, s, st, ns);     // 4 waves (2x2), 40 KB per stage
+        case 1: return launch_x3<192, 256, 96, 64, true>(p, s, st, ns);     // 8 waves (2x4), 56 KB per stage
+        case 2: return launch_x3<96, 256, 96, 64, true>(p, s, st, ns);      // 4 waves (1x4), 44 KB per stage
+    }
+    return PPY_ERR_BAD_ARG;
+}
+constexpr int kNumExtra = 3;
+
 template <bool F16>
 int dispatch_scheme(const ConvArgs &p, int c, int s, hipStream_t st, int ns = 2) {
     switch (c) {
@@ -768,8 +781,9 @@ __global__ void __launch_bounds__(256) split_weights_f16_kernel(const float *w, 
 }  // namespace
 
 // local ids: [0, 9) bf16x3, [9, 18) f16x2 (two LDS stages), [18, 27) f16x2 with three stages, [27, 36) with four,
-// [36, 45) f16x2 with slab reuse (3x3 / stride 1 / pad 1 layers) and two stages, [45, 54) the same with three
-int ppy_x3_num_configs() { return 6 * kNumX3; }
+// [36, 45) f16x2 with slab reuse (3x3 / stride 1 / pad 1 layers) and two stages, [45, 54) the same with three,
+// [54, 57) the 96 / 192-row f16x2 tiles with two stages, [57, 60) with three, [60, 63) with four
+int ppy_x3_num_configs() { return 6 * kNumX3 + 3 * kNumExtra; }
 int ppy_x3_f16_base() { return kNumX3; }
 
 int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
@@ -784,6 +798,7 @@ int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     q.scale = p.scale_f16;
     q.posb = p.posb ? p.posb_f16 : nullptr;
     const int local = c - kNumX3;
+    if (local >= 5 * kNumX3) return dispatch_extra(q, (local - 5 * kNumX3) % kNumExtra, s, st, 2 + (local - 5 * kNumX3) / kNumExtra);
     if (local >= 3 * kNumX3) return dispatch_slab(q, local % kNumX3, s, st, 2 + (local / kNumX3 - 3));
     return dispatch_scheme<true>(q, local % kNumX3, s, st, 2 + local / kNumX3);
 }

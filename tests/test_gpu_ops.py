@@ -58,9 +58,10 @@ def test_conv_units_golden(golden):
         close(y, T(g[p + 'y']), what='conv unit %d' % i)
 
 
-NUM_CFGS = 85      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 with 2 LDS stages + 9 with 3 + 9 with 4
-                   # + 9 + 9 f16x2 with slab reuse (3x3 / stride 1 / pad 1 only) and 2 / 3 stages (conv_x3.hip)
-SLAB0 = 67
+NUM_CFGS = 94      # 31 exact-fp32 MFMA configurations + 9 bf16x3 + 9 f16x2 with 2 LDS stages + 9 with 3 + 9 with 4
+                   # + 9 + 9 f16x2 with slab reuse (3x3 / stride 1 / pad 1 only) and 2 / 3 stages
+                   # + 3 x 3 f16x2 tiles of 192x128 / 192x256 / 96x256 with 2 / 3 / 4 stages (conv_x3.hip)
+SLAB0, SLAB1 = 67, 85
 
 
 @pytest.mark.parametrize('cfg', range(NUM_CFGS))
@@ -103,7 +104,7 @@ def test_conv_every_tile_config(cfg, splitk):
     assert torch.all(yout[..., :8] == -7.0), 'wrote outside the output channel slice'
 
 
-@pytest.mark.parametrize('cfg', range(49, 67))
+@pytest.mark.parametrize('cfg', list(range(49, 67)) + list(range(88, 94)))
 def test_deep_stage_variants_on_short_reductions(cfg):
     """3- and 4-stage f16x2 variants when the reduction has fewer chunks than stages (1, 2, 3 chunks; split-K leaving one
     chunk per split): the unused stage slots are requested as out-of-range dummies and must not leak into the result."""
@@ -415,7 +416,7 @@ def test_conv_random_shapes_all_kernels():
                               ops.View(y), stride, pad, act, residual=None if res is None else ops.View(nhwc(res).cuda()),
                               cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk),
                               w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
-        if cfg >= SLAB0 and not (R == 3 and stride == 1):        # slab reuse exists for 3x3 / stride 1 / pad 1 only: refused loudly
+        if SLAB0 <= cfg < SLAB1 and not (R == 3 and stride == 1):        # slab reuse exists for 3x3 / stride 1 / pad 1 only: refused loudly
             from ppyolo_hip._lib import PPYoloHipError
             with pytest.raises(PPYoloHipError):
                 run()
@@ -589,7 +590,7 @@ def test_f16x2_adversarial_max_error(case):
             assert v <= max(1.5 * errs['fp32'], 3 * 2.0 ** -24), (case, errs)
 
 
-@pytest.mark.parametrize('cfg', range(SLAB0, NUM_CFGS))
+@pytest.mark.parametrize('cfg', range(SLAB0, SLAB1))
 def test_slab_reuse_edge_shapes(cfg):
     """The slab variants of the f16x2 kernels (one BM+8-row slab per (channel chunk, r) serves the taps s = 0..2): maps one
     pixel wide / high, tiles that straddle several images, M far below a tile, one chunk of channels (9 chunks, splits that
