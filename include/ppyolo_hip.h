@@ -129,6 +129,69 @@ int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, f
                          int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
 size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 
+/* ------------------------------------------------------------------------------------
+ * Training-step operators around the convolutions (SURVEY 8f rank 2 / BASELINE config 5; csrc/train.hip).  Tensors are
+ * fp32 NHWC slices (pointer + pixel stride), P = N*H*W pixels.
+ *  ppy_bn_train_stats_f32 / _apply_f32: torch.nn.BatchNorm2d in TRAINING mode (the reference trains with every BatchNorm
+ *    on batch statistics: train.py never calls .eval(); model/custom_layers.py:122): per-channel mean and
+ *    invstd = 1/sqrt(biased var + eps) of x, running statistics updated in place with `momentum` (unbiased variance), then
+ *    y = act((x - mean) * invstd * gamma + beta [+ residual]).
+ *  ppy_bn_train_bwd_f32: given dy = d loss / d y: dz = dy * act'(y), dbeta = sum dz, dgamma = sum dz * xhat,
+ *    dx = gamma * invstd * (dz - (dbeta + xhat * dgamma) / P).
+ *  ppy_act_bwd_f32: dx = dy * act'(y) alone.
+ *  ppy_upsample2x_bwd_f32: backward of the nearest x2 upsample of the head routes (model/head.py:396-397): dx = sum of the
+ *    2x2 block of dy (accumulate != 0: added to dx).
+ *  ppy_spp_bwd_f32: backward of SPP (model/custom_layers.py:281-290): dy is [N,H,W,4C] = (x, pool5, pool9, pool13); every
+ *    window's gradient goes to its first maximum in (h, w) scan order, as torch.max_pool2d's does.
+ *  ppy_dropblock_mask_f32 / _apply_f32: DropBlock in training mode (custom_layers.py:303-342): seeds = u < gamma (gamma from
+ *    the feature HEIGHT, like the reference), mask = 1 - maxpool3x3(seeds), scale = numel / sum(mask); y = x * mask * scale
+ *    (the same map serves the backward).  u comes from a counter-based generator keyed by `seed` -- the reference draws from
+ *    torch's global generator, so masks are comparable in distribution only; parity tests inject the reference's mask.
+ *  ppy_sgd_momentum_f32: torch.optim.SGD(momentum, weight_decay) as built by train.py:271-280:
+ *    d = g + wd * p; v = first_step ? d : mu * v + d; p -= lr * v.
+ * All reductions run in a fixed order (no float atomics): results are run-to-run identical.
+ */
+size_t ppy_bn_train_workspace_bytes(int P, int C);
+int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, float eps, float momentum, float *mean, float *invstd,
+                           float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream);
+int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const float *invstd, const float *gamma,
+                           const float *beta, const float *residual, int res_ld, float *y, int y_ld, int P, int C, int act,
+                           void *stream);
+int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, int y_ld, const float *dy, int dy_ld, const float *mean,
+                         const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P,
+                         int C, int act, void *ws, size_t ws_bytes, void *stream);
+int ppy_act_bwd_f32(const float *dy, int dy_ld, const float *y, int y_ld, float *dx, int dx_ld, long long P, int C, int act,
+                    void *stream);
+int ppy_upsample2x_bwd_f32(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C, int accumulate,
+                           void *stream);
+size_t ppy_spp_bwd_workspace_bytes(int N, int H, int W, int C);
+int ppy_spp_bwd_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C,
+                    void *ws, size_t ws_bytes, void *stream);
+size_t ppy_dropblock_workspace_bytes(int N, int H, int W, int C);
+int ppy_dropblock_mask_f32(float *mask, float *scale_out, int N, int H, int W, int C, int block_size, float keep_prob,
+                           unsigned long long seed, void *ws, size_t ws_bytes, void *stream);
+int ppy_dropblock_apply_f32(const float *x, int x_ld, const float *mask, const float *scale, float *y, int y_ld, long long P,
+                            int C, void *stream);
+int ppy_sgd_momentum_f32(float *param, const float *grad, float *velocity, long long n, float lr, float momentum,
+                         float weight_decay, int first_step, void *stream);
+
+/* YOLOv3Loss of one head level, forward AND backward (csrc/yolo_loss.hip): the reference's
+ * YOLOv3Loss._get_fine_grained_loss (model/losses.py:121-253) with IouLoss / IouAwareLoss (model/iou_losses.py:39-246) and
+ * the ignore mask (losses.py:296-356), plus the analytic gradient of the SUM of all loss terms with respect to the head
+ * output -- what `all_loss.backward()` (train.py:441) hands to the output convolutions.
+ * head_out: NHWC [N,S,S,*] raw output of this level, channels [an IoU logits if iou_aware][an x (x, y, w, h, obj, C classes)].
+ * target: the reference's Gt2YoloTarget tensor [N, an, 6 + C, S, S] (tx, ty, tw, th, tscale, tobj, classes).
+ * gt_box: [N, num_gt, 4] normalised (cx, cy, w, h), zero rows = padding.  h_anchors_px: HOST array, an x (w, h) of this level.
+ * dout: NHWC like head_out (channels beyond an*(5+C)(+an) are not written).  loss6: device floats
+ * {loss_xy, loss_wh, loss_obj, loss_cls, loss_iou, loss_iou_aware}, each the batch mean as the reference logs it
+ * (accumulate != 0: added to what is there, for the sum over levels).  ws: ppy_yolov3_loss_workspace_bytes().
+ */
+size_t ppy_yolov3_loss_workspace_bytes(int N, int S, int an);
+int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const float *target, const float *gt_box, int num_gt,
+                        const float *h_anchors_px, int an, int num_classes, int N, int S, int downsample, double scale_x_y,
+                        double ignore_thresh, double iou_loss_weight, int iou_aware, double iou_aware_loss_weight,
+                        float *dout, int dout_ld, float *loss6, int accumulate, void *ws, size_t ws_bytes, void *stream);
+
 /* First backbone conv, `stage1_conv1_1` (reference model/resnet_vd.py:100, :133): 3x3
  * stride-2 conv C_in=3 -> K (K % 4 == 0, K <= 64) + BN affine + ReLU, reading the
  * caller's NCHW input directly and writing NHWC (fuses the layout change).

@@ -6,7 +6,7 @@ import of any op raises, and every call checks the C return code.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PPYOLO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libppyolo_hip.so')     # (override: experiments)
@@ -38,6 +38,27 @@ _PROTOS = {
     'ppy_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_conv2d_wgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 9),
+    'ppy_bn_train_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'ppy_bn_train_stats_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    'ppy_bn_train_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_void_p]),
+    'ppy_bn_train_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ppy_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
+    'ppy_upsample2x_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ppy_spp_bwd_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ppy_spp_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    'ppy_dropblock_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ppy_dropblock_mask_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_void_p, c_size_t,
+                                        c_void_p]),
+    'ppy_dropblock_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),
+    'ppy_sgd_momentum_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_int, c_void_p]),
+    'ppy_yolov3_loss_workspace_bytes': (c_size_t, [c_int] * 3),
+    'ppy_yolov3_loss_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_int, c_int, c_int, c_int, c_int,
+                                     c_double, c_double, c_double, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
+                                     c_void_p]),
     'ppy_stem_conv3x3s2_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ppy_preprocess_u8_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,

@@ -1,0 +1,458 @@
+// Training-step kernels around the convolutions (BASELINE config 5): everything the
+// reference's train.py:416-443 step does besides F.conv2d and its backward (csrc/conv_bwd.hip) -- BatchNorm on batch
+// statistics forward / backward (torch.nn.BatchNorm2d in training mode: the reference never calls .eval() before its
+// loop), the activation derivative, nearest x2 upsample backward (model/head.py:396-397), SPP max-pool backward
+// (model/custom_layers.py:281-290), DropBlock (custom_layers.py:303-342) and the SGD-momentum update with L2
+// (train.py:271-280).  All tensors fp32 NHWC (pixel stride ld); all of it HBM-bound elementwise / reduction work:
+// 16-byte accesses, one or two passes over the data, deterministic reductions (fixed slice order, no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_CH = 64;         // channels per workgroup of the statistics kernels (one wave = one pixel x 64 channels)
+constexpr int BN_MAX_SLICES = 64;
+
+struct BnArgs {
+    const float *x, *dy, *y;
+    float *out;
+    int x_ld, dy_ld, y_ld, out_ld;
+    int P, C, slices, pix_per_slice, act;
+    const float *mean, *invstd, *gamma, *beta, *sum_dz, *sum_dzx, *res;
+    int res_ld;
+    float *part;
+};
+
+// ---- forward statistics: per channel (n, mean, M2) of a pixel slice, Welford per thread, Chan merge across threads
+__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const BnArgs p) {
+    __shared__ float s_mean[4][BN_CH], s_m2[4][BN_CH], s_n[4][BN_CH];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * BN_CH + cl;
+    const int p0 = blockIdx.y * p.pix_per_slice, p1 = min(p0 + p.pix_per_slice, p.P);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < p.C)
+        for (int q = p0 + pl; q < p1; q += 4) {
+            const float v = p.x[(long long)q * p.x_ld + c];
+            n += 1.f;
+            const float d = v - mean;
+            mean += d / n;
+            m2 += d * (v - mean);
+        }
+    s_mean[pl][cl] = mean; s_m2[pl][cl] = m2; s_n[pl][cl] = n;
+    __syncthreads();
+    if (pl == 0 && c < p.C) {
+        for (int k = 1; k < 4; ++k) {
+            const float nb = s_n[k][cl];
+            if (nb > 0.f) {
+                const float d = s_mean[k][cl] - mean, nt = n + nb;
+                mean += d * (nb / nt);
+                m2 += s_m2[k][cl] + d * d * (n * nb / nt);
+                n = nt;
+            }
+        }
+        float *o = p.part + ((long long)blockIdx.y * p.C + c) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
+// one thread per channel: merge the slices in order; mean, 1/sqrt(biased var + eps); running statistics as
+// torch.nn.BatchNorm2d does: running = (1 - momentum) * running + momentum * {mean, UNBIASED var}
+__global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, int C, int slices, float eps, float momentum,
+                                                             float *mean_out, float *invstd_out, float *running_mean,
+                                                             float *running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const float *o = part + ((long long)s * C + c) * 3;
+        const float nb = o[0];
+        if (nb > 0.f) {
+            const float d = o[1] - mean, nt = n + nb;
+            mean += d * (nb / nt);
+            m2 += o[2] + d * d * (n * nb / nt);
+            n = nt;
+        }
+    }
+    const float var = m2 / n;
+    mean_out[c] = mean;
+    invstd_out[c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+}
+
+// ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread
+__global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p) {
+    const int c4 = p.C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.P * c4) return;
+    const int c = (int)(i % c4) * 4;
+    const long long q = i / c4;
+    const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
+    floatx4 r = {0.f, 0.f, 0.f, 0.f};
+    if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + q * p.res_ld + c);
+    floatx4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = p.invstd[c + k] * p.gamma[c + k];
+        o[k] = ppy_apply_act((v[k] - p.mean[c + k]) * a + p.beta[c + k] + r[k], p.act);
+    }
+    *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+}
+
+__device__ __forceinline__ float act_grad(float y, int act) {      // derivative from the OUTPUT: y > 0 <=> pre-activation > 0
+    if (act == PPY_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == PPY_ACT_LEAKY) return y > 0.f ? 1.f : 0.1f;
+    return 1.f;
+}
+
+// ---- backward reduction: per channel sum(dz), sum(dz * xhat), dz = dy * act'(y), xhat = (x - mean) * invstd
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs p) {
+    __shared__ float s_a[4][BN_CH], s_b[4][BN_CH];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * BN_CH + cl;
+    const int p0 = blockIdx.y * p.pix_per_slice, p1 = min(p0 + p.pix_per_slice, p.P);
+    float a = 0.f, b = 0.f;
+    if (c < p.C) {
+        const float mu = p.mean[c], is = p.invstd[c];
+        for (int q = p0 + pl; q < p1; q += 4) {
+            const float dz = p.dy[(long long)q * p.dy_ld + c] * act_grad(p.y[(long long)q * p.y_ld + c], p.act);
+            a += dz;
+            b += dz * ((p.x[(long long)q * p.x_ld + c] - mu) * is);
+        }
+    }
+    s_a[pl][cl] = a; s_b[pl][cl] = b;
+    __syncthreads();
+    if (pl == 0 && c < p.C) {
+        a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+        b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+        p.part[((long long)blockIdx.y * p.C + c) * 2] = a;
+        p.part[((long long)blockIdx.y * p.C + c) * 2 + 1] = b;
+    }
+}
+__global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float *part, int C, int slices, float *dbeta, float *dgamma) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        a += part[((long long)s * C + c) * 2];
+        b += part[((long long)s * C + c) * 2 + 1];
+    }
+    dbeta[c] = a;
+    dgamma[c] = b;
+}
+// dx = gamma * invstd * (dz - (sum_dz + xhat * sum_dzx) / P)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p) {
+    const int c4 = p.C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.P * c4) return;
+    const int c = (int)(i % c4) * 4;
+    const long long q = i / c4;
+    const floatx4 x = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
+    const floatx4 dy = *reinterpret_cast<const floatx4 *>(p.dy + q * p.dy_ld + c);
+    const floatx4 y = *reinterpret_cast<const floatx4 *>(p.y + q * p.y_ld + c);
+    const float invP = 1.0f / (float)p.P;
+    floatx4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float is = p.invstd[c + k], xh = (x[k] - p.mean[c + k]) * is;
+        const float dz = dy[k] * act_grad(y[k], p.act);
+        o[k] = p.gamma[c + k] * is * (dz - (p.sum_dz[c + k] + xh * p.sum_dzx[c + k]) * invP);
+    }
+    *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+}
+
+// ---- activation backward alone (convolutions with bias and no BatchNorm have none in PP-YOLO; kept for completeness)
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float *dy, int dy_ld, const float *y, int y_ld, float *dx, int dx_ld,
+                                                      long long P, int C, int act) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * c4) return;
+    const int c = (int)(i % c4) * 4;
+    const long long q = i / c4;
+    const floatx4 g = *reinterpret_cast<const floatx4 *>(dy + q * dy_ld + c);
+    const floatx4 v = *reinterpret_cast<const floatx4 *>(y + q * y_ld + c);
+    floatx4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = g[k] * act_grad(v[k], act);
+    *reinterpret_cast<floatx4 *>(dx + q * dx_ld + c) = o;
+}
+
+// ---- nearest x2 upsample backward: dx[n,h,w,:] = sum of the 2x2 block of dy   (accumulate != 0: dx += ...)
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C,
+                                                             int accumulate) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * c4) return;
+    const int c = (int)(i % c4) * 4;
+    long long q = i / c4;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    const float *s = dy + (((long long)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * dy_ld + c;
+    const floatx4 a = *reinterpret_cast<const floatx4 *>(s), b = *reinterpret_cast<const floatx4 *>(s + dy_ld);
+    const floatx4 d = *reinterpret_cast<const floatx4 *>(s + 2LL * W * dy_ld), e = *reinterpret_cast<const floatx4 *>(s + (2LL * W + 1) * dy_ld);
+    float *o = dx + (((long long)n * H + h) * W + w) * dx_ld + c;
+    floatx4 r = (a + b) + (d + e);
+    if (accumulate) r += *reinterpret_cast<const floatx4 *>(o);
+    *reinterpret_cast<floatx4 *>(o) = r;
+}
+
+// ---- SPP backward.  Forward (custom_layers.py:281-290): cat([x, pool5(x), pool9(x), pool13(x)]), stride 1, implicit -inf
+// padding.  torch's max_pool2d routes a window's gradient to its FIRST maximum in (h, w) scan order.  Deterministic gather
+// form: kernel 1 records every window's argmax position, kernel 2 lets each input element collect the gradients of the
+// windows (at most k*k) that chose it, in a fixed order, on top of the identity branch.
+__global__ void __launch_bounds__(256) spp_argmax_kernel(const float *x, int x_ld, int N, int H, int W, int C, int k, short *arg) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    const int r = k / 2;
+    // torch's CPU kernel: maxval = -inf, maxindex = first element of the window; take v when (v > maxval) || isnan(v)
+    const int h0 = max(h - r, 0), w0 = max(w - r, 0);
+    float best = -__builtin_huge_valf();
+    int bi = h0 * W + w0;
+    for (int hh = h0; hh <= min(h + r, H - 1); ++hh)
+        for (int ww = w0; ww <= min(w + r, W - 1); ++ww) {
+            const float v = x[(((long long)n * H + hh) * W + ww) * x_ld + c];
+            if (v > best || v != v) {
+                best = v;
+                bi = hh * W + ww;
+            }
+        }
+    arg[i] = (short)bi;
+}
+__global__ void __launch_bounds__(256) spp_bwd_kernel(const float *dy, int dy_ld, const short *arg5, const short *arg9, const short *arg13,
+                                                      float *dx, int dx_ld, int N, int H, int W, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    const int me = h * W + w;
+    float g = dy[(((long long)n * H + h) * W + w) * dy_ld + c];                       // identity branch: channels [0, C)
+    const short *args[3] = {arg5, arg9, arg13};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int r = 2 + 2 * b;                                                      // 5 -> 2, 9 -> 4, 13 -> 6
+        for (int hh = max(h - r, 0); hh <= min(h + r, H - 1); ++hh)
+            for (int ww = max(w - r, 0); ww <= min(w + r, W - 1); ++ww) {
+                const long long o = (((long long)n * H + hh) * W + ww);
+                if (args[b][o * C + c] == me) g += dy[o * dy_ld + (b + 1) * C + c];
+            }
+    }
+    dx[(((long long)n * H + h) * W + w) * dx_ld + c] = g;
+}
+
+// ---- DropBlock.  mask (1 = keep) is given; y = x * mask * (numel / sum(mask)).  The mask itself: seeds = u < gamma with a
+// counter-based uniform u (one Philox-style hash per element), mask = 1 - maxpool3x3(seeds) with zero padding
+// (custom_layers.py:330-336); sum(mask) by a deterministic two-level reduction.
+__device__ __forceinline__ unsigned mix32(unsigned long long key) {       // splitmix64 finaliser, high 32 bits
+    key += 0x9E3779B97F4A7C15ull;
+    key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+    key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((key ^ (key >> 31)) >> 32);
+}
+__global__ void __launch_bounds__(256) dropblock_mask_kernel(float *mask, int N, int H, int W, int C, float gamma, unsigned long long seed,
+                                                             float *block_sums) {
+    __shared__ float red[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (i < (long long)N * H * W * C) {
+        const int c = (int)(i % C);
+        long long q = i / C;
+        const int w = (int)(q % W);
+        q /= W;
+        const int h = (int)(q % H), n = (int)(q / H);
+        bool hit = false;
+        for (int hh = max(h - 1, 0); hh <= min(h + 1, H - 1); ++hh)
+            for (int ww = max(w - 1, 0); ww <= min(w + 1, W - 1); ++ww) {
+                const unsigned long long id = ((((unsigned long long)n * H + hh) * W + ww) * C + c);
+                const float u = (float)(mix32(seed ^ (id * 0xD1342543DE82EF95ull)) >> 8) * (1.0f / 16777216.0f);
+                hit = hit || (u < gamma);
+            }
+        m = hit ? 0.f : 1.f;
+        mask[i] = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) sum_blocks_kernel(const float *block_sums, int n, float numel, float *scale_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += block_sums[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scale_out[0] = numel / red[0];
+}
+// y = x * mask * scale[0]  (forward on activations, backward on gradients: the same map)
+__global__ void __launch_bounds__(256) dropblock_apply_kernel(const float *x, int x_ld, const float *mask, const float *scale, float *y,
+                                                              int y_ld, long long P, int C) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * c4) return;
+    const int c = (int)(i % c4) * 4;
+    const long long q = i / c4;
+    const floatx4 v = *reinterpret_cast<const floatx4 *>(x + q * x_ld + c);
+    const floatx4 m = *reinterpret_cast<const floatx4 *>(mask + q * C + c);
+    const float s = scale[0];
+    floatx4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = v[k] * m[k] * s;          // (x * mask) * scale: the reference's order up to the division
+    *reinterpret_cast<floatx4 *>(y + q * y_ld + c) = o;
+}
+
+// ---- SGD with momentum and L2 (torch.optim.SGD: d = g + wd * p; v = mu * v + d; p -= lr * v), first step: v = d
+__global__ void __launch_bounds__(256) sgd_kernel(float *p, const float *g, float *v, long long n, float lr, float mu, float wd, int first) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = g[i] + wd * p[i];
+    const float nv = first ? d : mu * v[i] + d;
+    v[i] = nv;
+    p[i] -= lr * nv;
+}
+
+static int slices_for(int P, int C) {
+    const int cb = ceil_div(C, BN_CH);
+    int sl = ceil_div(1024, cb);                       // ~4 workgroups per CU
+    const int maxsl = P / 64 > 0 ? P / 64 : 1;
+    if (sl > maxsl) sl = maxsl;
+    if (sl > BN_MAX_SLICES) sl = BN_MAX_SLICES;
+    return sl < 1 ? 1 : sl;
+}
+static inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" size_t ppy_bn_train_workspace_bytes(int P, int C) { return (size_t)slices_for(P, C) * C * 3 * sizeof(float); }
+
+extern "C" int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, float eps, float momentum, float *mean, float *invstd,
+                                      float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && mean && invstd && P > 0 && C > 0 && x_ld >= C);
+    if (!ws || ws_bytes < ppy_bn_train_workspace_bytes(P, C)) return PPY_ERR_WORKSPACE;
+    BnArgs p = {};
+    p.x = x; p.x_ld = x_ld; p.P = P; p.C = C; p.part = (float *)ws;
+    p.slices = slices_for(P, C);
+    p.pix_per_slice = ceil_div(P, p.slices);
+    p.slices = ceil_div(P, p.pix_per_slice);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const float *invstd, const float *gamma,
+                                      const float *beta, const float *residual, int res_ld, float *y, int y_ld, int P, int C, int act,
+                                      void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && mean && invstd && gamma && beta && y && P > 0 && C > 0 && C % 4 == 0 && x_ld >= C && y_ld >= C);
+    PPY_CHECK_ARG(x_ld % 4 == 0 && y_ld % 4 == 0 && (!residual || (res_ld >= C && res_ld % 4 == 0)));
+    BnArgs p = {};
+    p.x = x; p.x_ld = x_ld; p.out = y; p.out_ld = y_ld; p.P = P; p.C = C; p.act = act;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.res = residual; p.res_ld = res_ld;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((long long)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, p);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, int y_ld, const float *dy, int dy_ld, const float *mean,
+                                    const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P,
+                                    int C, int act, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && y && dy && mean && invstd && gamma && dx && dgamma && dbeta && P > 0 && C > 0 && C % 4 == 0);
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= C && dy_ld >= C && dx_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0);
+    if (!ws || ws_bytes < ppy_bn_train_workspace_bytes(P, C)) return PPY_ERR_WORKSPACE;
+    BnArgs p = {};
+    p.x = x; p.x_ld = x_ld; p.y = y; p.y_ld = y_ld; p.dy = dy; p.dy_ld = dy_ld; p.out = dx; p.out_ld = dx_ld;
+    p.P = P; p.C = C; p.act = act; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.part = (float *)ws;
+    p.slices = slices_for(P, C);
+    p.pix_per_slice = ceil_div(P, p.slices);
+    p.slices = ceil_div(P, p.pix_per_slice);
+    p.sum_dz = dbeta; p.sum_dzx = dgamma;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((long long)P * (C / 4))), dim3(256), 0, st, p);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_act_bwd_f32(const float *dy, int dy_ld, const float *y, int y_ld, float *dx, int dx_ld, long long P, int C, int act,
+                               void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && y && dx && P > 0 && C > 0 && C % 4 == 0 && dy_ld % 4 == 0 && y_ld % 4 == 0 && dx_ld % 4 == 0);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld, dx, dx_ld, P, C,
+                       act);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_upsample2x_bwd_f32(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C, int accumulate,
+                                      void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dy_ld >= C && dx_ld >= C && dy_ld % 4 == 0 && dx_ld % 4 == 0);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       dx, dx_ld, N, H, W, C, accumulate);
+    return ppy_launch_status();
+}
+
+extern "C" size_t ppy_spp_bwd_workspace_bytes(int N, int H, int W, int C) { return (size_t)3 * N * H * W * C * sizeof(short); }
+
+extern "C" int ppy_spp_bwd_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C,
+                               void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && x_ld >= C && dy_ld >= 4 * C && dx_ld >= C && H * W < 32768);
+    if (!ws || ws_bytes < ppy_spp_bwd_workspace_bytes(N, H, W, C)) return PPY_ERR_WORKSPACE;
+    const long long n = (long long)N * H * W * C;
+    short *a5 = (short *)ws, *a9 = a5 + n, *a13 = a9 + n;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 5, a5);
+    hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 9, a9);
+    hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 13, a13);
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, dy_ld, a5, a9, a13, dx, dx_ld, N, H, W, C);
+    return ppy_launch_status();
+}
+
+extern "C" size_t ppy_dropblock_workspace_bytes(int N, int H, int W, int C) {
+    return ((size_t)blocks_for((long long)N * H * W * C) + 1) * sizeof(float);
+}
+extern "C" int ppy_dropblock_mask_f32(float *mask, float *scale_out, int N, int H, int W, int C, int block_size, float keep_prob,
+                                      unsigned long long seed, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(mask && scale_out && N > 0 && H >= block_size && W > 0 && C > 0 && block_size == 3 && keep_prob > 0.f && keep_prob <= 1.f);
+    if (!ws || ws_bytes < ppy_dropblock_workspace_bytes(N, H, W, C)) return PPY_ERR_WORKSPACE;
+    // gamma from the HEIGHT only, like the reference (custom_layers.py:306-325)
+    const float h = (float)H, bs = (float)block_size;
+    const float gamma = (h * h * (1.0f - keep_prob)) / (bs * bs * ((h - bs + 1.0f) * (h - bs + 1.0f)));
+    const long long n = (long long)N * H * W * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dropblock_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, st, mask, N, H, W, C, gamma, seed, (float *)ws);
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, (int)blocks_for(n), (float)n, scale_out);
+    return ppy_launch_status();
+}
+extern "C" int ppy_dropblock_apply_f32(const float *x, int x_ld, const float *mask, const float *scale, float *y, int y_ld, long long P,
+                                       int C, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && mask && scale && y && P > 0 && C > 0 && C % 4 == 0 && x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
+    hipLaunchKernelGGL(dropblock_apply_kernel, dim3(blocks_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, mask, scale, y, y_ld,
+                       P, C);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_sgd_momentum_f32(float *param, const float *grad, float *velocity, long long n, float lr, float momentum,
+                                    float weight_decay, int first_step, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(param && grad && velocity && n > 0);
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, velocity, n, lr, momentum,
+                       weight_decay, first_step);
+    return ppy_launch_status();
+}

@@ -1,0 +1,207 @@
+// YOLOv3Loss forward + backward for one head level in ONE kernel (BASELINE config 5):
+// the reference's YOLOv3Loss._get_fine_grained_loss (model/losses.py:121-253) with IouLoss / IouAwareLoss
+// (model/iou_losses.py:39-246) and the ignore mask of _calc_obj_loss (losses.py:296-356), and -- instead of an autograd
+// graph of ~150 ATen ops per level -- the analytic gradient d(sum of all loss terms) / d(head output), which is what
+// train.py:441 `all_loss.backward()` delivers to the head's last convolutions.
+//
+// One thread per (image, anchor, grid cell): it reads its 5 + C (+1 IoU) logits from the NHWC head output, its target
+// column from the reference's target layout [N, an, 6 + C, S, S] and the image's ground-truth boxes, and writes its slice
+// of dout plus six loss contributions (reduced afterwards in a fixed order).  HBM-bound by design: every input is read
+// once (the head outputs are a few MB per level).  Faithful to the reference's arithmetic, including
+//   * the IoU-aware term's reduction over grid x before the multiplication with tobj (iou_losses.py:241-242):
+//     loss = sum_h (sum_w tobj[h,w]) * (sum_w' iou[h,w'] * -log(ioup[h,w'] + 1e-9)),
+//   * `+ 1e-9` INSIDE the logarithms, `+ 1e-10` in the IoU union of the IoU losses and none in the ignore-mask IoU,
+//   * |.| gradients with sign(0) = 0, min / max ties sharing the gradient, clamp(min=0) passing it at 0 (torch autograd).
+#include "common.h"
+
+namespace {
+
+struct LossArgs {
+    const float *out, *target, *gt;
+    float *dout, *part;
+    int out_ld, dout_ld;
+    int N, S, an, C, G, iou_aware;
+    float aw[4], ah[4];
+    float downsample, scale_x_y, ignore_thresh, w_iou, w_iou_aware, inv_n;
+};
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+// d min(a, b) / d a  and  d max(a, b) / d a  as torch's elementwise min / max backward: ties share
+__device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+__global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
+    const int cells = p.S * p.S;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.N * p.an * cells) return;
+    const int cell = (int)(i % cells), a = (int)((i / cells) % p.an), n = (int)(i / ((long long)cells * p.an));
+    const int h = cell / p.S, w = cell - h * p.S;
+    const float S = (float)p.S;
+    const float *o = p.out + (((long long)n * p.S + h) * p.S + w) * p.out_ld;
+    float *d = p.dout + (((long long)n * p.S + h) * p.S + w) * p.dout_ld;
+    const int base = (p.iou_aware ? p.an : 0) + a * (5 + p.C);
+    const float *t = p.target + ((long long)(n * p.an + a) * (6 + p.C)) * cells + cell;
+    const float tx = t[0], ty = t[cells], tw = t[2 * cells], th = t[3 * cells], tscale = t[4 * cells], tobj = t[5 * cells];
+    const float ts = tscale * tobj;
+    const float x = o[base], y = o[base + 1], lw = o[base + 2], lh = o[base + 3], obj = o[base + 4];
+    const float sx = sigm(x), sy = sigm(y);
+    const float sxy = p.scale_x_y;
+    float l_xy, g_x, g_y;
+    float px, py;                                          // decoded centre offset inside the cell
+    if (fabsf(sxy - 1.0f) < 1e-10f) {                      // plain YOLOv3: binary cross-entropy on sigmoid(x)
+        px = sx; py = sy;
+        l_xy = (tx * (0.f - logf(sx + 1e-9f)) + (1.f - tx) * (0.f - logf(1.f - sx + 1e-9f))) * ts +
+               (ty * (0.f - logf(sy + 1e-9f)) + (1.f - ty) * (0.f - logf(1.f - sy + 1e-9f))) * ts;
+        g_x = ts * (-tx / (sx + 1e-9f) + (1.f - tx) / (1.f - sx + 1e-9f)) * sx * (1.f - sx);
+        g_y = ts * (-ty / (sy + 1e-9f) + (1.f - ty) / (1.f - sy + 1e-9f)) * sy * (1.f - sy);
+    } else {                                               // Grid Sensitive: L1 on the decoded offset
+        px = sxy * sx - 0.5f * (sxy - 1.0f);
+        py = sxy * sy - 0.5f * (sxy - 1.0f);
+        l_xy = fabsf(px - tx) * ts + fabsf(py - ty) * ts;
+        g_x = sgn(px - tx) * ts * sxy * sx * (1.f - sx);
+        g_y = sgn(py - ty) * ts * sxy * sy * (1.f - sy);
+    }
+    const float l_wh = fabsf(lw - tw) * ts + fabsf(lh - th) * ts;
+    float g_w = sgn(lw - tw) * ts, g_h = sgn(lh - th) * ts;
+
+    // ---- IoU of the decoded box with the target box (iou_losses.py:135-190 -> :74-96), all in units of the image side
+    const float aw = p.aw[a], ah = p.ah[a], den = S * p.downsample;
+    const float cx = (px + (float)w) / S, cy = (py + (float)h) / S;
+    const float pw = (expf(lw) * aw) / den, ph = (expf(lh) * ah) / den;
+    const float x1 = cx - 0.5f * pw, y1 = cy - 0.5f * ph, x2r = cx + 0.5f * pw, y2r = cy + 0.5f * ph;
+    const float cxg = (tx + (float)w) / S, cyg = (ty + (float)h) / S;
+    const float pwg = (expf(tw) * aw) / den, phg = (expf(th) * ah) / den;
+    const float x1g = cxg - 0.5f * pwg, y1g = cyg - 0.5f * phg, x2g = cxg + 0.5f * pwg, y2g = cyg + 0.5f * phg;
+    const float x2 = fmaxf(x1, x2r), y2 = fmaxf(y1, y2r);
+    const float m_x2 = dmax_a(x2r, x1), m_y2 = dmax_a(y2r, y1);          // share of x2r in x2 = max(x1, x2r) (1 unless degenerate)
+    const float iw_raw = fminf(x2, x2g) - fmaxf(x1, x1g), ih_raw = fminf(y2, y2g) - fmaxf(y1, y1g);
+    const float iw = fmaxf(iw_raw, 0.f), ih = fmaxf(ih_raw, 0.f);
+    const float inter = iw * ih;
+    const float uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter + 1e-10f;
+    const float k = inter / uni;
+    const float l_iou = (1.f - k * k) * p.w_iou * ts;
+    float dk = -2.f * k * p.w_iou * ts;                                   // d(all losses) / d k, before the batch mean
+    float l_ia = 0.f, g_ioup = 0.f;
+    if (p.iou_aware) {
+        const float *trow = p.target + ((long long)(n * p.an + a) * (6 + p.C) + 5) * cells + h * p.S;
+        float T = 0.f;
+        for (int q = 0; q < p.S; ++q) T += trow[q];                       // sum over grid x of tobj: the reference's broadcast
+        const float ip = sigm(o[a]);
+        const float ce = 0.f - logf(ip + 1e-9f);
+        l_ia = T * k * ce * p.w_iou_aware;
+        dk += T * ce * p.w_iou_aware;
+        g_ioup = T * k * p.w_iou_aware * (-1.f / (ip + 1e-9f)) * ip * (1.f - ip);
+    }
+    if (dk != 0.f) {
+        const float cw = iw_raw >= 0.f ? 1.f : 0.f, chh = ih_raw >= 0.f ? 1.f : 0.f;          // clamp(min=0) backward
+        // d iw / d x2, d iw / d x1 (through x2 = max(x1, x2r): x1 also reaches iw via x2 when degenerate)
+        const float diw_dx2 = cw * dmin_a(x2, x2g), diw_dx1 = -cw * dmax_a(x1, x1g);
+        const float dih_dy2 = chh * dmin_a(y2, y2g), dih_dy1 = -chh * dmax_a(y1, y1g);
+        const float di_dx2 = ih * diw_dx2, di_dx1 = ih * diw_dx1, di_dy2 = iw * dih_dy2, di_dy1 = iw * dih_dy1;
+        const float du_dx2 = (y2 - y1) - di_dx2, du_dx1 = -(y2 - y1) - di_dx1;
+        const float du_dy2 = (x2 - x1) - di_dy2, du_dy1 = -(x2 - x1) - di_dy1;
+        const float iu2 = 1.0f / (uni * uni);
+        float dk_dx2 = (di_dx2 * uni - inter * du_dx2) * iu2, dk_dx1 = (di_dx1 * uni - inter * du_dx1) * iu2;
+        float dk_dy2 = (di_dy2 * uni - inter * du_dy2) * iu2, dk_dy1 = (di_dy1 * uni - inter * du_dy1) * iu2;
+        // x2 = max(x1, x2r): hand x2's gradient to x2r / x1 by their shares
+        const float dk_dx2r = dk_dx2 * m_x2, dk_dy2r = dk_dy2 * m_y2;
+        dk_dx1 += dk_dx2 * (1.f - m_x2);
+        dk_dy1 += dk_dy2 * (1.f - m_y2);
+        const float dk_dcx = dk_dx1 + dk_dx2r, dk_dpw = 0.5f * (dk_dx2r - dk_dx1);
+        const float dk_dcy = dk_dy1 + dk_dy2r, dk_dph = 0.5f * (dk_dy2r - dk_dy1);
+        const float dpx_dx = (fabsf(sxy - 1.0f) < 1e-10f ? 1.f : sxy) * sx * (1.f - sx);
+        const float dpy_dy = (fabsf(sxy - 1.0f) < 1e-10f ? 1.f : sxy) * sy * (1.f - sy);
+        g_x += dk * dk_dcx * dpx_dx / S;
+        g_y += dk * dk_dcy * dpy_dy / S;
+        g_w += dk * dk_dpw * pw;
+        g_h += dk * dk_dph * ph;
+    }
+
+    // ---- objectness with the ignore mask (losses.py:296-356): boxes as paddle_yolo_box decodes them (losses.py:22-83)
+    const float bx = (sxy * sx + (float)w - (sxy - 1.0f) * 0.5f) * p.downsample, by = (sxy * sy + (float)h - (sxy - 1.0f) * 0.5f) * p.downsample;
+    const float bw = expf(lw) * aw, bh = expf(lh) * ah;
+    const float q0 = (bx - bw / 2) / S / p.downsample, q1 = (by - bh / 2) / S / p.downsample;
+    const float q2 = (bx + bw / 2) / S / p.downsample, q3 = (by + bh / 2) / S / p.downsample;
+    const float area_a = (q2 - q0) * (q3 - q1);
+    float best = -__builtin_huge_valf();
+    const float *gt = p.gt + (long long)n * p.G * 4;
+    for (int g = 0; g < p.G; ++g) {
+        const float gx = gt[4 * g], gy = gt[4 * g + 1], gw = gt[4 * g + 2], gh = gt[4 * g + 3];
+        const float g0 = gx - gw / 2.f, g1 = gy - gh / 2.f, g2 = gx + gw / 2.f, g3 = gy + gh / 2.f;
+        const float ww = fmaxf(fminf(q2, g2) - fmaxf(q0, g0), 0.f), hh = fmaxf(fminf(q3, g3) - fmaxf(q1, g1), 0.f);
+        const float it = ww * hh;
+        const float iou = it / (area_a + (g2 - g0) * (g3 - g1) - it);
+        best = (iou > best || iou != iou) ? iou : best;                     // torch.max propagates NaN
+    }
+    const float iou_mask = best <= p.ignore_thresh ? 1.f : 0.f;
+    const float noobj = (1.0f - (tobj > 0.f ? 1.f : 0.f)) * iou_mask;
+    const float so = sigm(obj);
+    const float l_obj = tobj * (0.f - logf(so + 1e-9f)) + noobj * (0.f - logf(1.f - so + 1e-9f));
+    const float g_obj = (-tobj / (so + 1e-9f) + noobj / (1.f - so + 1e-9f)) * so * (1.f - so);
+
+    // ---- classification
+    float l_cls = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+        const float sc = sigm(o[base + 5 + c]), tc = t[(long long)(6 + c) * cells];
+        l_cls += tc * (0.f - logf(sc + 1e-9f)) + (1.f - tc) * (0.f - logf(1.f - sc + 1e-9f));
+        d[base + 5 + c] = tobj * (-tc / (sc + 1e-9f) + (1.f - tc) / (1.f - sc + 1e-9f)) * sc * (1.f - sc) * p.inv_n;
+    }
+    l_cls *= tobj;
+    d[base] = g_x * p.inv_n;
+    d[base + 1] = g_y * p.inv_n;
+    d[base + 2] = g_w * p.inv_n;
+    d[base + 3] = g_h * p.inv_n;
+    d[base + 4] = g_obj * p.inv_n;
+    if (p.iou_aware) d[a] = g_ioup * p.inv_n;
+    float *lp = p.part + i * 6;
+    lp[0] = l_xy; lp[1] = l_wh; lp[2] = l_obj; lp[3] = l_cls; lp[4] = l_iou; lp[5] = l_ia;
+}
+
+// loss[j] = inv_n * sum over the cells, fixed order: one workgroup, strided partial sums, tree
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float *part, long long cells, float inv_n, float *loss, int accumulate) {
+    __shared__ float red[6][256];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long i = threadIdx.x; i < cells; i += 256)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s[j] += part[i * 6 + j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = s[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) loss[threadIdx.x] = (accumulate ? loss[threadIdx.x] : 0.f) + red[threadIdx.x][0] * inv_n;
+}
+
+}  // namespace
+
+extern "C" size_t ppy_yolov3_loss_workspace_bytes(int N, int S, int an) { return (size_t)N * an * S * S * 6 * sizeof(float); }
+
+extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const float *target, const float *gt_box, int num_gt,
+                                   const float *h_anchors_px, int an, int num_classes, int N, int S, int downsample, double scale_x_y,
+                                   double ignore_thresh, double iou_loss_weight, int iou_aware, double iou_aware_loss_weight,
+                                   float *dout, int dout_ld, float *loss6, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(head_out && target && gt_box && h_anchors_px && dout && loss6 && N > 0 && S > 0 && an > 0 && an <= 4 && num_classes > 0);
+    const int nch = an * (5 + num_classes) + (iou_aware ? an : 0);
+    PPY_CHECK_ARG(out_ld >= nch && dout_ld >= nch && num_gt >= 0 && downsample > 0);
+    if (!ws || ws_bytes < ppy_yolov3_loss_workspace_bytes(N, S, an)) return PPY_ERR_WORKSPACE;
+    LossArgs p;
+    p.out = head_out; p.target = target; p.gt = gt_box; p.dout = dout; p.part = (float *)ws;
+    p.out_ld = out_ld; p.dout_ld = dout_ld; p.N = N; p.S = S; p.an = an; p.C = num_classes; p.G = num_gt; p.iou_aware = iou_aware ? 1 : 0;
+    for (int a = 0; a < an; ++a) {
+        p.aw[a] = h_anchors_px[2 * a];
+        p.ah[a] = h_anchors_px[2 * a + 1];
+    }
+    p.downsample = (float)downsample; p.scale_x_y = (float)scale_x_y; p.ignore_thresh = (float)ignore_thresh;
+    p.w_iou = (float)iou_loss_weight; p.w_iou_aware = (float)iou_aware_loss_weight; p.inv_n = 1.0f / (float)N;
+    const long long cells = (long long)N * an * S * S;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, cells, p.inv_n, loss6, accumulate);
+    return ppy_launch_status();
+}

@@ -166,6 +166,105 @@ def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None):
     return ws
 
 
+# ---- training-step operators (csrc/train.hip, csrc/yolo_loss.hip) ---------------------------------------------------
+def _ws_for(nbytes, ws, device):
+    if ws is None or ws.numel() * ws.element_size() < nbytes:
+        ws = _bwd_ws(nbytes, device)
+    return ws
+
+
+def bn_train_stats(x, eps, momentum, mean, invstd, running_mean=None, running_var=None, ws=None):
+    """x: View; mean / invstd [C] written; running statistics updated in place.  See ppy_bn_train_stats_f32."""
+    _dev(x.t, mean, invstd, running_mean, running_var)
+    P = x.N * x.H * x.W
+    ws = _ws_for(int(lib().ppy_bn_train_workspace_bytes(P, x.C)), ws, x.t.device)
+    check(lib().ppy_bn_train_stats_f32(x.ptr, x.ld, P, x.C, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                                       _p(running_mean), _p(running_var), ws.data_ptr(), ws.numel() * 4, _stream()),
+          'ppy_bn_train_stats_f32')
+    return ws
+
+
+def bn_train_apply(x, mean, invstd, gamma, beta, y, act=None, residual=None):
+    _dev(x.t, mean, invstd, gamma, beta, y.t)
+    check(lib().ppy_bn_train_apply_f32(x.ptr, x.ld, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                       None if residual is None else residual.ptr, 0 if residual is None else residual.ld, y.ptr,
+                                       y.ld, x.N * x.H * x.W, x.C, ACT[act], _stream()), 'ppy_bn_train_apply_f32')
+
+
+def bn_train_bwd(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, act=None, ws=None):
+    _dev(x.t, y.t, dy.t, mean, invstd, gamma, dx.t, dgamma, dbeta)
+    P = x.N * x.H * x.W
+    ws = _ws_for(int(lib().ppy_bn_train_workspace_bytes(P, x.C)), ws, x.t.device)
+    check(lib().ppy_bn_train_bwd_f32(x.ptr, x.ld, y.ptr, y.ld, dy.ptr, dy.ld, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                     dx.ptr, dx.ld, dgamma.data_ptr(), dbeta.data_ptr(), P, x.C, ACT[act], ws.data_ptr(),
+                                     ws.numel() * 4, _stream()), 'ppy_bn_train_bwd_f32')
+    return ws
+
+
+def act_bwd(dy, y, dx, act):
+    _dev(dy.t, y.t, dx.t)
+    check(lib().ppy_act_bwd_f32(dy.ptr, dy.ld, y.ptr, y.ld, dx.ptr, dx.ld, dy.N * dy.H * dy.W, dy.C, ACT[act], _stream()),
+          'ppy_act_bwd_f32')
+
+
+def upsample2x_bwd(dy, dx, accumulate=False):
+    _dev(dy.t, dx.t)
+    assert dy.H == 2 * dx.H and dy.W == 2 * dx.W and dy.C == dx.C
+    check(lib().ppy_upsample2x_bwd_f32(dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, int(bool(accumulate)), _stream()),
+          'ppy_upsample2x_bwd_f32')
+
+
+def spp_bwd(x, dy, dx, ws=None):
+    """x: View [N,H,W,C] (the SPP input); dy: View [N,H,W,4C]; dx: View [N,H,W,C]."""
+    _dev(x.t, dy.t, dx.t)
+    assert dy.C == 4 * x.C and dx.C == x.C
+    ws = _ws_for(int(lib().ppy_spp_bwd_workspace_bytes(x.N, x.H, x.W, x.C)), ws, x.t.device)
+    check(lib().ppy_spp_bwd_f32(x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, x.N, x.H, x.W, x.C, ws.data_ptr(), ws.numel() * 4,
+                                _stream()), 'ppy_spp_bwd_f32')
+    return ws
+
+
+def dropblock_mask(mask, scale, keep_prob, seed, block_size=3, ws=None):
+    """mask: [N,H,W,C] fp32 (written: 1 = keep); scale: [1] fp32 (numel / sum(mask))."""
+    _dev(mask, scale)
+    N, H, W, C = mask.shape
+    ws = _ws_for(int(lib().ppy_dropblock_workspace_bytes(N, H, W, C)), ws, mask.device)
+    check(lib().ppy_dropblock_mask_f32(mask.data_ptr(), scale.data_ptr(), N, H, W, C, block_size, float(keep_prob), int(seed),
+                                       ws.data_ptr(), ws.numel() * 4, _stream()), 'ppy_dropblock_mask_f32')
+    return ws
+
+
+def dropblock_apply(x, mask, scale, y):
+    _dev(x.t, mask, scale, y.t)
+    assert mask.is_contiguous() and tuple(mask.shape) == (x.N, x.H, x.W, x.C)
+    check(lib().ppy_dropblock_apply_f32(x.ptr, x.ld, mask.data_ptr(), scale.data_ptr(), y.ptr, y.ld, x.N * x.H * x.W, x.C, _stream()),
+          'ppy_dropblock_apply_f32')
+
+
+def sgd_momentum(param, grad, velocity, lr, momentum, weight_decay, first_step):
+    _dev(param, grad, velocity)
+    assert param.is_contiguous() and grad.is_contiguous() and velocity.is_contiguous() and param.numel() == grad.numel() == velocity.numel()
+    check(lib().ppy_sgd_momentum_f32(param.data_ptr(), grad.data_ptr(), velocity.data_ptr(), param.numel(), float(lr), float(momentum),
+                                     float(weight_decay), int(bool(first_step)), _stream()), 'ppy_sgd_momentum_f32')
+
+
+def yolov3_loss(head_out, target, gt_box, anchors_px, num_classes, downsample, scale_x_y, ignore_thresh, iou_loss_weight, iou_aware,
+                iou_aware_loss_weight, dout, loss6, accumulate=False, ws=None):
+    """head_out / dout: View [N,S,S,*]; target [N,an,6+C,S,S]; gt_box [N,G,4]; loss6 [6] fp32.  See ppy_yolov3_loss_f32."""
+    _dev(head_out.t, target, gt_box, dout.t, loss6)
+    an = len(anchors_px)
+    N, S = head_out.N, head_out.H
+    assert head_out.H == head_out.W and target.is_contiguous() and gt_box.is_contiguous()
+    assert tuple(target.shape) == (N, an, 6 + num_classes, S, S) and gt_box.shape[0] == N and gt_box.shape[2] == 4
+    arr = (ctypes.c_float * (2 * an))(*[float(v) for a in anchors_px for v in a])
+    ws = _ws_for(int(lib().ppy_yolov3_loss_workspace_bytes(N, S, an)), ws, head_out.t.device)
+    check(lib().ppy_yolov3_loss_f32(head_out.ptr, head_out.ld, target.data_ptr(), gt_box.data_ptr(), gt_box.shape[1], arr, an, num_classes,
+                                    N, S, int(downsample), float(scale_x_y), float(ignore_thresh), float(iou_loss_weight),
+                                    int(bool(iou_aware)), float(iou_aware_loss_weight), dout.ptr, dout.ld, loss6.data_ptr(),
+                                    int(bool(accumulate)), ws.data_ptr(), ws.numel() * 4, _stream()), 'ppy_yolov3_loss_f32')
+    return ws
+
+
 def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None):
     _dev(x_nchw, w_kcrs, scale, shift, y.t)
     N, C, H, W = x_nchw.shape

@@ -1,0 +1,194 @@
+"""Training-step operators (csrc/train.hip, csrc/yolo_loss.hip) through the C ABI against torch
+autograd on the CPU (= what the reference's backward is), the training oracle (oracle/train_oracle.py) and the gradients the
+REFERENCE produced in its own step (golden g12: d loss / d head outputs, loss terms)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('shape,act', [((8, 64, 19, 19), 'leaky'), ((2, 260, 3, 3), None), ((3, 100, 7, 5), 'relu'),
+                                       ((8, 32, 152, 152), 'relu'), ((1, 512, 1, 2), 'leaky')])
+def test_batchnorm_training_forward_and_backward(shape, act):
+    from ppyolo_hip import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(1, C, 1, 1, generator=g)) + torch.randn(1, C, 1, 1, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(N, C, H, W, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    y_ref = F.relu(z) if act == 'relu' else (F.leaky_relu(z, 0.1) if act == 'leaky' else z)
+    y_ref.backward(dy)
+    xd = nhwc(x).cuda()
+    mean, invstd = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    rmd, rvd = rm.cuda(), rv.cuda()
+    ops.bn_train_stats(ops.View(xd), 1e-5, 0.1, mean, invstd, rmd, rvd)
+    y = torch.full((N, H, W, C), 5.0).cuda()
+    ops.bn_train_apply(ops.View(xd), mean, invstd, gamma.cuda(), beta.cuda(), ops.View(y), act)
+    dx = torch.zeros(N, H, W, C).cuda()
+    dgam, dbet = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    ops.bn_train_bwd(ops.View(xd), ops.View(y), ops.View(nhwc(dy).cuda()), mean, invstd, gamma.cuda(), ops.View(dx), dgam, dbet, act)
+    torch.cuda.synchronize()
+    assert rel(mean, x.mean((0, 2, 3))) <= 2e-6 and rel(invstd, 1 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)) <= 5e-6
+    assert rel(rmd, rm_ref) <= 2e-6 and rel(rvd, rv_ref) <= 5e-6
+    assert rel(nchw(y), y_ref.detach()) <= 2e-5
+    assert rel(dgam, gr.grad) <= 5e-5 and rel(dbet, br.grad) <= 5e-5, (rel(dgam, gr.grad), rel(dbet, br.grad))
+    assert rel(nchw(dx), xr.grad) <= 1e-4, rel(nchw(dx), xr.grad)
+
+
+def test_upsample_spp_act_backward():
+    from oracle import ppyolo_oracle as orc
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 7, 9, generator=g, requires_grad=True)
+    dy = torch.randn(2, 64, 14, 18, generator=g)
+    F.interpolate(x, scale_factor=2, mode='nearest').backward(dy)
+    dx = torch.ones(2, 7, 9, 64).cuda()
+    ops.upsample2x_bwd(ops.View(nhwc(dy).cuda()), ops.View(dx), accumulate=True)
+    torch.cuda.synchronize()
+    assert rel(nchw(dx) - 1.0, x.grad) <= 1e-6
+    xs = torch.randn(2, 32, 19, 19, generator=g, requires_grad=True)
+    xs.data[0, 0, 3, 3] = xs.data[0, 0, 3, 4] = 9.0                 # an exact tie inside one window: first in scan order wins
+    dys = torch.randn(2, 128, 19, 19, generator=g)
+    orc.spp(xs).backward(dys)
+    dxs = torch.zeros(2, 19, 19, 32).cuda()
+    ops.spp_bwd(ops.View(nhwc(xs.detach()).cuda()), ops.View(nhwc(dys).cuda()), ops.View(dxs))
+    torch.cuda.synchronize()
+    assert rel(nchw(dxs), xs.grad) <= 2e-6
+    y = torch.randn(2, 5, 5, 32, generator=g)
+    d = torch.randn(2, 5, 5, 32, generator=g)
+    out = torch.zeros(2, 5, 5, 32).cuda()
+    ops.act_bwd(ops.View(d.cuda()), ops.View(y.cuda()), ops.View(out), 'leaky')
+    assert torch.equal(out.cpu(), d * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.1)))
+
+
+def test_dropblock_mask_and_apply():
+    """mask = 1 - maxpool3x3(u < gamma) with the counter-based generator (replicated here bit for bit), gamma from the
+    reference's formula, scale = numel / sum(mask); forward y = x * mask * scale."""
+    from ppyolo_hip import ops
+    N, H, W, C, keep, seed = 2, 12, 12, 64, 0.9, 12345
+    mask, scale = torch.zeros(N, H, W, C).cuda(), torch.zeros(1).cuda()
+    ops.dropblock_mask(mask, scale, keep, seed)
+    torch.cuda.synchronize()
+    ids = np.arange(N * H * W * C, dtype=np.uint64)
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over='ignore'):
+        key = (np.uint64(seed) ^ (ids * np.uint64(0xD1342543DE82EF95))) + np.uint64(0x9E3779B97F4A7C15)
+        key = (key ^ (key >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        key = (key ^ (key >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        key = (key ^ (key >> np.uint64(31))) >> np.uint64(32)
+    u = ((key >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(N, H, W, C)
+    gamma = np.float32(H * H * (1 - keep)) / np.float32(9 * (H - 2) ** 2)
+    seeds = torch.from_numpy((u < gamma).astype(np.float32)).permute(0, 3, 1, 2)
+    want = 1.0 - F.max_pool2d(seeds, 3, 1, 1)
+    assert torch.equal(nchw(mask.cpu()), want)
+    assert abs(float(scale) - mask.numel() / float(want.sum())) <= 1e-6 * float(scale)
+    frac = 1.0 - float(want.mean())
+    assert 0.04 < frac < 0.2, frac                                         # ~1 - keep_prob of the activations are dropped
+    x = torch.randn(N, H, W, C).cuda()
+    y = torch.zeros_like(x)
+    ops.dropblock_apply(ops.View(x), mask, scale, ops.View(y))
+    assert rel(y, x.cpu() * mask.cpu() * float(scale)) <= 1e-6
+
+
+def test_sgd_momentum_matches_torch():
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(1000, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=0.0005)
+    p, v = p0.clone().cuda(), torch.zeros(1000).cuda()
+    for step in range(3):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.sgd_momentum(p, gr.cuda(), v, 0.01, 0.9, 0.0005, first_step=(step == 0))
+    torch.cuda.synchronize()
+    assert rel(p, ref.detach()) <= 1e-6
+
+
+@pytest.mark.parametrize('tag', ['r18vd_96', 'r50vd_96'])
+def test_loss_and_dout_match_the_reference_step(golden, tag):
+    """Golden g12: the REFERENCE's head outputs of its training step -> its loss terms and d loss / d outputs."""
+    from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+    from ppyolo_hip import ops
+    g = golden('g12_train_' + tag)
+    cfg = {'r18vd_96': PPYOLO_r18vd_Config, 'r50vd_96': PPYOLO_2x_Config}[tag]()
+    hc = cfg.head
+    L = len(hc['anchor_masks'])
+    loss6 = torch.zeros(6).cuda()
+    gt = torch.from_numpy(g['gt_bbox']).cuda()
+    for i in range(L):
+        out = torch.from_numpy(g['out%d' % i])
+        N, nch, S, _ = out.shape
+        ld = (nch + 31) // 32 * 32
+        ob = torch.zeros(N, S, S, ld).cuda()
+        ob[..., :nch] = nhwc(out).cuda()
+        db = torch.full((N, S, S, ld), 0.0).cuda()
+        anchors = [hc['anchors'][m] for m in hc['anchor_masks'][i]]
+        ops.yolov3_loss(ops.View(ob, 0, nch), torch.from_numpy(g['target%d' % i]).cuda(), gt, anchors, 80, hc['downsample'][i],
+                        cfg.yolo_loss['scale_x_y'], cfg.yolo_loss['ignore_thresh'], cfg.iou_loss['loss_weight'], hc['iou_aware'],
+                        cfg.iou_aware_loss['loss_weight'] if hc['iou_aware'] else 0.0, ops.View(db, 0, nch), loss6, accumulate=i > 0)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(g['dout%d' % i])
+        e = rel(nchw(db[..., :nch]), want)
+        assert e <= 2e-5, 'level %d: d loss / d head output off by %.3e of its maximum' % (i, e)
+        # and element by element where the gradient is not tiny
+        got = nchw(db[..., :nch]).cpu()
+        big = want.abs() > 1e-4 * want.abs().max()
+        assert ((got[big] - want[big]).abs() / want[big].abs()).max() <= 2e-3
+    names = [str(n) for n in g['loss_names']]
+    mine = dict(zip(['loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou', 'loss_iou_aware'], loss6.cpu().tolist()))
+    for nme, val in zip(names, g['loss_values']):
+        assert abs(mine[nme] - float(val)) <= 2e-5 * abs(float(val)), (nme, mine[nme], float(val))
+
+
+def test_loss_plain_yolov3_branch_and_ignore_mask():
+    """scale_x_y = 1 (cross-entropy on x / y), gts that overlap predictions above the ignore threshold, random targets:
+    against the training oracle's autograd."""
+    from config import PPYOLO_r18vd_Config
+    from oracle import train_oracle as trn
+    from ppyolo_hip import ops
+    cfg = PPYOLO_r18vd_Config()
+    cfg.yolo_loss = dict(cfg.yolo_loss, scale_x_y=1.0, ignore_thresh=0.3)
+    cfg.head = dict(cfg.head, anchor_masks=[[3, 4, 5]], downsample=[32])
+    g = torch.Generator().manual_seed(8)
+    N, S, an, C = 3, 6, 3, 80
+    out = (torch.randn(N, an * 85, S, S, generator=g) * 0.7).requires_grad_(True)
+    tgt = torch.zeros(N, an, 6 + C, S, S)
+    gt = torch.zeros(N, 50, 4)
+    for n in range(N):
+        for j in range(4):
+            a, hh, ww = int(torch.randint(0, an, (1,), generator=g)), int(torch.randint(0, S, (1,), generator=g)), int(torch.randint(0, S, (1,), generator=g))
+            tgt[n, a, 0:2, hh, ww] = torch.rand(2, generator=g)
+            tgt[n, a, 2:4, hh, ww] = torch.randn(2, generator=g) * 0.3
+            tgt[n, a, 4, hh, ww] = 1.5
+            tgt[n, a, 5, hh, ww] = 0.7 if j == 0 else 1.0
+            tgt[n, a, 6 + int(torch.randint(0, C, (1,), generator=g)), hh, ww] = 1.0
+            gt[n, j] = torch.tensor([(ww + 0.5) / S, (hh + 0.5) / S, 0.3, 0.25])
+    losses = trn.yolov3_loss([out], [tgt], gt, cfg)
+    sum(losses.values()).backward()
+    ob, db, loss6 = nhwc(out.detach()).cuda(), torch.zeros(N, S, S, an * 85).cuda(), torch.zeros(6).cuda()
+    ops.yolov3_loss(ops.View(ob), tgt.cuda(), gt.cuda(), [cfg.head['anchors'][m] for m in (3, 4, 5)], C, 32, 1.0, 0.3,
+                    cfg.iou_loss['loss_weight'], False, 0.0, ops.View(db), loss6)
+    torch.cuda.synchronize()
+    assert rel(nchw(db), out.grad) <= 2e-5
+    for j, nme in enumerate(['loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou']):
+        assert abs(float(loss6[j]) - float(losses[nme])) <= 2e-5 * abs(float(losses[nme])), nme
