@@ -174,6 +174,13 @@ int ppy_dropblock_apply_f32(const float *x, int x_ld, const float *mask, const f
                             int C, void *stream);
 int ppy_sgd_momentum_f32(float *param, const float *grad, float *velocity, long long n, float lr, float momentum,
                          float weight_decay, int first_step, void *stream);
+/* Plumbing of the training graph: dst += src (second gradient of a tensor with two consumers); the nearest x2 upsample
+ * forward (model/head.py:396-397; the inference path fuses it into the producing convolution's store, which BatchNorm on
+ * batch statistics rules out); per-channel sum over the pixels = gradient of a convolution bias
+ * (ws: ppy_bn_train_workspace_bytes(P, C)). */
+int ppy_add_inplace_f32(float *dst, int dst_ld, const float *src, int src_ld, long long P, int C, void *stream);
+int ppy_upsample2x_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C, void *stream);
+int ppy_channel_sum_f32(const float *dy, int dy_ld, int P, int C, float *out, void *ws, size_t ws_bytes, void *stream);
 
 /* YOLOv3Loss of one head level, forward AND backward (csrc/yolo_loss.hip): the reference's
  * YOLOv3Loss._get_fine_grained_loss (model/losses.py:121-253) with IouLoss / IouAwareLoss (model/iou_losses.py:39-246) and

@@ -55,6 +55,9 @@ _PROTOS = {
                                         c_void_p]),
     'ppy_dropblock_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),
     'ppy_sgd_momentum_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_int, c_void_p]),
+    'ppy_add_inplace_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_void_p]),
+    'ppy_upsample2x_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ppy_channel_sum_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_yolov3_loss_workspace_bytes': (c_size_t, [c_int] * 3),
     'ppy_yolov3_loss_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_int, c_int, c_int, c_int, c_int,
                                      c_double, c_double, c_double, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,

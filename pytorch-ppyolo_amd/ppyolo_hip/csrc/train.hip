@@ -322,6 +322,56 @@ __global__ void __launch_bounds__(256) sgd_kernel(float *p, const float *g, floa
     p[i] -= lr * nv;
 }
 
+// ---- small plumbing kernels of the training graph
+// dst += src (a tensor with two consumers receives its second gradient)
+__global__ void __launch_bounds__(256) add_inplace_kernel(float *dst, int dst_ld, const float *src, int src_ld, long long P, int C) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * c4) return;
+    const int c = (int)(i % c4) * 4;
+    const long long q = i / c4;
+    floatx4 a = *reinterpret_cast<const floatx4 *>(dst + q * dst_ld + c);
+    a += *reinterpret_cast<const floatx4 *>(src + q * src_ld + c);
+    *reinterpret_cast<floatx4 *>(dst + q * dst_ld + c) = a;
+}
+// nearest x2 upsample forward (model/head.py:396-397): y[n, 2h+i, 2w+j, :] = x[n, h, w, :]
+__global__ void __launch_bounds__(256) upsample2x_kernel(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * c4) return;
+    const int c = (int)(i % c4) * 4;
+    long long q = i / c4;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    const floatx4 v = *reinterpret_cast<const floatx4 *>(x + (((long long)n * H + h) * W + w) * x_ld + c);
+    float *o = y + (((long long)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * y_ld + c;
+    *reinterpret_cast<floatx4 *>(o) = v;
+    *reinterpret_cast<floatx4 *>(o + y_ld) = v;
+    *reinterpret_cast<floatx4 *>(o + 2LL * W * y_ld) = v;
+    *reinterpret_cast<floatx4 *>(o + (2LL * W + 1) * y_ld) = v;
+}
+// per-channel sum over the pixels (gradient of a convolution bias): partial sums per slice, then ordered combine
+__global__ void __launch_bounds__(256) chan_sum_partial_kernel(const float *dy, int dy_ld, int P, int C, int pix_per_slice, float *part) {
+    __shared__ float s_a[4][BN_CH];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * BN_CH + cl;
+    const int p0 = blockIdx.y * pix_per_slice, p1 = min(p0 + pix_per_slice, P);
+    float a = 0.f;
+    if (c < C)
+        for (int q = p0 + pl; q < p1; q += 4) a += dy[(long long)q * dy_ld + c];
+    s_a[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && c < C) part[(long long)blockIdx.y * C + c] = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+}
+__global__ void __launch_bounds__(256) chan_sum_final_kernel(const float *part, int C, int slices, float *out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < slices; ++s) a += part[(long long)s * C + c];
+    out[c] = a;
+}
+
 static int slices_for(int P, int C) {
     const int cb = ceil_div(C, BN_CH);
     int sl = ceil_div(1024, cb);                       // ~4 workgroups per CU
@@ -454,5 +504,33 @@ extern "C" int ppy_sgd_momentum_f32(float *param, const float *grad, float *velo
     PPY_CHECK_ARG(param && grad && velocity && n > 0);
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, velocity, n, lr, momentum,
                        weight_decay, first_step);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_add_inplace_f32(float *dst, int dst_ld, const float *src, int src_ld, long long P, int C, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dst && src && P > 0 && C > 0 && C % 4 == 0 && dst_ld >= C && src_ld >= C && dst_ld % 4 == 0 && src_ld % 4 == 0);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, src, src_ld, P, C);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_upsample2x_f32(const float *x, int x_ld, float *y, int y_ld, int N, int H, int W, int C, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, y,
+                       y_ld, N, H, W, C);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_channel_sum_f32(const float *dy, int dy_ld, int P, int C, float *out, void *ws, size_t ws_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && out && P > 0 && C > 0 && dy_ld >= C);
+    if (!ws || ws_bytes < ppy_bn_train_workspace_bytes(P, C)) return PPY_ERR_WORKSPACE;
+    int sl = slices_for(P, C);
+    const int pps = ceil_div(P, sl);
+    sl = ceil_div(P, pps);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_sum_partial_kernel, dim3(ceil_div(C, BN_CH), sl), dim3(256), 0, st, dy, dy_ld, P, C, pps, (float *)ws);
+    hipLaunchKernelGGL(chan_sum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, sl, out);
     return ppy_launch_status();
 }

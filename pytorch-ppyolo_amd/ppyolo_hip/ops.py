@@ -248,6 +248,26 @@ def sgd_momentum(param, grad, velocity, lr, momentum, weight_decay, first_step):
                                      float(weight_decay), int(bool(first_step)), _stream()), 'ppy_sgd_momentum_f32')
 
 
+def add_inplace(dst, src):
+    _dev(dst.t, src.t)
+    assert dst.C == src.C
+    check(lib().ppy_add_inplace_f32(dst.ptr, dst.ld, src.ptr, src.ld, dst.N * dst.H * dst.W, dst.C, _stream()), 'ppy_add_inplace_f32')
+
+
+def upsample2x(x, y):
+    _dev(x.t, y.t)
+    assert y.H == 2 * x.H and y.W == 2 * x.W and y.C == x.C
+    check(lib().ppy_upsample2x_f32(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_upsample2x_f32')
+
+
+def channel_sum(dy, out, ws=None):
+    _dev(dy.t, out)
+    P = dy.N * dy.H * dy.W
+    ws = _ws_for(int(lib().ppy_bn_train_workspace_bytes(P, dy.C)), ws, dy.t.device)
+    check(lib().ppy_channel_sum_f32(dy.ptr, dy.ld, P, dy.C, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), 'ppy_channel_sum_f32')
+    return ws
+
+
 def yolov3_loss(head_out, target, gt_box, anchors_px, num_classes, downsample, scale_x_y, ignore_thresh, iou_loss_weight, iou_aware,
                 iou_aware_loss_weight, dout, loss6, accumulate=False, ws=None):
     """head_out / dout: View [N,S,S,*]; target [N,an,6+C,S,S]; gt_box [N,G,4]; loss6 [6] fp32.  See ppy_yolov3_loss_f32."""

@@ -1,0 +1,472 @@
+"""One training step of PP-YOLO on the MI355X (BASELINE config 5).
+
+What the reference's `train.py:416-443` does per iteration -- `losses = model(images, None, False, gt_bbox, gt_class,
+gt_score, targets)`, `all_loss.backward()`, `optimizer.step()` -- as a sequence of hand-written HIP kernels behind the C ABI:
+
+  * training-mode forward of the WHOLE network: every convolution unfused from its BatchNorm, which runs on batch statistics
+    (the reference never calls `.eval()`; `backbone.freeze()` only stops gradients: model/resnet_vd.py:174-200), DropBlock
+    drawing a mask, CoordConv as a real concatenation (its two weight columns train);
+  * YOLOv3Loss forward + backward in one kernel per head level (csrc/yolo_loss.hip);
+  * backward through the head only (freeze_at = 5 in both configs): BatchNorm / LeakyReLU backward, conv wgrad and dgrad
+    (csrc/conv_bwd.hip), nearest-upsample, SPP and DropBlock backward -- a tape recorded during the forward, replayed in
+    reverse;
+  * one RCCL all-reduce of ALL gradients (they live in one flat buffer) when several ranks train data-parallel, then
+    SGD-momentum with the reference's parameter groups (weight decay on convolution weights only: custom_layers.py:167-215).
+
+The convolutions run on the exact bf16x3 split (no tracked maxima needed); torch supplies memory, streams and
+`torch.distributed` only.  There is no CPU path.
+"""
+import torch
+
+from . import ops as K
+from ._lib import PPYoloHipError
+
+
+class Act(object):
+    """NHWC activation: channel slice [coff, coff + C) of a buffer [N, H, W, ld]; `g` = its gradient (an Act) once a
+    consumer has produced one; `req` = whether anything upstream wants that gradient."""
+    __slots__ = ('t', 'coff', 'C', 'g', 'req')
+
+    def __init__(self, t, coff=0, C=None, req=False):
+        self.t, self.coff, self.C, self.g, self.req = t, coff, (t.shape[3] - coff if C is None else C), None, req
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    def view(self):
+        return K.View(self.t, self.coff, self.C)
+
+    def slice(self, coff, C):
+        return Act(self.t, self.coff + coff, C, self.req)
+
+    def dense_nchw(self):
+        return self.t[..., self.coff:self.coff + self.C].permute(0, 3, 1, 2).contiguous()
+
+
+def _r32(c):
+    return (c + 31) // 32 * 32
+
+
+class TrainStep(object):
+    def __init__(self, model, cfg, world_size=1):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise PPYoloHipError('the training step needs the model on a ROCm device (got %s); there is no CPU path' % dev)
+        if cfg.backbone.get('freeze_at', 5) != 5:
+            raise PPYoloHipError('only the reference configurations (freeze_at = 5: the head trains) are implemented')
+        self.model, self.cfg, self.dev, self.world = model, cfg, dev, world_size
+        self.sd = model.state_dict()                       # tensors alias the module's parameters / buffers
+        self.train_keys = [k for k, _ in model.named_parameters() if k.startswith('head.')]
+        self._wcache = {}
+        self._const = {}
+        self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
+        self.steps_done = 0
+        self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
+        self.weight_decay = cfg.optimizerBuilder['regularizer']['factor']
+        self.gflat = None
+        self.G, self.V = {}, {}
+        self.masks = None
+        self.seed = 0
+        self.acts = None
+
+    # ---- constants / buffers -------------------------------------------------------------------------------------
+    def _vec(self, name, n, val):
+        key = (name, n)
+        if key not in self._const:
+            self._const[key] = torch.full((n,), val, dtype=torch.float32, device=self.dev)
+        return self._const[key]
+
+    def new(self, N, H, W, C, ld=None, req=False, zero=False):
+        ld = C if ld is None else ld
+        t = (torch.zeros if zero else torch.empty)((N, H, W, ld), dtype=torch.float32, device=self.dev)
+        return Act(t, 0, C, req)
+
+    # ---- parameters in kernel layout ---------------------------------------------------------------------------------
+    def weight(self, key, coord=False):
+        """-> dict(krsc, planes, Cin): the convolution weight `key` ([K, C, R, S] in the state_dict) as KRSC, padded to a
+        multiple of 32 input channels behind a CoordConv; trainable weights keep a MASTER copy here (updated by SGD, written
+        back by sync_to_model) and get their bf16 planes re-split every step."""
+        ent = self._wcache.get(key)
+        if ent is None:
+            w = self.sd[key].detach().float()
+            Kout, Cin, R, S = w.shape
+            Cp = _r32(Cin) if (coord or Cin % 32) else Cin
+            krsc = torch.zeros((Kout, R, S, Cp), dtype=torch.float32, device=self.dev)
+            krsc[..., :Cin] = w.permute(0, 2, 3, 1)
+            ent = dict(krsc=krsc, planes=None, Cin=Cin, trainable=key in self.train_keys)
+            self._wcache[key] = ent
+        if ent['planes'] is None or ent['trainable']:
+            ent['planes'] = K.split_weights_bf16x3(ent['krsc'])
+        return ent
+
+    def _alloc_grads(self):
+        """All gradients in ONE flat buffer (a single all-reduce serves every tensor), views per parameter in kernel layout."""
+        shapes = {}
+        for k in self.train_keys:
+            shapes[k] = tuple(self._wcache[k]['krsc'].shape) if k in self._wcache else tuple(self.sd[k].shape)
+        offs, total = {}, 0
+        for k, shp in shapes.items():
+            n = 1
+            for d in shp:
+                n *= d
+            offs[k] = (total, n, shp)
+            total += (n + 63) // 64 * 64
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.vflat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        for k, (o, n, shp) in offs.items():
+            self.G[k] = self.gflat[o:o + n].view(shp)
+            self.V[k] = self.vflat[o:o + n].view(shp)
+
+    # ---- forward ops ---------------------------------------------------------------------------------------------------
+    def coord_concat(self, x):
+        """CoordConv.__call__ (reference model/custom_layers.py:261-272) as a real concatenation, zero-padded to a multiple
+        of 32 channels for the implicit GEMM: [x, x_range, y_range, 0 ...]."""
+        Cp = _r32(x.C + 2)
+        out = self.new(x.N, x.H, x.W, Cp, req=x.req, zero=True)
+        out.t[..., :x.C].copy_(x.t[..., x.coff:x.coff + x.C])
+        key = ('coord', x.H, x.W)
+        if key not in self._const:
+            xr = torch.arange(0, x.W, dtype=torch.float32, device=self.dev) / (x.W - 1) * 2.0 - 1
+            yr = torch.arange(0, x.H, dtype=torch.float32, device=self.dev) / (x.H - 1) * 2.0 - 1
+            g = torch.zeros((x.H, x.W, 2), dtype=torch.float32, device=self.dev)
+            g[:, :, 0] = xr.view(1, x.W)
+            g[:, :, 1] = yr.view(x.H, 1)
+            self._const[key] = g
+        out.t[..., x.C:x.C + 2] = self._const[key]
+        return out
+
+    def conv_unit(self, prefix, x, stride=1, act=None, res=None, coord=False, out=None):
+        """Conv2dUnit.forward in training mode (reference model/custom_layers.py:243-253): conv -> BatchNorm on batch
+        statistics -> activation; records its backward when its parameters train."""
+        sd = self.sd
+        if prefix + '.conv.dcn_weight' in sd:
+            return self._dcn_unit(prefix, x, stride, act)
+        wkey = prefix + '.conv.weight'
+        ent = self.weight(wkey, coord)
+        trainable = ent['trainable']
+        xin = self.coord_concat(x) if coord else x
+        krsc = ent['krsc']
+        Kout, R, S, Cp = krsc.shape
+        if xin.C != Cp:
+            raise PPYoloHipError('%s: input has %d channels, the weight %d' % (prefix, xin.C, Cp))
+        pad = (R - 1) // 2
+        Ho, Wo = K.conv_out_hw(xin.H, xin.W, R, S, stride, pad)
+        bias = sd.get(prefix + '.conv.bias')
+        has_bn = prefix + '.bn.weight' in sd
+        raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
+        K.conv2d_bn_act(xin.view(), krsc, self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0),
+                        raw.view(), stride, pad, None, ws=self.ws, w_x3=ent['planes'])
+        if not has_bn:
+            y = raw
+            mean = invstd = None
+        else:
+            mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+            invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+            K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
+            sd[prefix + '.bn.num_batches_tracked'] += 1
+            y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
+            y.req = trainable
+            K.bn_train_apply(raw.view(), mean, invstd, sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'], y.view(), act,
+                             None if res is None else res.view())
+        if trainable:
+            self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent))
+        if self.acts is not None:          # debugging / tests: activations (and, after the backward, their gradients) by layer
+            self.acts[prefix] = y
+        return y
+
+    def _conv_unit_bwd(self, prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent):
+        dy = y.g
+        if dy is None:
+            raise PPYoloHipError('%s: no gradient reached this layer' % prefix)
+        sd = self.sd
+        if mean is not None:
+            d_raw = self.new(raw.N, raw.H, raw.W, raw.C)
+            K.bn_train_bwd(raw.view(), y.view(), dy.view(), mean, invstd, sd[prefix + '.bn.weight'], d_raw.view(),
+                           self.G[prefix + '.bn.weight'], self.G[prefix + '.bn.bias'], act, self.ws)
+        else:
+            d_raw = dy
+            K.channel_sum(dy.view(), self.G[prefix + '.conv.bias'], self.ws)
+        K.conv2d_wgrad(xin.view(), d_raw.view(), self.G[prefix + '.conv.weight'], stride, pad, self.ws)
+        if x.req:
+            dxin = self.new(xin.N, xin.H, xin.W, xin.C)
+            K.conv2d_dgrad(d_raw.view(), ent['krsc'], dxin.view(), stride, pad, self.ws)
+            self.accum(x, dxin.slice(0, x.C))
+
+    def _dcn_unit(self, prefix, x, stride, act):
+        """DCNv2 inside a (frozen) backbone unit: offsets / masks from conv_offset, deformable contraction, BatchNorm on batch
+        statistics (reference model/custom_layers.py:551-677)."""
+        sd = self.sd
+        co = self.weight(prefix + '.conv.conv_offset.weight')
+        Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
+        om = self.new(x.N, Ho, Wo, 27, ld=32, zero=True)
+        K.conv2d_bn_act(x.view(), co['krsc'], self._vec('one', 27, 1.0), sd[prefix + '.conv.conv_offset.bias'], om.view(), stride, 1, None,
+                        ws=self.ws, w_x3=co['planes'])
+        w = self.weight(prefix + '.conv.dcn_weight')
+        Kout = w['krsc'].shape[0]
+        raw = self.new(x.N, Ho, Wo, Kout)
+        K.dcnv2(x.view(), w['krsc'], self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), om.view(), raw.view(), stride, 1, None,
+                self.ws, w_x3=w['planes'])
+        mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+        invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+        K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
+        sd[prefix + '.bn.num_batches_tracked'] += 1
+        y = self.new(x.N, Ho, Wo, Kout)
+        K.bn_train_apply(raw.view(), mean, invstd, sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'], y.view(), act)
+        return y
+
+    def accum(self, x, g):
+        if x.g is None:
+            x.g = g
+        else:
+            K.add_inplace(x.g.view(), g.view())
+
+    # ---- backbone (forward only: frozen) ----------------------------------------------------------------------------------
+    def _stem(self, x_nchw):
+        sd, p = self.sd, 'backbone.stage1_conv1_1'
+        w = sd[p + '.conv.weight']
+        N, _, H, W = x_nchw.shape
+        Ho, Wo = K.conv_out_hw(H, W, 3, 3, 2, 1)
+        Kout = w.shape[0]
+        raw = self.new(N, Ho, Wo, Kout)
+        K.stem_conv(x_nchw, w.detach().float().contiguous(), self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), raw.view(), None)
+        mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+        invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
+        K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], self.ws)
+        sd[p + '.bn.num_batches_tracked'] += 1
+        y = self.new(N, Ho, Wo, Kout)
+        K.bn_train_apply(raw.view(), mean, invstd, sd[p + '.bn.weight'], sd[p + '.bn.bias'], y.view(), 'relu')
+        y = self.conv_unit('backbone.stage1_conv1_2', y, 1, 'relu')
+        y = self.conv_unit('backbone.stage1_conv1_3', y, 1, 'relu')
+        Hp, Wp = K.conv_out_hw(y.H, y.W, 3, 3, 2, 1)
+        o = self.new(N, Hp, Wp, y.C)
+        K.maxpool3x3s2(y.view(), o.view())
+        return o
+
+    def _avgpool(self, x):
+        o = self.new(x.N, x.H // 2, x.W // 2, x.C)
+        K.avgpool2x2(x.view(), o.view())
+        return o
+
+    def _bottleneck(self, p, x, stride, has_proj, is_first):
+        # reference model/resnet_vd.py:48-57, :81-87
+        y = self.conv_unit(p + '.conv1', x, 1, 'relu')
+        y = self.conv_unit(p + '.conv2', y, stride, 'relu')
+        if has_proj:
+            s = self.conv_unit(p + '.conv4', x, stride, None) if is_first else self.conv_unit(p + '.conv4', self._avgpool(x), 1, None)
+        else:
+            s = x
+        return self.conv_unit(p + '.conv3', y, 1, 'relu', res=s)             # relu(bn(conv3) + shortcut)
+
+    def _basic(self, p, x, stride, is_first):
+        # reference model/resnet_vd.py:256-267
+        y = self.conv_unit(p + '.conv1', x, stride, 'relu')
+        if stride == 2 or is_first:
+            s = self.conv_unit(p + '.conv3', x, stride, None) if is_first else self.conv_unit(p + '.conv3', self._avgpool(x), 1, None)
+        else:
+            s = x
+        return self.conv_unit(p + '.conv2', y, 1, 'relu', res=s)
+
+    def backbone(self, x_nchw):
+        cfg = self.cfg
+        x = self._stem(x_nchw)
+        feats = {}
+        if cfg.backbone_type == 'Resnet50Vd':
+            for stage, nblk in ((2, 3), (3, 4), (4, 6), (5, 3)):
+                for b in range(nblk):
+                    p = 'backbone.stage%d_%d' % (stage, b)
+                    x = self._bottleneck(p, x, 1 if (stage == 2 or b > 0) else 2, b == 0, stage == 2)
+                feats[stage] = x
+        else:
+            for stage in (2, 3, 4, 5):
+                for b in range(2):
+                    p = 'backbone.stage%d_%d' % (stage, b)
+                    x = self._basic(p, x, 2 if (b == 0 and stage > 2) else 1, b == 0 and stage == 2)
+                feats[stage] = x
+        return [feats[s] for s in (2, 3, 4, 5) if s in cfg.backbone['feature_maps']]
+
+    # ---- head (trains) --------------------------------------------------------------------------------------------------------
+    def drop_block(self, x, keep_prob):
+        """DropBlock in training mode (reference model/custom_layers.py:303-342)."""
+        if self.masks is not None:                         # parity tests: the reference's own mask ([N, C, H, W], 1 = keep)
+            m = self.masks.pop(0).to(self.dev).permute(0, 2, 3, 1).contiguous()
+            scale = torch.tensor([float(m.numel()) / float(m.sum())], dtype=torch.float32, device=self.dev)
+        else:
+            m = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=self.dev)
+            scale = torch.empty(1, dtype=torch.float32, device=self.dev)
+            self.seed += 1
+            K.dropblock_mask(m, scale, keep_prob, (self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
+        y = self.new(x.N, x.H, x.W, x.C, req=True)
+        K.dropblock_apply(x.view(), m, scale, y.view())
+
+        def bwd():
+            g = self.new(x.N, x.H, x.W, x.C)
+            K.dropblock_apply(y.g.view(), m, scale, g.view())
+            self.accum(x, g)
+        self.tape.append(bwd)
+        return y
+
+    def detection_block(self, p, x, hcfg, is_first):
+        """DetectionBlock.__call__ (reference model/head.py:146-231); layer indices as in the state_dict keys."""
+        nblk, coord = hcfg.get('conv_block_num', 2), hcfg.get('coord_conv', True)
+        use_spp, drop, keep = hcfg.get('spp', True), hcfg.get('drop_block', True), hcfg.get('keep_prob', 0.9)
+        idx = 0
+        for j in range(nblk):
+            if use_spp and is_first and j == 1:
+                Cw = self.sd['%s.layers.%d.conv.weight' % (p, idx + 1)].shape[0]
+                wide = self.new(x.N, x.H, x.W, 4 * Cw, req=True)
+                slot0 = wide.slice(0, Cw)
+                self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord, out=slot0)
+                K.spp(slot0.view(), wide.slice(Cw, Cw).view(), wide.slice(2 * Cw, Cw).view(), wide.slice(3 * Cw, Cw).view())
+
+                def spp_bwd(wide=wide, slot0=slot0, Cw=Cw):
+                    g = self.new(wide.N, wide.H, wide.W, Cw)
+                    K.spp_bwd(slot0.view(), wide.g.view(), g.view(), self.ws)
+                    self.accum(slot0, g)
+                self.tape.append(spp_bwd)
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 3), wide, 1, 'leaky')
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 4), x, 1, 'leaky')
+                idx += 5
+            else:
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord)
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 2), x, 1, 'leaky')
+                idx += 3
+            if drop and j == 0 and not is_first:
+                x = self.drop_block(x, keep)
+                idx += 1
+        if drop and is_first:
+            x = self.drop_block(x, keep)
+            idx += 1
+        route = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord)
+        tip = self.conv_unit('%s.tip_layers.1' % p, route, 1, 'leaky', coord=coord)
+        return route, tip
+
+    def head(self, feats):
+        """YOLOv3Head._get_outputs (reference model/head.py:381-398)."""
+        hcfg = self.cfg.head
+        n_lvl = len(hcfg['anchor_masks'])
+        blocks = feats[::-1][:n_lvl]
+        outs, route = [], None
+        for i, feat in enumerate(blocks):
+            if i > 0:
+                Cr = route.C
+                wide = self.new(feat.N, feat.H, feat.W, Cr + feat.C, req=True)
+                up = wide.slice(0, Cr)
+                K.upsample2x(route.view(), up.view())
+                wide.t[..., Cr:].copy_(feat.t[..., feat.coff:feat.coff + feat.C])
+
+                def up_bwd(route=route, wide=wide, Cr=Cr):
+                    g = self.new(route.N, route.H, route.W, Cr)
+                    K.upsample2x_bwd(wide.g.slice(0, Cr).view(), g.view())
+                    self.accum(route, g)
+                self.tape.append(up_bwd)
+                blk = wide
+            else:
+                blk = feat
+            route, tip = self.detection_block('head.detection_blocks.%d' % i, blk, hcfg, i == 0)
+            outs.append(self.conv_unit('head.yolo_output_convs.%d' % i, tip, 1, None))
+            if i < n_lvl - 1:
+                route = self.conv_unit('head.upsample_layers.%d' % (2 * i), route, 1, 'leaky')
+        return outs
+
+    # ---- the step ------------------------------------------------------------------------------------------------------------
+    def forward_backward(self, x_nchw, gt_box, targets, dropblock_masks=None, inject_douts=None):
+        """Forward + loss + backward.  -> the six loss terms (device tensor [6]: loss_xy, loss_wh, loss_obj, loss_cls, loss_iou,
+        loss_iou_aware).  `dropblock_masks` / `inject_douts` are test hooks: the reference's own DropBlock masks, and a loss
+        gradient computed elsewhere (the L1 terms of the loss have kinks, so two fp32 evaluations of the network that differ by
+        1e-3 can disagree on a sign there; the loss kernel is checked on identical inputs in tests/test_gpu_train_ops.py)."""
+        if not x_nchw.is_cuda:
+            raise PPYoloHipError('the training step needs ROCm device tensors; there is no CPU path')
+        self.tape = []
+        self.masks = list(dropblock_masks) if dropblock_masks is not None else None
+        with torch.no_grad():
+            feats = self.backbone(x_nchw.float().contiguous())
+        return self.head_loss_backward(feats, gt_box, targets, inject_douts)
+
+    def head_loss_backward(self, feats, gt_box, targets, inject_douts=None):
+        """Head forward on the given backbone features (list of Act, shallowest first), loss, backward, -> loss terms [6]."""
+        cfg, hcfg = self.cfg, self.cfg.head
+        with torch.no_grad():
+            outs = self.head(feats)
+            if self.gflat is None:
+                self._alloc_grads()
+            loss6 = torch.zeros(6, dtype=torch.float32, device=self.dev)
+            iou_aware = bool(hcfg.get('iou_aware', False))
+            for i, out in enumerate(outs):
+                anchors = [hcfg['anchors'][m] for m in hcfg['anchor_masks'][i]]
+                dout = Act(torch.zeros_like(out.t), 0, out.C)
+                K.yolov3_loss(out.view(), targets[i].float().contiguous(), gt_box.float().contiguous(), anchors, hcfg['num_classes'],
+                              hcfg['downsample'][i], cfg.yolo_loss['scale_x_y'], cfg.yolo_loss['ignore_thresh'], cfg.iou_loss['loss_weight'],
+                              iou_aware, cfg.iou_aware_loss['loss_weight'] if iou_aware else 0.0, dout.view(), loss6, accumulate=i > 0,
+                              ws=self.ws)
+                if inject_douts is not None:
+                    dout.t[..., :out.C].copy_(inject_douts[i].to(self.dev).permute(0, 2, 3, 1))
+                out.g = dout
+            for fn in reversed(self.tape):
+                fn()
+        self.outs = outs
+        self.tape = []
+        return loss6
+
+    def all_reduce(self):
+        """Data-parallel ranks: average ALL gradients with one collective (RCCL over xGMI; BatchNorm stays per GPU, like
+        the reference's 'sync_bn' -> 'bn' alias, model/custom_layers.py:28-29)."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gflat)
+            self.gflat.mul_(1.0 / self.world)
+
+    def sgd(self, lr):
+        """optimizer.step() of train.py:442 with the reference's parameter groups."""
+        first = self.steps_done == 0
+        for k in self.train_keys:
+            p = self._wcache[k]['krsc'] if k in self._wcache else self.sd[k]
+            wd = self.weight_decay if k.endswith('conv.weight') else 0.0
+            K.sgd_momentum(p.view(-1), self.G[k].view(-1), self.V[k].view(-1), lr, self.momentum, wd, first)
+        self.steps_done += 1
+
+    def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None):
+        loss6 = self.forward_backward(x_nchw, gt_box, targets, dropblock_masks)
+        self.all_reduce()
+        self.sgd(lr)
+        return loss6
+
+    # ---- views for tests / checkpoints --------------------------------------------------------------------------------------
+    def grads(self):
+        """Gradients in the state_dict's own layouts ([K, C, R, S] convolution weights)."""
+        out = {}
+        for k in self.train_keys:
+            g = self.G[k]
+            if k in self._wcache:
+                g = g[..., :self._wcache[k]['Cin']].permute(0, 3, 1, 2).contiguous()
+            out[k] = g.clone()
+        return out
+
+    def sync_to_model(self):
+        """Write the trained convolution weights (kept in kernel layout during training) back into the module."""
+        for k in self.train_keys:
+            if k in self._wcache:
+                ent = self._wcache[k]
+                self.sd[k].copy_(ent['krsc'][..., :ent['Cin']].permute(0, 3, 1, 2))
+        if hasattr(self.model, '_plans'):
+            self.model._plans.clear()
+
+
+def lr_at(iter_id, cfg):
+    """calc_lr of the reference (train.py:172-188): linear warm-up, then piecewise decay."""
+    lrc = cfg.learningRate
+    base, gamma, miles = lrc['base_lr'], lrc['PiecewiseDecay']['gamma'], lrc['PiecewiseDecay']['milestones']
+    for i in range(len(miles), 0, -1):
+        if iter_id >= miles[i - 1]:
+            return base * gamma ** i
+    steps, start = lrc['LinearWarmup']['steps'], lrc['LinearWarmup']['start_factor']
+    if iter_id <= steps:
+        return base * (start + (1.0 - start) / steps * iter_id)
+    return base
