@@ -391,6 +391,65 @@ def check_world(gpus, env):
     return world
 
 
+def train_bench(a, wl, dev, rank, world):
+    """BASELINE config 5: the TRAINING step (reference train.py:416-443) of the same network, 8 images per GPU, data parallel:
+    training-mode forward, YOLOv3Loss, backward through the head, ONE RCCL all-reduce of all gradients, SGD
+    (ppyolo_hip/train.py).  Prints its own JSON line (rank 0)."""
+    import numpy as np
+    from ppyolo_hip import synth
+    from ppyolo_hip.targets import gt2yolo_target, synth_ground_truth
+    from ppyolo_hip.train import TrainStep, lr_at
+    model, sd, cfg = build_model(wl['cfg'], dev)
+    S, hc = wl['size'], None
+    hc = cfg.head
+    x = synth.synth_images(a.batch, S, seed=1234 + rank + a.seed_offset).to(dev)
+    bb, cc, ss = synth_ground_truth(a.batch, 50 + rank + a.seed_offset)
+    targets = [torch.from_numpy(t).to(dev) for t in gt2yolo_target(bb, cc, ss, hc['anchors'], hc['anchor_masks'], hc['downsample'], 80, S)]
+    gt = torch.from_numpy(bb).to(dev)
+    ts = TrainStep(model, cfg, world)
+    lr = lr_at(4000, cfg)
+    losses = []
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(1, a.warmup)):
+        losses.append(ts.step(x, gt, targets, lr))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses.append(ts.step(x, gt, targets, lr))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if a.dump_dets and rank == 0:                       # tests: the averaged gradients of the last step
+        np.save(a.dump_dets, ts.gflat.cpu().numpy())
+    if rank == 0:
+        tot = [float(l.sum()) for l in losses]
+        flops = ts.flops
+        ach = flops / (dt / a.steps) / 1e12
+        out = dict(metric='images/sec %s %dx%d TRAIN step, %d images per GPU' % (wl['model'], S, S, a.batch),
+                   value=round(world * a.batch * a.steps / dt, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=max(1, a.warmup),
+                   ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+                   data='synthetic (randn images, synthetic boxes through Gt2YoloTarget, deterministic random weights)',
+                   config=dict(workload='%s %dx%d training step (reference train.py:416-443, freeze_at=5: the head trains), %d images per '
+                                        'GPU' % (wl['model'], S, S, a.batch), global_batch=world * a.batch,
+                               parallelism=('data parallel x%d, one all-reduce of %.1f MB of gradients per step' % (world, ts.gflat.numel() * 4 / 1e6))
+                               if world > 1 else 'single GPU', math='bf16x3 (exact 3-term bf16 split, fp32 accumulate) for every convolution, '
+                               'exact-fp32 MFMA for the weight gradients', eager=True),
+                   loss_first=round(tot[0], 4), loss_last=round(tot[-1], 4),
+                   roofline=dict(bound='mfma', achieved=round(ach, 2), peak=round(X3_PEAK_TFLOPS, 1), unit='TFLOP/s',
+                                 frac=round(ach / X3_PEAK_TFLOPS, 4), traffic=None, flops_per_step=flops,
+                                 kernel='conv_igemm_x3_kernel<*> (bf16x3) forward + dgrad, conv_wgrad_kernel (exact fp32 MFMA)',
+                                 peak_note='achieved = algorithmic convolution FLOPs of forward + head backward / WHOLE step time (BatchNorm, loss, '
+                                           'SGD and launch gaps included: the step is not graph-captured yet); peak = dense bf16 MFMA / 6'))
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -418,6 +477,8 @@ def main():
                     'computes the batch rank r computes in a multi-rank run; tests)')
     ap.add_argument('--dump-dets', default=None, help='rank 0 writes the gathered detection records of one extra step '
                     '([world*batch, keep_top_k+1, 6]) to this .npy file (tests)')
+    ap.add_argument('--train', action='store_true', help='BASELINE config 5: time the training step (ppyolo_hip/train.py) instead of '
+                    'inference; prints its own JSON line')
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state running before the timed K steps and '
                     'length of the `sustained` measurement (the board is power-managed: DESIGN.md 4.1)')
     a = ap.parse_args()
@@ -444,6 +505,11 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()
+    if a.train:
+        train_bench(a, wl, dev, rank, world)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     model, sd, cfg = build_model(wl['cfg'], dev)
     from ppyolo_hip import synth
     x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank + a.seed_offset).to(dev)

@@ -77,6 +77,7 @@ class TrainStep(object):
         self.masks = None
         self.seed = 0
         self.acts = None
+        self.flops = 0                      # algorithmic convolution FLOPs (2 * MAC) of the last forward + backward
 
     # ---- constants / buffers -------------------------------------------------------------------------------------
     def _vec(self, name, n, val):
@@ -165,6 +166,7 @@ class TrainStep(object):
         raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
         K.conv2d_bn_act(xin.view(), krsc, self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0),
                         raw.view(), stride, pad, None, ws=self.ws, w_x3=ent['planes'])
+        self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
         if not has_bn:
             y = raw
             mean = invstd = None
@@ -196,7 +198,10 @@ class TrainStep(object):
             d_raw = dy
             K.channel_sum(dy.view(), self.G[prefix + '.conv.bias'], self.ws)
         K.conv2d_wgrad(xin.view(), d_raw.view(), self.G[prefix + '.conv.weight'], stride, pad, self.ws)
+        unit = 2 * raw.N * raw.H * raw.W * raw.C * ent['krsc'].shape[1] * ent['krsc'].shape[2] * ent['Cin']
+        self.flops += unit
         if x.req:
+            self.flops += unit
             dxin = self.new(xin.N, xin.H, xin.W, xin.C)
             K.conv2d_dgrad(d_raw.view(), ent['krsc'], dxin.view(), stride, pad, self.ws)
             self.accum(x, dxin.slice(0, x.C))
@@ -215,6 +220,7 @@ class TrainStep(object):
         raw = self.new(x.N, Ho, Wo, Kout)
         K.dcnv2(x.view(), w['krsc'], self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), om.view(), raw.view(), stride, 1, None,
                 self.ws, w_x3=w['planes'])
+        self.flops += 2 * x.N * Ho * Wo * (Kout * 9 * x.C + 27 * 9 * x.C)
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
@@ -386,6 +392,7 @@ class TrainStep(object):
         if not x_nchw.is_cuda:
             raise PPYoloHipError('the training step needs ROCm device tensors; there is no CPU path')
         self.tape = []
+        self.flops = 0
         self.masks = list(dropblock_masks) if dropblock_masks is not None else None
         with torch.no_grad():
             feats = self.backbone(x_nchw.float().contiguous())

@@ -82,3 +82,28 @@ def test_two_ranks_equal_two_single_runs(tmp_path):
     r2 = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     assert np.array_equal(np.load(f), singles[0])
+
+
+@pytest.mark.gpu
+def test_train_step_two_ranks_average_their_gradients(tmp_path):
+    """BASELINE config 5 on two ranks (one GPU shared, gloo): after the all-reduce every rank holds the MEAN of the two ranks'
+    gradients -- compared with two single-rank runs on the same batches."""
+    common = ['--train', '--workload', 'r18vd_320', '--batch', '4', '--steps', '1', '--warmup', '1', '--min-seconds', '0']
+    two = str(tmp_path / 'g2.npy')
+    r = _run(['--gpus', '2', '--share-gpu', '--dump-dets', two] + common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 8 and 'TRAIN' in line['metric'] and np.isfinite(line['loss_last'])
+    singles = []
+    for off in (0, 1):
+        f = str(tmp_path / ('g1_%d.npy' % off))
+        r1 = _run(['--gpus', '1', '--seed-offset', str(off), '--dump-dets', f] + common)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        singles.append(np.load(f))
+    # step 1 (warm-up) already updated the weights with rank-specific vs averaged gradients, so only the FIRST step's gradients
+    # are comparable: with --warmup 1 --steps 1 the dump is the second step's -- compare at the tolerance one SGD step of
+    # lr 1e-4 allows (the weights of the two settings differ by lr * |g1 - g2| / 2)
+    got, want = np.load(two), 0.5 * (singles[0] + singles[1])
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    assert rel <= 5e-2, rel
+    assert np.abs(singles[0] - singles[1]).max() / np.abs(want).max() > 0.2      # the two batches do produce different gradients
