@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int BN_CH = 64;         // channels per workgroup of the statistics kernels (one wave = one pixel x 64 channels)
-constexpr int BN_MAX_SLICES = 64;
+constexpr int BN_MAX_SLICES = 256;
 
 struct BnArgs {
     const float *x, *dy, *y;
@@ -22,53 +22,89 @@ struct BnArgs {
     float *part;
 };
 
-// ---- forward statistics: per channel (n, mean, M2) of a pixel slice, Welford per thread, Chan merge across threads
+// ---- forward statistics: per channel (n, mean, M2) of a pixel slice.  256 threads = 16 pixel lanes x 16 groups of 4 channels
+// (16-byte loads).  Two passes over the slice -- its mean first, then the squared deviations from it (the slice is a few dozen
+// KB, so the second pass is served by L2) -- which is as accurate as Welford's update without a division per element; slices
+// are merged with Chan's formula.
 __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const BnArgs p) {
-    __shared__ float s_mean[4][BN_CH], s_m2[4][BN_CH], s_n[4][BN_CH];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * BN_CH + cl;
+    __shared__ float s_1[16][BN_CH], s_mean[BN_CH];
+    const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * BN_CH + cg * 4;
     const int p0 = blockIdx.y * p.pix_per_slice, p1 = min(p0 + p.pix_per_slice, p.P);
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < p.C)
-        for (int q = p0 + pl; q < p1; q += 4) {
-            const float v = p.x[(long long)q * p.x_ld + c];
-            n += 1.f;
-            const float d = v - mean;
-            mean += d / n;
-            m2 += d * (v - mean);
-        }
-    s_mean[pl][cl] = mean; s_m2[pl][cl] = m2; s_n[pl][cl] = n;
-    __syncthreads();
-    if (pl == 0 && c < p.C) {
-        for (int k = 1; k < 4; ++k) {
-            const float nb = s_n[k][cl];
-            if (nb > 0.f) {
-                const float d = s_mean[k][cl] - mean, nt = n + nb;
-                mean += d * (nb / nt);
-                m2 += s_m2[k][cl] + d * d * (n * nb / nt);
-                n = nt;
+    const float n = (float)(p1 - p0);
+    const bool vec = c + 3 < p.C && (p.x_ld & 3) == 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        floatx4 a = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
+        if (pass == 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = s_mean[cg * 4 + e];
+        if (c < p.C) {
+            if (vec) {
+                for (int q = p0 + pl; q < p1; q += 16) {
+                    const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + (long long)q * p.x_ld + c) - m;
+                    a += pass ? v * v : v;
+                }
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < p.C)
+                        for (int q = p0 + pl; q < p1; q += 16) {
+                            const float v = p.x[(long long)q * p.x_ld + c + e] - m[e];
+                            a[e] += pass ? v * v : v;
+                        }
             }
         }
-        float *o = p.part + ((long long)blockIdx.y * p.C + c) * 3;
-        o[0] = n; o[1] = mean; o[2] = m2;
+        __syncthreads();                                   // (pass 1: everybody has read s_mean / finished with s_1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_1[pl][cg * 4 + e] = a[e];
+        __syncthreads();
+        if (threadIdx.x < BN_CH) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) t += s_1[l][threadIdx.x];
+            const int cc = blockIdx.x * BN_CH + threadIdx.x;
+            if (pass == 0) {
+                s_mean[threadIdx.x] = t / n;
+            } else if (cc < p.C) {
+                float *o = p.part + ((long long)blockIdx.y * p.C + cc) * 3;
+                o[0] = n;
+                o[1] = s_mean[threadIdx.x];
+                o[2] = t;
+            }
+        }
+        __syncthreads();
     }
 }
 
-// one thread per channel: merge the slices in order; mean, 1/sqrt(biased var + eps); running statistics as
-// torch.nn.BatchNorm2d does: running = (1 - momentum) * running + momentum * {mean, UNBIASED var}
+// 64 channels x 4 lanes per workgroup: lane l merges the slices l, l+4, ... in order, lane 0 merges the four; mean,
+// 1/sqrt(biased var + eps); running statistics as torch.nn.BatchNorm2d does: running = (1 - momentum) * running + momentum *
+// {mean, UNBIASED var}
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, int C, int slices, float eps, float momentum,
                                                              float *mean_out, float *invstd_out, float *running_mean,
                                                              float *running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float s_n[4][BN_CH], s_m[4][BN_CH], s_q[4][BN_CH];
+    const int cl = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int c = blockIdx.x * BN_CH + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < slices; ++s) {
-        const float *o = part + ((long long)s * C + c) * 3;
-        const float nb = o[0];
+    if (c < C)
+        for (int s = l; s < slices; s += 4) {
+            const float *o = part + ((long long)s * C + c) * 3;
+            const float nb = o[0];
+            if (nb > 0.f) {
+                const float d = o[1] - mean, nt = n + nb;
+                mean += d * (nb / nt);
+                m2 += o[2] + d * d * (n * nb / nt);
+                n = nt;
+            }
+        }
+    s_n[l][cl] = n; s_m[l][cl] = mean; s_q[l][cl] = m2;
+    __syncthreads();
+    if (l != 0 || c >= C) return;
+    for (int k = 1; k < 4; ++k) {
+        const float nb = s_n[k][cl];
         if (nb > 0.f) {
-            const float d = o[1] - mean, nt = n + nb;
+            const float d = s_m[k][cl] - mean, nt = n + nb;
             mean += d * (nb / nt);
-            m2 += o[2] + d * d * (n * nb / nt);
+            m2 += s_q[k][cl] + d * d * (n * nb / nt);
             n = nt;
         }
     }
@@ -375,7 +411,7 @@ __global__ void __launch_bounds__(256) chan_sum_final_kernel(const float *part, 
 static int slices_for(int P, int C) {
     const int cb = ceil_div(C, BN_CH);
     int sl = ceil_div(1024, cb);                       // ~4 workgroups per CU
-    const int maxsl = P / 64 > 0 ? P / 64 : 1;
+    const int maxsl = P / 128 > 0 ? P / 128 : 1;
     if (sl > maxsl) sl = maxsl;
     if (sl > BN_MAX_SLICES) sl = BN_MAX_SLICES;
     return sl < 1 ? 1 : sl;
@@ -398,7 +434,7 @@ extern "C" int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, fl
     p.slices = ceil_div(P, p.pix_per_slice);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, BN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
                        invstd, running_mean, running_var);
     return ppy_launch_status();
 }

@@ -78,6 +78,8 @@ class TrainStep(object):
         self.seed = 0
         self.acts = None
         self.flops = 0                      # algorithmic convolution FLOPs (2 * MAC) of the last forward + backward
+        from .engine import tuned_table
+        self._tuned = tuned_table('bf16x3')
 
     # ---- constants / buffers -------------------------------------------------------------------------------------
     def _vec(self, name, n, val):
@@ -164,8 +166,11 @@ class TrainStep(object):
         bias = sd.get(prefix + '.conv.bias')
         has_bn = prefix + '.bn.weight' in sd
         raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
+        # tile configuration: the measured bf16x3 table of the inference path knows most of these layer shapes
+        tuned = self._tuned.get('conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride))
+        cfg_id, splitk = (tuned[0], tuned[1]) if tuned else (-1, 0)
         K.conv2d_bn_act(xin.view(), krsc, self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0),
-                        raw.view(), stride, pad, None, ws=self.ws, w_x3=ent['planes'])
+                        raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws, w_x3=ent['planes'])
         self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
         if not has_bn:
             y = raw
