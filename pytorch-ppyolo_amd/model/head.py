@@ -185,4 +185,5 @@ class YOLOv3Head(torch.nn.Module):
                     iou_aware_factor=self.iou_aware_factor, clip_bbox=self.clip_bbox, M_total=M, nms=nms)
 
     def get_loss(self, *a, **k):
-        raise NotImplementedError('training (YOLOv3Loss) is outside the inference hot path -- SURVEY.md 8(f)')
+        raise NotImplementedError('the training step does not run through autograd here: the loss (forward AND backward, one HIP kernel per '
+                                  'level) is part of ppyolo_hip.train.TrainStep.step(images, gt_box, targets, lr) -- INTEGRATION.md section 4')

@@ -19,7 +19,9 @@ class PPYOLO(torch.nn.Module):
 
     def forward(self, x, im_size, eval=True, gt_box=None, gt_label=None, gt_score=None, targets=None):
         if not eval:
-            raise NotImplementedError('training forward (get_loss) is outside the inference hot path')
+            raise NotImplementedError('forward(eval=False) returns autograd losses in the reference; here the whole training step (forward, '
+                                      'YOLOv3Loss, backward, SGD) is ppyolo_hip.train.TrainStep(model, cfg).step(images, gt_box, targets, lr) -- '
+                                      'INTEGRATION.md section 4')
         ex = self._plans.executor(x)
         ex.set_inputs(x, im_size)
         ex.run()
