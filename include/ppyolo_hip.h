@@ -174,6 +174,10 @@ int ppy_dropblock_apply_f32(const float *x, int x_ld, const float *mask, const f
                             int C, void *stream);
 int ppy_sgd_momentum_f32(float *param, const float *grad, float *velocity, long long n, float lr, float momentum,
                          float weight_decay, int first_step, void *stream);
+/* ExponentialMovingAverage.update of the reference (model/EMA.py:29-44; train.py:443-444), on the device instead of a numpy
+ * round trip per step: shadow = decay * shadow + (1 - decay) * param in float32 with separate roundings (numpy's arithmetic);
+ * the caller computes decay = min(ema_decay, (1 + t) / (10 + t)) and passes float32(decay), float32(1 - decay). */
+int ppy_ema_update_f32(float *shadow, const float *param, long long n, float decay, float one_minus_decay, void *stream);
 /* Plumbing of the training graph: dst += src (second gradient of a tensor with two consumers); the nearest x2 upsample
  * forward (model/head.py:396-397; the inference path fuses it into the producing convolution's store, which BatchNorm on
  * batch statistics rules out); per-channel sum over the pixels = gradient of a convolution bias

@@ -210,3 +210,11 @@ def train_step(sd, cfg, x, gt_box, targets, rng_seed=None):
     grads = {k: v.grad for k, v in state.items() if v.requires_grad}
     return dict(losses=losses, all_loss=all_loss, outs=outs, douts=[o.grad for o in outs], grads=grads,
                 state={k: v.detach() for k, v in state.items()})
+
+
+def ema_update(shadow, param, step, ema_decay=0.9998):
+    """ExponentialMovingAverage.update for one tensor -- reference model/EMA.py:29-44: decay warms up as (1+t)/(10+t);
+    numpy evaluates `decay * old + (1 - decay) * new` in float32 (the Python floats are weak scalars)."""
+    decay = min(ema_decay, (1 + step) / (10 + step))
+    old, new = np.asarray(shadow, dtype=np.float32), np.asarray(param, dtype=np.float32)
+    return decay * old + (1 - decay) * new, decay

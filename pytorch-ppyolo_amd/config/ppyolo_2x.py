@@ -43,6 +43,8 @@ class PPYOLO_2x_Config(object):
         self.iou_loss = dict(loss_weight=2.5, max_height=608, max_width=608, ciou_term=False)
         self.iou_aware_loss_type = 'IouAwareLoss'
         self.iou_aware_loss = dict(loss_weight=1.0, max_height=608, max_width=608)
+        self.use_ema = True            # reference config: lines 92-94
+        self.ema_decay = 0.9998
         self.yolo_loss_type = 'YOLOv3Loss'
         self.yolo_loss = dict(ignore_thresh=0.7, scale_x_y=1.05, label_smooth=False, use_fine_grained_loss=True)
         self.learningRate = dict(base_lr=0.0001, PiecewiseDecay=dict(gamma=0.1, milestones=[400000, 450000]),

@@ -55,6 +55,7 @@ _PROTOS = {
                                         c_void_p]),
     'ppy_dropblock_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),
     'ppy_sgd_momentum_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_int, c_void_p]),
+    'ppy_ema_update_f32': (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_float, c_void_p]),
     'ppy_add_inplace_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_void_p]),
     'ppy_upsample2x_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ppy_channel_sum_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

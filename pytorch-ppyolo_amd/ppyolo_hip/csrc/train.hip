@@ -408,6 +408,14 @@ __global__ void __launch_bounds__(256) chan_sum_final_kernel(const float *part, 
     out[c] = a;
 }
 
+// ---- ExponentialMovingAverage of the trainable parameters (reference model/EMA.py:29-44): numpy's float32 arithmetic,
+// shadow = decay * shadow + (1 - decay) * param with three separate roundings (no fused multiply-add)
+__global__ void __launch_bounds__(256) ema_kernel(float *shadow, const float *param, long long n, float decay, float one_minus) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    shadow[i] = __fadd_rn(__fmul_rn(decay, shadow[i]), __fmul_rn(one_minus, param[i]));
+}
+
 static int slices_for(int P, int C) {
     const int cb = ceil_div(C, BN_CH);
     int sl = ceil_div(1024, cb);                       // ~4 workgroups per CU
@@ -568,5 +576,12 @@ extern "C" int ppy_channel_sum_f32(const float *dy, int dy_ld, int P, int C, flo
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_sum_partial_kernel, dim3(ceil_div(C, BN_CH), sl), dim3(256), 0, st, dy, dy_ld, P, C, pps, (float *)ws);
     hipLaunchKernelGGL(chan_sum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, sl, out);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_ema_update_f32(float *shadow, const float *param, long long n, float decay, float one_minus_decay, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(shadow && param && n > 0);
+    hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, shadow, param, n, decay, one_minus_decay);
     return ppy_launch_status();
 }

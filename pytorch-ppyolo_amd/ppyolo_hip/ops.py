@@ -248,6 +248,17 @@ def sgd_momentum(param, grad, velocity, lr, momentum, weight_decay, first_step):
                                      float(weight_decay), int(bool(first_step)), _stream()), 'ppy_sgd_momentum_f32')
 
 
+def ema_update(shadow, param, step, ema_decay):
+    """One ExponentialMovingAverage.update (reference model/EMA.py:29-44) over flat fp32 tensors; returns the decay used."""
+    import numpy as np
+    _dev(shadow, param)
+    assert shadow.is_contiguous() and param.is_contiguous() and shadow.numel() == param.numel()
+    decay = min(ema_decay, (1 + step) / (10 + step))
+    check(lib().ppy_ema_update_f32(shadow.data_ptr(), param.data_ptr(), param.numel(), float(np.float32(decay)),
+                                   float(np.float32(1 - decay)), _stream()), 'ppy_ema_update_f32')
+    return decay
+
+
 def add_inplace(dst, src):
     _dev(dst.t, src.t)
     assert dst.C == src.C

@@ -73,7 +73,10 @@ class TrainStep(object):
         self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
         self.weight_decay = cfg.optimizerBuilder['regularizer']['factor']
         self.gflat = None
-        self.G, self.V = {}, {}
+        self.G, self.V, self.P = {}, {}, {}
+        self.use_ema = bool(getattr(cfg, 'use_ema', True))          # reference config/ppyolo_2x.py:92-94
+        self.ema_decay = float(getattr(cfg, 'ema_decay', 0.9998))
+        self.ema_steps = 0
         self.masks = None
         self.seed = 0
         self.acts = None
@@ -111,23 +114,39 @@ class TrainStep(object):
             ent['planes'] = K.split_weights_bf16x3(ent['krsc'])
         return ent
 
-    def _alloc_grads(self):
-        """All gradients in ONE flat buffer (a single all-reduce serves every tensor), views per parameter in kernel layout."""
-        shapes = {}
-        for k in self.train_keys:
-            shapes[k] = tuple(self._wcache[k]['krsc'].shape) if k in self._wcache else tuple(self.sd[k].shape)
+    def _alloc_flat(self):
+        """Parameters, gradients, velocities and EMA shadows of ALL trainable tensors in flat buffers, in kernel layout:
+        convolution weights first (the weight-decay group), then biases and BatchNorm scales / offsets -- so that SGD is two
+        launches, the EMA one, and data-parallel ranks average every gradient with ONE all-reduce.  The kernels read the
+        parameters through views into `pflat` from now on; sync_to_model() writes them back into the module."""
+        convs = [k for k in self.train_keys if k in self._wcache]
+        rest = [k for k in self.train_keys if k not in self._wcache]
         offs, total = {}, 0
-        for k, shp in shapes.items():
+        for k in convs + rest:
+            shp = tuple(self._wcache[k]['krsc'].shape) if k in self._wcache else tuple(self.sd[k].shape)
             n = 1
             for d in shp:
                 n *= d
             offs[k] = (total, n, shp)
             total += (n + 63) // 64 * 64
-        self.gflat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-        self.vflat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            if k == convs[-1]:
+                self.n_decay = total                       # [0, n_decay): weight decay applies
+        z = lambda: torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.gflat, self.vflat, self.pflat = z(), z(), z()
         for k, (o, n, shp) in offs.items():
             self.G[k] = self.gflat[o:o + n].view(shp)
             self.V[k] = self.vflat[o:o + n].view(shp)
+            self.P[k] = self.pflat[o:o + n].view(shp)
+            if k in self._wcache:
+                self.P[k].copy_(self._wcache[k]['krsc'])
+                self._wcache[k]['krsc'] = self.P[k]
+            else:
+                self.P[k].copy_(self.sd[k])
+        self.sflat = self.pflat.clone() if self.use_ema else None        # EMA.register(): shadow = parameters
+
+    def param(self, key):
+        """A bias / BatchNorm scale or offset as the kernels should read it: the flat master copy once it exists."""
+        return self.P[key] if key in self.P else self.sd.get(key)
 
     # ---- forward ops ---------------------------------------------------------------------------------------------------
     def coord_concat(self, x):
@@ -163,7 +182,7 @@ class TrainStep(object):
             raise PPYoloHipError('%s: input has %d channels, the weight %d' % (prefix, xin.C, Cp))
         pad = (R - 1) // 2
         Ho, Wo = K.conv_out_hw(xin.H, xin.W, R, S, stride, pad)
-        bias = sd.get(prefix + '.conv.bias')
+        bias = self.param(prefix + '.conv.bias')
         has_bn = prefix + '.bn.weight' in sd
         raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
         # tile configuration: the measured bf16x3 table of the inference path knows most of these layer shapes
@@ -182,7 +201,7 @@ class TrainStep(object):
             sd[prefix + '.bn.num_batches_tracked'] += 1
             y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
             y.req = trainable
-            K.bn_train_apply(raw.view(), mean, invstd, sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'], y.view(), act,
+            K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
                              None if res is None else res.view())
         if trainable:
             self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent))
@@ -197,7 +216,7 @@ class TrainStep(object):
         sd = self.sd
         if mean is not None:
             d_raw = self.new(raw.N, raw.H, raw.W, raw.C)
-            K.bn_train_bwd(raw.view(), y.view(), dy.view(), mean, invstd, sd[prefix + '.bn.weight'], d_raw.view(),
+            K.bn_train_bwd(raw.view(), y.view(), dy.view(), mean, invstd, self.param(prefix + '.bn.weight'), d_raw.view(),
                            self.G[prefix + '.bn.weight'], self.G[prefix + '.bn.bias'], act, self.ws)
         else:
             d_raw = dy
@@ -409,7 +428,7 @@ class TrainStep(object):
         with torch.no_grad():
             outs = self.head(feats)
             if self.gflat is None:
-                self._alloc_grads()
+                self._alloc_flat()
             loss6 = torch.zeros(6, dtype=torch.float32, device=self.dev)
             iou_aware = bool(hcfg.get('iou_aware', False))
             for i, out in enumerate(outs):
@@ -436,13 +455,18 @@ class TrainStep(object):
             self.gflat.mul_(1.0 / self.world)
 
     def sgd(self, lr):
-        """optimizer.step() of train.py:442 with the reference's parameter groups."""
+        """optimizer.step() of train.py:442 with the reference's parameter groups (custom_layers.py:167-215: weight decay on
+        convolution weights, none on biases and BatchNorm scales / offsets; every head layer has lr multiplier 1), then
+        ema.update() (train.py:443-444, model/EMA.py:29-44)."""
         first = self.steps_done == 0
-        for k in self.train_keys:
-            p = self._wcache[k]['krsc'] if k in self._wcache else self.sd[k]
-            wd = self.weight_decay if k.endswith('conv.weight') else 0.0
-            K.sgd_momentum(p.view(-1), self.G[k].view(-1), self.V[k].view(-1), lr, self.momentum, wd, first)
+        nd, n = self.n_decay, self.pflat.numel()
+        K.sgd_momentum(self.pflat[:nd], self.gflat[:nd], self.vflat[:nd], lr, self.momentum, self.weight_decay, first)
+        if n > nd:
+            K.sgd_momentum(self.pflat[nd:], self.gflat[nd:], self.vflat[nd:], lr, self.momentum, 0.0, first)
         self.steps_done += 1
+        if self.use_ema:
+            K.ema_update(self.sflat, self.pflat, self.ema_steps, self.ema_decay)
+            self.ema_steps += 1
 
     def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None):
         loss6 = self.forward_backward(x_nchw, gt_box, targets, dropblock_masks)
@@ -461,12 +485,22 @@ class TrainStep(object):
             out[k] = g.clone()
         return out
 
-    def sync_to_model(self):
-        """Write the trained convolution weights (kept in kernel layout during training) back into the module."""
-        for k in self.train_keys:
-            if k in self._wcache:
-                ent = self._wcache[k]
-                self.sd[k].copy_(ent['krsc'][..., :ent['Cin']].permute(0, 3, 1, 2))
+    def sync_to_model(self, ema=False):
+        """Write the trained parameters (kept flat, in kernel layout, during training) back into the module; `ema=True` writes
+        the EMA shadows instead -- what the reference evaluates and saves after ema.apply() (train.py:476-500)."""
+        src = self.sflat if ema else self.pflat
+        if ema and src is None:
+            raise PPYoloHipError('EMA is off (cfg.use_ema)')
+        if self.gflat is not None:
+            base = self.pflat.data_ptr()
+            for k in self.train_keys:
+                v = self.P[k]
+                o = (v.data_ptr() - base) // 4
+                t = src[o:o + v.numel()].view(v.shape)
+                if k in self._wcache:
+                    self.sd[k].copy_(t[..., :self._wcache[k]['Cin']].permute(0, 3, 1, 2))
+                else:
+                    self.sd[k].copy_(t)
         if hasattr(self.model, '_plans'):
             self.model._plans.clear()
 

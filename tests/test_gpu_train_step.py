@@ -185,3 +185,41 @@ def test_sgd_step_changes_the_model_and_loss_goes_down():
     model.head.set_dropblock(is_test=True)
     out = model(x, synth.synth_im_size(N).cuda())
     assert len(out) == N
+
+
+def test_sgd_groups_and_ema_semantics():
+    """optimizer.step() + ema.update() of reference train.py:442-444: weight decay on convolution weights only
+    (custom_layers.py:167-215), momentum buffers start as the first gradient, EMA decay warms up as (1+t)/(10+t)."""
+    from ppyolo_hip.train import TrainStep
+    cfg = PPYOLO_r18vd_Config()
+    N, S, lr = 2, 128, 0.01
+    model, sd = build_model(cfg, 0, 'cuda')
+    x = synth.synth_images(N, S, seed=3).cuda()
+    gt, targets = synth_targets(cfg, N, S, 9)
+    gt, targets = gt.cuda(), [t.cuda() for t in targets]
+    ts = TrainStep(model, cfg)
+    wd, mu = cfg.optimizerBuilder['regularizer']['factor'], cfg.optimizerBuilder['optimizer']['momentum']
+    keys = ['head.yolo_output_convs.1.conv.weight', 'head.yolo_output_convs.1.conv.bias', 'head.detection_blocks.0.layers.2.bn.weight',
+            'head.detection_blocks.1.tip_layers.1.conv.weight']
+    p = {k: sd[k].clone() for k in keys}
+    v = {}
+    shadow = {k: sd[k].clone().numpy() for k in keys}
+    for step in range(3):
+        ts.forward_backward(x, gt, targets)
+        g = {k: t.cpu() for k, t in ts.grads().items() if k in keys}
+        ts.sgd(lr)
+        ts.sync_to_model()
+        now = {k: model.state_dict()[k].cpu() for k in keys}
+        for k in keys:
+            d = g[k] + (wd if k.endswith('conv.weight') else 0.0) * p[k]
+            v[k] = d if step == 0 else mu * v[k] + d
+            p[k] = p[k] - lr * v[k]
+            assert relmax(now[k], p[k]) <= 2e-6, (step, k, relmax(now[k], p[k]))
+            shadow[k], decay = trn.ema_update(shadow[k], now[k].numpy(), step, cfg.ema_decay if hasattr(cfg, 'ema_decay') else 0.9998)
+            p[k] = now[k]                      # follow the device values: the comparison is per step
+        assert abs(decay - (1 + step) / (10 + step)) < 1e-12
+    ts.sync_to_model(ema=True)
+    for k in keys:
+        assert relmax(model.state_dict()[k].cpu(), torch.from_numpy(shadow[k])) <= 2e-6, k
+    ts.sync_to_model()
+    assert relmax(model.state_dict()[keys[0]].cpu(), p[keys[0]]) <= 1e-7

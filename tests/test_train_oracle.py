@@ -80,3 +80,14 @@ def test_loss_pieces_have_the_documented_shape_quirks():
     cx = (1.05 * torch.sigmoid(o[0, a, 0, hh, ww]) + ww - 0.025) * 8
     bw = torch.exp(o[0, a, 2, hh, ww]) * anchors[2 * a]
     assert torch.allclose(b[0, (a * S + hh) * S + ww, 0], (cx - bw / 2) / S / 8)
+
+
+def test_ema_matches_reference(golden):
+    """ExponentialMovingAverage (reference model/EMA.py) through four updates: golden g13 from the reference's own class."""
+    g = golden('g13_ema')
+    sa, sb = g['a0'], g['b0']
+    for t in range(4):
+        sa, d = trn.ema_update(sa, g['a_param%d' % t], t)
+        sb, _ = trn.ema_update(sb, g['b_param%d' % t], t)
+        assert d == g['decays'][t]
+        assert sa.dtype == np.float32 and np.array_equal(sa, g['a_shadow%d' % t]) and np.array_equal(sb, g['b_shadow%d' % t])

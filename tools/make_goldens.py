@@ -560,8 +560,35 @@ def g12_train_step():
         save('g12_train_' + tag, **arrs)
 
 
+def g13_ema():
+    """ExponentialMovingAverage of the trainable parameters (reference model/EMA.py:16-44; train.py:283-286, :443-444): the
+    reference's own class on a small module through four updates -- the warm-up of the decay, min(0.9998, (1+t)/(10+t)), and
+    numpy's float32 arithmetic of `decay * old + (1 - decay) * new`."""
+    from model.EMA import ExponentialMovingAverage
+    g = gen(5)
+    m = torch.nn.Module()
+    m.a = torch.nn.Parameter(torch.randn(7, 5, generator=g))
+    m.b = torch.nn.Parameter(torch.randn(11, generator=g) * 1e-3)
+    m.frozen = torch.nn.Parameter(torch.randn(3, generator=g), requires_grad=False)
+    ema = ExponentialMovingAverage(m, 0.9998)
+    ema.register()
+    arrs = dict(a0=m.a.detach().clone(), b0=m.b.detach().clone())
+    decays = []
+    for t in range(4):
+        with torch.no_grad():
+            m.a.add_(torch.randn(7, 5, generator=g) * 0.1)
+            m.b.mul_(1.5)
+            m.frozen.add_(1.0)
+        decays.append(ema.update())
+        arrs['a_param%d' % t], arrs['b_param%d' % t] = m.a.detach().clone(), m.b.detach().clone()
+        arrs['a_shadow%d' % t], arrs['b_shadow%d' % t] = ema._shadow['a'].copy(), ema._shadow['b'].copy()
+        assert ema._shadow['a'].dtype == np.float32 and 'frozen' not in ema._shadow
+    arrs['decays'] = np.array(decays, dtype=np.float64)
+    save('g13_ema', **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
