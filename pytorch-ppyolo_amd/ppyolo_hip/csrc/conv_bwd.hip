@@ -15,6 +15,8 @@
 //           the slices are combined in a fixed order by a second kernel (deterministic, no atomics).  Exact fp32.
 #include "conv_shared.h"
 
+#include <cstdlib>
+
 namespace {
 
 // w[K][R][S][C] -> wt[C][R][S][Kp] with both taps flipped and zero rows for k in [K, Kp); also ones[C], zeros[C]
@@ -144,6 +146,140 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #endif
 }
 
+// ---- wgrad on the 16-bit MFMA: exact 3-term bf16 split of both operands, the 6 leading products (as conv_x3.hip's bf16x3).
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE reduction indices per lane, and the reduction index here is the pixel, which
+// is the strided one in NHWC -- so a step of 32 pixels goes through LDS transposed: every thread loads 4 pixels x 4 channels
+// of dy and of x (16-byte loads, the padding taps of x as zeros), splits the 32 values once (not once per consuming wave) and
+// stores [plane][channel][pixel] bf16 with 8-byte LDS writes; a fragment is then one 16-byte LDS read per plane
+// (row pitch 80 B: conflict-free for the 16-lane groups of ds_read_b128).  One LDS buffer, two barriers per step; two
+// workgroups per CU overlap each other's store / MFMA phases.  Tile 128 (k) x 128 (c) of one tap over a pixel slice.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned uintx4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned uintx2_t;
+constexpr int X3_PIX = 32;                 // pixels per step
+constexpr int X3_PITCH = 80;               // bytes per channel row: 32 pixels x 2 B + 16 B
+constexpr int X3_TILE = 3 * 128 * X3_PITCH;        // one operand: 3 planes x 128 channels
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // RNE, a -> low half
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float floatx2_t;
+    const floatx2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// 4 pixels of one channel -> its three bf16 terms, each as 4 x bf16 = 8 bytes
+__device__ __forceinline__ void split4(const float (&v)[4], uintx2_t (&out)[3]) {
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const unsigned lo = pack_bf16(r[0], r[1]), hi = pack_bf16(r[2], r[3]);
+        out[t] = uintx2_t{lo, hi};
+        r[0] -= __uint_as_float(lo << 16);
+        r[1] -= __uint_as_float(lo & 0xffff0000u);
+        r[2] -= __uint_as_float(hi << 16);
+        r[3] -= __uint_as_float(hi & 0xffff0000u);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char smem[2 * X3_TILE];
+    char *sA = smem, *sB = smem + X3_TILE;                      // dy (k rows), x (c rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int tile = blockIdx.x;
+    const int tk = tile / p.tiles_c, tc = tile - tk * p.tiles_c;
+    const int tap = blockIdx.y, r = tap / p.S, s = tap - r * p.S;
+    const int k0 = tk * WG_TK, c0 = tc * WG_TC;
+    const int p_begin = blockIdx.z * p.pix_per_slice;
+    const int p_end = min(p_begin + p.pix_per_slice, p.P);
+    // loader role: pixel quad pq (4 pixels), channel group cg (4 channels)
+    const int pq = tid & 7, cg = tid >> 3;
+    const int hw = p.Ho * p.Wo;
+    const bool a_ok = k0 + cg * 4 < p.K, b_ok = c0 + cg * 4 < p.C;          // (whole float4 groups: K, C are multiples of 4 or the
+                                                                            //  buffers are zero beyond them up to a multiple of 4)
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    floatx4 ra[4], rb[4];
+    auto fetch = [&](int pbase) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pix = pbase + pq * 4 + q;
+            ra[q] = rb[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (pix < p_end) {
+                if (a_ok) ra[q] = *reinterpret_cast<const floatx4 *>(p.dy + (long long)pix * p.dy_ld + k0 + cg * 4);
+                const int n = pix / hw, rem = pix - n * hw;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int hi = ho * p.stride + r - p.pad, wi = wo * p.stride + s - p.pad;
+                if (b_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    rb[q] = *reinterpret_cast<const floatx4 *>(p.x + (((long long)n * p.H + hi) * p.W + wi) * p.x_ld + c0 + cg * 4);
+            }
+        }
+    };
+    auto stage = [&]() {        // registers -> three bf16 planes, transposed: [plane][channel][pixel]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float va[4] = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]}, vb[4] = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
+            uintx2_t ta[3], tb[3];
+            split4(va, ta);
+            split4(vb, tb);
+            const int row = cg * 4 + e;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                *reinterpret_cast<uintx2_t *>(sA + (t * 128 + row) * X3_PITCH + pq * 8) = ta[t];
+                *reinterpret_cast<uintx2_t *>(sB + (t * 128 + row) * X3_PITCH + pq * 8) = tb[t];
+            }
+        }
+    };
+    const int frow = lane & 31, fh = lane >> 5;
+    fetch(p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += X3_PIX) {
+        __syncthreads();                        // everybody has finished reading the previous step
+        stage();
+        __syncthreads();
+        fetch(p0 + X3_PIX);                     // next step's global loads fly under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uintx4_t fa[2][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    fa[i][t] = *reinterpret_cast<const uintx4_t *>(sA + (t * 128 + wk * 64 + i * 32 + frow) * X3_PITCH + ks * 32 + fh * 16);
+                    fb[i][t] = *reinterpret_cast<const uintx4_t *>(sB + (t * 128 + wc * 64 + i * 32 + frow) * X3_PITCH + ks * 32 + fh * 16);
+                }
+            // the six leading products, smallest first
+            constexpr int ta_[6] = {2, 1, 0, 1, 0, 0}, tb_[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i][ta_[t]]),
+                                                                           __builtin_bit_cast(bf16x8_t, fb[j][tb_[t]]), acc[i][j], 0, 0, 0);
+        }
+    }
+    float *out = p.out + (long long)blockIdx.z * p.K * p.R * p.S * p.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + 32 * j + frow;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wk * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (k < p.K && c < p.C) out[(((long long)k * p.R + r) * p.S + s) * p.C + c] = acc[i][j][e];
+            }
+        }
+#endif
+}
+
 // dw[i] = sum over the slices in index order (a fixed summation order: run-to-run identical results)
 __global__ void __launch_bounds__(256) wgrad_combine_kernel(const float *part, float *dw, long long n, int slices) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -267,12 +403,25 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     const int sl = wgrad_slices(K, C, R, S, p.P);
     const size_t need = sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
     if (need && (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0)) return PPY_ERR_WORKSPACE;
-    p.pix_per_slice = ceil_div(ceil_div(p.P, sl), PIX) * PIX;
+    // the bf16x3 kernel reads whole float4 channel groups: pixel strides and base pointers 16-byte aligned, and the last group
+    // of a tensor whose channel count is not a multiple of 4 must be readable up to the multiple (what lies there only
+    // reaches output rows / columns that are not stored) -- true for this library's own buffers (pixel stride = channels
+    // rounded up to 32); PPY_WGRAD_FP32=1 forces the exact-fp32 kernel
+    static const bool force_fp32 = getenv("PPY_WGRAD_FP32") && getenv("PPY_WGRAD_FP32")[0] == '1';
+    const bool x3 = !force_fp32 && x_ld % 4 == 0 && dy_ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
+                    (C % 4 == 0 || x_ld >= (C + 3) / 4 * 4) && (K % 4 == 0 || dy_ld >= (K + 3) / 4 * 4);
+    const int gran = x3 ? X3_PIX : PIX;
+    p.pix_per_slice = ceil_div(ceil_div(p.P, sl), gran) * gran;
     const int slices = ceil_div(p.P, p.pix_per_slice);
     p.tiles_c = ceil_div(C, WG_TC);
     p.out = slices > 1 ? (float *)ws : dw_krsc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(ceil_div(K, WG_TK) * p.tiles_c, R * S, slices), dim3(256), 0, st, p);
+    const dim3 grid(ceil_div(K, WG_TK) * p.tiles_c, R * S, slices);
+    if (x3) {
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+    }
     int rc = ppy_launch_status();
     if (rc != PPY_OK) return rc;
     if (slices > 1) {
