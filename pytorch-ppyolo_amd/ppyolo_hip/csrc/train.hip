@@ -75,39 +75,41 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const BnArgs p) {
     }
 }
 
-// 64 channels x 4 lanes per workgroup: lane l merges the slices l, l+4, ... in order, lane 0 merges the four; mean,
-// 1/sqrt(biased var + eps); running statistics as torch.nn.BatchNorm2d does: running = (1 - momentum) * running + momentum *
-// {mean, UNBIASED var}
+// Chan's merge of two (n, mean, M2) triples
+__device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, float nb, float mb, float qb) {
+    if (nb > 0.f) {
+        const float d = mb - mean, nt = n + nb;
+        mean += d * (nb / nt);
+        m2 += qb + d * d * (n * nb / nt);
+        n = nt;
+    }
+}
+// 16 channels x 16 lanes per workgroup: lane l merges the slices l, l+16, ... in order, then a 4-level tree over the lanes
+// (fixed order: run-to-run identical); mean, 1/sqrt(biased var + eps); running statistics as torch.nn.BatchNorm2d does:
+// running = (1 - momentum) * running + momentum * {mean, UNBIASED var}
+constexpr int FIN_CH = 16;
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, int C, int slices, float eps, float momentum,
                                                              float *mean_out, float *invstd_out, float *running_mean,
                                                              float *running_var) {
-    __shared__ float s_n[4][BN_CH], s_m[4][BN_CH], s_q[4][BN_CH];
-    const int cl = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int c = blockIdx.x * BN_CH + cl;
+    __shared__ float s_n[16][FIN_CH], s_m[16][FIN_CH], s_q[16][FIN_CH];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * FIN_CH + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C)
-        for (int s = l; s < slices; s += 4) {
+        for (int s = l; s < slices; s += 16) {
             const float *o = part + ((long long)s * C + c) * 3;
-            const float nb = o[0];
-            if (nb > 0.f) {
-                const float d = o[1] - mean, nt = n + nb;
-                mean += d * (nb / nt);
-                m2 += o[2] + d * d * (n * nb / nt);
-                n = nt;
-            }
+            chan_merge(n, mean, m2, o[0], o[1], o[2]);
         }
     s_n[l][cl] = n; s_m[l][cl] = mean; s_q[l][cl] = m2;
     __syncthreads();
-    if (l != 0 || c >= C) return;
-    for (int k = 1; k < 4; ++k) {
-        const float nb = s_n[k][cl];
-        if (nb > 0.f) {
-            const float d = s_m[k][cl] - mean, nt = n + nb;
-            mean += d * (nb / nt);
-            m2 += s_q[k][cl] + d * d * (n * nb / nt);
-            n = nt;
+    for (int w = 8; w > 0; w >>= 1) {
+        if (l < w) {
+            chan_merge(n, mean, m2, s_n[l + w][cl], s_m[l + w][cl], s_q[l + w][cl]);
+            s_n[l][cl] = n; s_m[l][cl] = mean; s_q[l][cl] = m2;
         }
+        __syncthreads();
     }
+    if (l != 0 || c >= C) return;
     const float var = m2 / n;
     mean_out[c] = mean;
     invstd_out[c] = 1.0f / sqrtf(var + eps);
@@ -115,7 +117,8 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, 
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
 }
 
-// ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread
+// ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread, the per-channel
+// parameters as 16-byte loads (L1 / L2 resident)
 __global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p) {
     const int c4 = p.C >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -125,12 +128,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p) {
     const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
     floatx4 r = {0.f, 0.f, 0.f, 0.f};
     if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + q * p.res_ld + c);
+    const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), is = *reinterpret_cast<const floatx4 *>(p.invstd + c);
+    const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), be = *reinterpret_cast<const floatx4 *>(p.beta + c);
     floatx4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float a = p.invstd[c + k] * p.gamma[c + k];
-        o[k] = ppy_apply_act((v[k] - p.mean[c + k]) * a + p.beta[c + k] + r[k], p.act);
-    }
+    for (int k = 0; k < 4; ++k) o[k] = ppy_apply_act((v[k] - mu[k]) * (is[k] * ga[k]) + be[k] + r[k], p.act);
     *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
 }
 
@@ -165,15 +167,28 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs p) {
     }
 }
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float *part, int C, int slices, float *dbeta, float *dgamma) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float s_a[16][FIN_CH], s_b[16][FIN_CH];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * FIN_CH + cl;
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < slices; ++s) {
-        a += part[((long long)s * C + c) * 2];
-        b += part[((long long)s * C + c) * 2 + 1];
+    if (c < C)
+        for (int s = l; s < slices; s += 16) {
+            a += part[((long long)s * C + c) * 2];
+            b += part[((long long)s * C + c) * 2 + 1];
+        }
+    s_a[l][cl] = a; s_b[l][cl] = b;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (l < w) {
+            s_a[l][cl] += s_a[l + w][cl];
+            s_b[l][cl] += s_b[l + w][cl];
+        }
+        __syncthreads();
     }
-    dbeta[c] = a;
-    dgamma[c] = b;
+    if (l == 0 && c < C) {
+        dbeta[c] = s_a[0][cl];
+        dgamma[c] = s_b[0][cl];
+    }
 }
 // dx = gamma * invstd * (dz - (sum_dz + xhat * sum_dzx) / P)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p) {
@@ -186,12 +201,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p) {
     const floatx4 dy = *reinterpret_cast<const floatx4 *>(p.dy + q * p.dy_ld + c);
     const floatx4 y = *reinterpret_cast<const floatx4 *>(p.y + q * p.y_ld + c);
     const float invP = 1.0f / (float)p.P;
+    const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), isv = *reinterpret_cast<const floatx4 *>(p.invstd + c);
+    const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), sa = *reinterpret_cast<const floatx4 *>(p.sum_dz + c);
+    const floatx4 sb = *reinterpret_cast<const floatx4 *>(p.sum_dzx + c);
     floatx4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float is = p.invstd[c + k], xh = (x[k] - p.mean[c + k]) * is;
+        const float xh = (x[k] - mu[k]) * isv[k];
         const float dz = dy[k] * act_grad(y[k], p.act);
-        o[k] = p.gamma[c + k] * is * (dz - (p.sum_dz[c + k] + xh * p.sum_dzx[c + k]) * invP);
+        o[k] = ga[k] * isv[k] * (dz - (sa[k] + xh * sb[k]) * invP);
     }
     *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
 }
@@ -442,7 +460,7 @@ extern "C" int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, fl
     p.slices = ceil_div(P, p.pix_per_slice);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, BN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
                        invstd, running_mean, running_var);
     return ppy_launch_status();
 }
@@ -453,6 +471,7 @@ extern "C" int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mea
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && mean && invstd && gamma && beta && y && P > 0 && C > 0 && C % 4 == 0 && x_ld >= C && y_ld >= C);
     PPY_CHECK_ARG(x_ld % 4 == 0 && y_ld % 4 == 0 && (!residual || (res_ld >= C && res_ld % 4 == 0)));
+    PPY_CHECK_ARG((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);      // 16-byte parameter loads
     BnArgs p = {};
     p.x = x; p.x_ld = x_ld; p.out = y; p.out_ld = y_ld; p.P = P; p.C = C; p.act = act;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.res = residual; p.res_ld = res_ld;
@@ -466,6 +485,7 @@ extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, in
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && y && dy && mean && invstd && gamma && dx && dgamma && dbeta && P > 0 && C > 0 && C % 4 == 0);
     PPY_CHECK_ARG(x_ld >= C && y_ld >= C && dy_ld >= C && dx_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0);
+    PPY_CHECK_ARG((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0);
     if (!ws || ws_bytes < ppy_bn_train_workspace_bytes(P, C)) return PPY_ERR_WORKSPACE;
     BnArgs p = {};
     p.x = x; p.x_ld = x_ld; p.y = y; p.y_ld = y_ld; p.dy = dy; p.dy_ld = dy_ld; p.out = dx; p.out_ld = dx_ld;
@@ -476,7 +496,7 @@ extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, in
     p.sum_dz = dbeta; p.sum_dzx = dgamma;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((long long)P * (C / 4))), dim3(256), 0, st, p);
     return ppy_launch_status();
 }
