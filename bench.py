@@ -116,8 +116,14 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
     ideal_s = 0.0
     fam_flops = {'fp32': 0, 'bf16x3': 0, 'f16x2': 0}
     for i in convs:
-        cfg = ex.plan.ops[i]['cfg']
-        fam = 'fp32' if cfg < NUM_FP32_CFGS else ('bf16x3' if cfg < NUM_FP32_CFGS + NUM_X3_CFGS else 'f16x2')
+        op = ex.plan.ops[i]
+        cfg = op['cfg']
+        if op['op'] == 'dcn':      # ids of the fused DCNv2 kernel: scheme * tiles + tile; < 0 = the library picks by operands
+            from ppyolo_hip import ops as K
+            fam = (('fp32', 'bf16x3', 'f16x2')[cfg // (K.dcnv2_num_configs() // 3)] if cfg >= 0 else
+                   ('f16x2' if op.get('wf16') is not None else ('bf16x3' if op.get('w3') is not None else 'fp32')))
+        else:
+            fam = 'fp32' if cfg < NUM_FP32_CFGS else ('bf16x3' if cfg < NUM_FP32_CFGS + NUM_X3_CFGS else 'f16x2')
         peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16x3': X3_PEAK_TFLOPS, 'f16x2': F16X2_PEAK_TFLOPS}[fam]
         ideal_s += per_op_flops[i] / (peak * 1e12)
         fam_flops[fam] += per_op_flops[i]
@@ -465,6 +471,7 @@ def main():
     ap.add_argument('--no-alt-math', action='store_true', help='skip the side measurement of the other math modes')
     ap.add_argument('--autotune', action='store_true', help='re-measure tile configs instead of using the '
                     'committed tuned_gfx950.json table')
+    ap.add_argument('--tune-kinds', default='conv,dcn', help='with --autotune: plan op kinds to re-measure (conv,dcn)')
     ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
                     'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
     ap.add_argument('--verbose-tune', action='store_true')
@@ -524,7 +531,7 @@ def main():
         e.run()
     torch.cuda.synchronize()
     if a.autotune:
-        ex.autotune(iters=5)
+        ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')))
         if a.co_tune and depth > 1:
             lanes[1][0].use_graph = True
             changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)

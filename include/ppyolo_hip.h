@@ -237,9 +237,14 @@ int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int 
  * external/DCNv2/src/dcn_v2.h:9-23: input, weight, bias-like, offset, mask, kernel,
  * stride, pad).  `offset_mask`: NHWC [N,Ho,Wo,27] RAW output of conv_offset (18
  * (y,x)-interleaved offsets then 9 mask logits; sigmoid is applied here).
- * ppy_dcnv2_sample_f32 writes the modulated bilinear samples ("columns")
- * cols[N*Ho*Wo][9*C] in (tap, c) order; ppy_dcnv2_f32 = sample + MFMA contraction with
- * w [K][3][3][C] + BN affine + activation.  ws must hold N*Ho*Wo*9*C floats (+ split-K). */
+ * ppy_dcnv2_f32 is ONE kernel: every workgroup gathers the modulated bilinear samples of its
+ * output tile into LDS, chunk by chunk, and contracts them on the MFMA with w [K][3][3][C],
+ * then BN affine + activation -- there is no "columns" buffer; ws holds split-K partials only
+ * (ppy_dcnv2_workspace_bytes; 0 without split-K).  cfg: -1 = heuristic, else
+ * math scheme * (ppy_dcnv2_num_configs() / 3) + tile, schemes 0 exact fp32, 1 bf16x3 (needs
+ * w_x3), 2 f16x2 (needs w_f16x2, scale_f16x2, amax_in) -- the operands of the convolution entry
+ * point above.  ppy_dcnv2_sample_f32 is the stand-alone gather: columns
+ * cols[N*Ho*Wo][9*C] in (tap, c) order, the same arithmetic op for op. */
 int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offset_mask, int om_ld,
                          float *cols, int N, int H, int W, int C, int Ho, int Wo, int stride,
                          int pad, void *stream);
@@ -250,6 +255,7 @@ int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x
                   float *amax_out, void *ws, size_t ws_bytes, void *stream);
 size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int cfg,
                                  int splitk);
+int ppy_dcnv2_num_configs(void);
 
 /* ------------------------------------------------------------------------------------
  * get_iou_aware_score + yolo_box for ONE head level (reference model/head.py:21-141),

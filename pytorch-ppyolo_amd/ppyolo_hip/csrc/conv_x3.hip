@@ -47,46 +47,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float floatx2;
-typedef __attribute__((ext_vector_type(4))) unsigned uintx4;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // RNE, a -> low half
-    const floatx2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// halves of a packed pair back to fp32 (scalar bit casts: a vector bit_cast of the packed word was mis-combined
-// across the pairs of a fragment by hipcc -O3 -- every pair subtracted the FIRST pair's value)
-__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
-__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // RNE, a -> low half
-    const floatx2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-// 8 consecutive-k floats of one row -> three bf16x8 MFMA operands (exact 3-term split)
-__device__ __forceinline__ void split8(const floatx4 lo, const floatx4 hi, bf16x8 (&out)[3]) {
-    uintx4 p0, p1, p2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a = q < 2 ? lo[2 * q] : hi[2 * q - 4], b = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
-        const unsigned P0 = cvt_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(P0 << 16), rb = b - __uint_as_float(P0 & 0xffff0000u);
-        const unsigned P1 = cvt_pk_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(P1 << 16), sb = rb - __uint_as_float(P1 & 0xffff0000u);
-        p0[q] = P0;
-        p1[q] = P1;
-        p2[q] = cvt_pk_bf16(sa, sb);
-    }
-    out[0] = __builtin_bit_cast(bf16x8, p0);
-    out[1] = __builtin_bit_cast(bf16x8, p1);
-    out[2] = __builtin_bit_cast(bf16x8, p2);
-}
-
 __global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long long n, unsigned short *out) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
     if (i >= n) return;

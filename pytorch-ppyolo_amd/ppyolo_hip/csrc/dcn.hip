@@ -6,7 +6,9 @@
 // uniform registers), and sweep the C channels of the 4 corner pixels with 16-byte loads
 // (NHWC: a corner pixel's C channels are one contiguous, fully coalesced run).  The blended,
 // mask-modulated samples are written as the (tap, c)-ordered row of the "columns" matrix
-// [N*Ho*Wo][9*C] that the MFMA contraction (conv_igemm.hip, as a 1x1 conv with K=9C) consumes.
+// [N*Ho*Wo][9*C].  The model's forward pass no longer goes through this matrix -- dcn_fused.hip builds the same
+// samples inside the contraction kernel -- this kernel remains as the stand-alone gather (parity of the sampling
+// arithmetic against the reference's own offsets, tests/test_gpu_ops.py; columns for a weight gradient).
 //
 // Arithmetic follows the reference bit-for-bit (no fp contraction in this file):
 //   * coordinates live in a zero-padded frame of size (H+2p+1) x (W+2p+1)   (:571-574)
@@ -97,34 +99,4 @@ extern "C" int ppy_dcnv2_sample_f32(const float *x, int x_ld, const float *offse
     hipLaunchKernelGGL(dcn_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld,
                        offset_mask, om_ld, cols, N, H, W, C, Ho, Wo, stride, pad);
     return ppy_launch_status();
-}
-
-extern "C" size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int cfg,
-                                            int splitk) {
-    if (stride <= 0) return 0;
-    const int Ho = (H + 2 * pad - 2) / stride, Wo = (W + 2 * pad - 2) / stride;
-    if (Ho <= 0 || Wo <= 0) return 0;
-    const size_t cols = (size_t)N * Ho * Wo * 9 * C * sizeof(float);
-    return cols + ppy_conv2d_workspace_bytes(N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, cfg, splitk);
-}
-
-extern "C" int ppy_dcnv2_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3, const void *w_f16x2,
-                             const float *scale, const float *scale_f16x2,
-                             const float *shift, const float *offset_mask, int om_ld, float *y, int y_ld, int N,
-                             int H, int W, int C, int K, int stride, int pad, int act, int cfg, int splitk,
-                             const float *amax_in, float *amax_out, void *ws, size_t ws_bytes, void *stream) {
-    PPY_CHECK_ARG(stride > 0 && C % 32 == 0);
-    const int Ho = (H + 2 * pad - 2) / stride, Wo = (W + 2 * pad - 2) / stride;
-    PPY_CHECK_ARG(Ho > 0 && Wo > 0);
-    const size_t cols_bytes = (size_t)N * Ho * Wo * 9 * C * sizeof(float);
-    if (!ws || ws_bytes < ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
-        return PPY_ERR_WORKSPACE;
-    float *cols = (float *)ws;
-    int rc = ppy_dcnv2_sample_f32(x, x_ld, offset_mask, om_ld, cols, N, H, W, C, Ho, Wo, stride, pad, stream);
-    if (rc != PPY_OK) return rc;
-    // contraction over (tap, c): a 1x1 conv on the columns viewed as NHWC [N,Ho,Wo,9C]
-    // |column| <= max|x| (bilinear weights and the sigmoid mask are <= 1): the input's tracked maximum bounds the columns
-    return ppy_conv2d_bn_act_f32(cols, 9 * C, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, nullptr, 0, nullptr, nullptr, y, y_ld, N, Ho, Wo,
-                                 9 * C, K, 1, 1, 1, 0, act, 0, cfg, splitk, amax_in, amax_out, (char *)ws + cols_bytes,
-                                 ws_bytes - cols_bytes, stream);
 }

@@ -72,7 +72,9 @@ def tune_key(op):
     x = op['x']
     Kout, R, S, C = op['w'].shape
     f16 = op.get('wf16') is not None and op.get('amax_in_id') is not None
-    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s' % (op['op'], x.N, x.H, x.W, C, Kout, R, op['stride'], ':f' if f16 else '')
+    # ('dcnf': ids of the fused DCNv2 kernel, ops.dcnv2_num_configs -- not the convolution's numbering)
+    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s' % ('dcnf' if op['op'] == 'dcn' else op['op'], x.N, x.H, x.W, C, Kout, R,
+                                                 op['stride'], ':f' if f16 else '')
 
 
 def tuned_table(mode=None):
@@ -528,25 +530,26 @@ class HipExecutor(object):
         self._graph_stream = None
 
     # ---- autotune --------------------------------------------------------------------------
-    def autotune(self, iters=3, verbose=False):
+    def autotune(self, iters=3, verbose=False, kinds=('conv', 'dcn')):
         """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
         guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
         from ._lib import lib
-        ncfg = {'fp32': NUM_FP32_CFGS, 'bf16x3': NUM_FP32_CFGS + NUM_X3_CFGS}.get(self.math, lib().ppy_conv2d_num_configs())
+        ncfg_conv = {'fp32': NUM_FP32_CFGS, 'bf16x3': NUM_FP32_CFGS + NUM_X3_CFGS}.get(self.math, lib().ppy_conv2d_num_configs())
+        ncfg_dcn = K.dcnv2_num_configs() // 3 * {'fp32': 1, 'bf16x3': 2}.get(self.math, 3)      # schemes up to this mode's
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
         with torch.cuda.device(self.device):
             big = 0
             for op in self.plan.ops:
                 if op['op'] in ('conv', 'dcn'):
-                    for c in range(ncfg):
+                    for c in range(ncfg_dcn if op['op'] == 'dcn' else ncfg_conv):
                         for s in splits:
                             o = dict(op, cfg=c, splitk=s)
                             big = max(big, self._ws_need(o))
             if self.ws.numel() * 4 < big:
                 self.ws = torch.empty(((big + 3) // 4,), dtype=torch.float32, device=self.device)
             for op in self.plan.ops:
-                if op['op'] not in ('conv', 'dcn'):
+                if op['op'] not in kinds:
                     continue
                 Kout = op['w'].shape[0]
                 Kred = op['w'].shape[1] * op['w'].shape[2] * op['w'].shape[3]
@@ -586,7 +589,7 @@ class HipExecutor(object):
                     return ms
 
                 cands = []
-                for c in range(ncfg):
+                for c in range(ncfg_dcn if op['op'] == 'dcn' else ncfg_conv):
                     for s in splits:
                         if s > 1 and chunks // s < 4:
                             continue

@@ -348,6 +348,11 @@ def dcnv2_sample(x, offset_mask, cols, stride, pad):
                                      x.C, Ho, Wo, stride, pad, _stream()), 'ppy_dcnv2_sample_f32')
 
 
+def dcnv2_num_configs():
+    """ids of the fused DCNv2 kernel: math scheme (0 exact fp32, 1 bf16x3, 2 f16x2) * tiles + tile"""
+    return int(lib().ppy_dcnv2_num_configs())
+
+
 def dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg=-1, splitk=0):
     return int(lib().ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
 

@@ -234,6 +234,57 @@ def test_stem_conv(golden):
 
 
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [
+    # N, H, W, C, K, stride        (stage-5 shapes of R50vd in small, ragged tiles, K % 4 != 0 = scalar epilogue)
+    (2, 19, 19, 64, 128, 1), (3, 13, 11, 96, 72, 2), (1, 9, 9, 32, 33, 1), (2, 20, 20, 128, 256, 2), (8, 19, 19, 64, 64, 1)])
+def test_dcn_fused_matches_the_columns_path(shape):
+    """The fused DCNv2 kernel (csrc/dcn_fused.hip: gather inside the contraction, no columns buffer) against the columns
+    of ppy_dcnv2_sample_f32 -- bit-equal to the reference's gather, test below -- contracted in float64: every math
+    scheme x tile x split-K, offsets up to +-12 px (far outside the image), masks on both sigmoid tails."""
+    from ppyolo_hip import ops
+    N, H, W, C, K, stride = shape
+    g = torch.Generator().manual_seed(N * 1000 + C + K)
+    Ho, Wo = ops.dcn_out_hw(H, W, stride, 1)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    om = torch.randn(N, Ho, Wo, 27, generator=g)
+    om[..., :18] *= 3.0
+    om[0, :, :, :18] *= 4.0                     # image 0: most samples land in the padding
+    om[..., 18:] *= 4.0
+    om = om.cuda()
+    w = (torch.randn(K, 3, 3, C, generator=g) * (1.0 / (9 * C)) ** 0.5).cuda()
+    scale = (torch.rand(K, generator=g) + 0.5).cuda()
+    shift = torch.randn(K, generator=g).cuda()
+    M = N * Ho * Wo
+    cols = torch.empty(M, 9 * C, device='cuda')
+    ops.dcnv2_sample(ops.View(x), ops.View(om), cols, stride, 1)
+    ref = cols.double() @ w.reshape(K, -1).double().t() * scale.double() + shift.double()
+    ref = torch.where(ref > 0, ref, 0.1 * ref).float().view(N, Ho, Wo, K)
+    w3, wf, amax = ops.split_weights_bf16x3(w), ops.split_weights_f16x2(w, scale), ops.amax_slots(x)
+    ncfg = ops.dcnv2_num_configs()
+    assert ncfg % 3 == 0 and ncfg >= 12
+    worst = {}
+    for cfg in list(range(ncfg)) + [-1]:
+        for splitk in (1, 2, 3, 9) if cfg >= 0 else (0,):
+            need = ops.dcnv2_workspace_bytes(N, H, W, C, K, stride, 1, cfg, splitk)
+            assert need <= 9 * M * K * 4         # split-K partials only: no N*Ho*Wo*9*C columns
+            assert splitk > 1 or cfg < 0 or need == 0
+            ws = torch.empty(max(need // 4, 1), device='cuda')
+            y = torch.full((N, Ho, Wo, K), float('nan'), device='cuda')
+            amax_out = ops.amax_slots(device='cuda', N=N)
+            ops.dcnv2(ops.View(x), w, scale, shift, ops.View(om), ops.View(y), stride, 1, 'leaky', ws, cfg=cfg, splitk=splitk,
+                      w_x3=w3, w_f16=wf, amax_in=amax, amax_out=amax_out)
+            err = float((y - ref).abs().max() / ref.abs().max())
+            scheme = 'auto' if cfg < 0 else ('fp32', 'bf16x3', 'f16x2')[cfg // (ncfg // 3)]
+            worst[scheme] = max(worst.get(scheme, 0.0), err)
+            assert err <= 2e-6, (cfg, splitk, err)
+            got = amax_out.view(N, -1).amax(dim=1)
+            assert torch.allclose(got, y.reshape(N, -1).abs().amax(dim=1), rtol=0, atol=0), (cfg, splitk)
+    print('fused DCNv2 %s: max error relative to max|y| per scheme: %s' % (shape, {k: '%.1e' % v for k, v in worst.items()}))
+    # schemes without their operands are refused, not silently replaced
+    with pytest.raises(Exception):
+        ops.dcnv2(ops.View(x), w, scale, shift, ops.View(om), ops.View(y), stride, 1, None, ws, cfg=ncfg - 1, splitk=1)
+
+
 def test_dcn_gather_and_full_layer(golden):
     from model.custom_layers import Conv2dUnit
     from ppyolo_hip import ops

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Merge autotune outputs (tools/retune.sh) into the committed per-mode table.
-usage: merge_tuned.py <mode> file.json [file.json ...]"""
+usage: merge_tuned.py <mode> [--only PREFIX] file.json [file.json ...]     (--only dcnf: just the fused-DCNv2 keys)"""
 import json
 import os
 import sys
@@ -10,7 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 mode = sys.argv[1]
 dst = os.path.join(ROOT, 'pytorch-ppyolo_amd', 'ppyolo_hip', 'tuned_gfx950%s.json' % ('' if mode == 'fp32' else '_' + mode))
 tab = json.load(open(dst)) if os.path.exists(dst) else {}
-for f in sys.argv[2:]:
-    tab.update(json.load(open(f)))
+files = sys.argv[2:]
+only = None
+if files and files[0] == '--only':
+    only, files = files[1], files[2:]
+for f in files:
+    tab.update({k: v for k, v in json.load(open(f)).items() if only is None or k.startswith(only + ':')})
 json.dump(tab, open(dst, 'w'), indent=0, sort_keys=True)
 print(dst, len(tab), 'entries; configs used:', Counter(v[0] for v in tab.values()).most_common())
