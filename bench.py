@@ -415,6 +415,10 @@ def train_bench(a, wl, dev, rank, world):
     ts = TrainStep(model, cfg, world)
     lr = lr_at(4000, cfg)
     losses = []
+    if a.autotune:          # measure the convolution geometries the tables do not know (-> ppyolo_hip/tuned_gfx950_train.json)
+        got = ts.autotune(x, gt, targets, a.save_tuning if rank == 0 else None)
+        if rank == 0:
+            print('train autotune: %d geometries measured' % len(got), file=sys.stderr)
 
     def barrier():
         if world > 1:
@@ -446,11 +450,11 @@ def train_bench(a, wl, dev, rank, world):
                                         'GPU' % (wl['model'], S, S, a.batch), global_batch=world * a.batch,
                                parallelism=('data parallel x%d, one all-reduce of %.1f MB of gradients per step' % (world, ts.gflat.numel() * 4 / 1e6))
                                if world > 1 else 'single GPU', math='bf16x3 (exact 3-term bf16 split, fp32 accumulate) for every convolution, '
-                               'exact-fp32 MFMA for the weight gradients', eager=True),
+                               'bf16x3 weight gradients (LDS-transposed operands)', eager=True),
                    loss_first=round(tot[0], 4), loss_last=round(tot[-1], 4),
                    roofline=dict(bound='mfma', achieved=round(ach, 2), peak=round(X3_PEAK_TFLOPS, 1), unit='TFLOP/s',
                                  frac=round(ach / X3_PEAK_TFLOPS, 4), traffic=None, flops_per_step=flops,
-                                 kernel='conv_igemm_x3_kernel<*> (bf16x3) forward + dgrad, conv_wgrad_kernel (exact fp32 MFMA)',
+                                 kernel='conv_igemm_x3_kernel<*> (bf16x3) forward + dgrad, conv_wgrad_x3_kernel (bf16x3)',
                                  peak_note='achieved = algorithmic convolution FLOPs of forward + head backward / WHOLE step time (BatchNorm, loss, '
                                            'SGD and launch gaps included: the step is not graph-captured yet); peak = dense bf16 MFMA / 6'))
         print(json.dumps(out), flush=True)

@@ -116,15 +116,19 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  *   ppy_conv2d_dgrad_f32: dx[n,h,w,c] = sum_{k,r,s} dy[n,h+pad-r,w+pad-s,k] * w[k,r,s,c]  (written, not accumulated).
  *     stride 1 only (PPY_ERR_UNSUPPORTED otherwise: with the reference's freeze_at = 5 only the head trains and it has
  *     no strided convolution).  Runs the forward implicit-GEMM kernels on the flipped / transposed weights; K need not
- *     be a multiple of 32 (the 258-channel output convolutions are zero-padded in the workspace).
+ *     be a multiple of 32 (the 258-channel output convolutions are zero-padded in the workspace).  cfg / splitk: tile
+ *     configuration of that forward kernel for the geometry (N, Ho, Wo, C' = K rounded up to 32, K' = C), as in
+ *     ppy_conv2d_bn_act_f32 (-1 / 0 = heuristic).
  *   ppy_conv2d_wgrad_f32: dw[k,r,s,c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
  *     (written, not accumulated; any stride / C / K).  Exact fp32 MFMA; pixel slices are combined in a fixed order, so
  *     results are run-to-run identical.
  * ws: ppy_conv2d_{dgrad,wgrad}_workspace_bytes() bytes, 256-byte aligned.
  */
 int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H, int W,
-                         int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
-size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+                         int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, void *ws, size_t ws_bytes,
+                         void *stream);
+size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int cfg,
+                                        int splitk);
 int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
                          int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
 size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);

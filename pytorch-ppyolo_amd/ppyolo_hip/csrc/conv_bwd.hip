@@ -322,19 +322,20 @@ static bool bwd_geometry(int N, int H, int W, int C, int K, int R, int S, int st
 
 }  // namespace
 
-extern "C" size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+extern "C" size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int cfg,
+                                        int splitk) {
     Geometry g;          // (of the layer itself: C need not be a multiple of 32 here -- CoordConv layers have C = 514 -- K is padded)
     if (stride != 1 || !bwd_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
     const int Kp = (K + 31) / 32 * 32;
     size_t b = align256((size_t)C * R * S * Kp * 4) + align256((size_t)C * 4) * 2;      // w', ones, zeros
     b += align256((size_t)C * R * S * Kp * 6);                                          // three bf16 planes of w'
     if (Kp != K) b += align256((size_t)g.M * Kp * 4);                                   // channel-padded dy
-    return b + align256(ppy_conv2d_workspace_bytes(N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, -1, 0));
+    return b + align256(ppy_conv2d_workspace_bytes(N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, cfg, splitk));
 }
 
 extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H,
-                                    int W, int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes,
-                                    void *stream) {
+                                    int W, int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, void *ws,
+                                    size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(dy && w_krsc && dx && N > 0 && C > 0 && K > 0 && dy_ld >= K && dx_ld >= C);
     if (stride != 1) return PPY_ERR_UNSUPPORTED;           // (the trainable head has no strided convolution)
@@ -342,7 +343,7 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     if (!bwd_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
     const int Kp = (K + 31) / 32 * 32;
     PPY_CHECK_ARG(R - 1 - pad >= 0 && (Kp != K || (dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0)));      // (a padded copy is aligned by construction)
-    const size_t need = ppy_conv2d_dgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad);
+    const size_t need = ppy_conv2d_dgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad, cfg, splitk);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 255) != 0) return PPY_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *base = (char *)ws;
@@ -377,7 +378,7 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     const size_t rest = ws_bytes - (size_t)(base - (char *)ws);
     // dy is [N, Ho, Wo, K]; for stride 1 the forward convolution with pad' = R-1-pad maps it back onto [N, H, W, C]
     return ppy_conv2d_bn_act_f32(src, src_ld, wt, planes, nullptr, ones, nullptr, zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N,
-                                 g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, -1, 0, nullptr, nullptr, base, rest,
+                                 g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, cfg, splitk, nullptr, nullptr, base, rest,
                                  stream);
 }
 

@@ -16,10 +16,16 @@ gt_score, targets)`, `all_loss.backward()`, `optimizer.step()` -- as a sequence 
 The convolutions run on the exact bf16x3 split (no tracked maxima needed); torch supplies memory, streams and
 `torch.distributed` only.  There is no CPU path.
 """
+import json
+import os
+
 import torch
 
 from . import ops as K
 from ._lib import PPYoloHipError
+
+NUM_FP32_CFGS = 31      # ids below: exact-fp32 MFMA tiles; the next nine: bf16x3 (csrc/conv_igemm.hip, conv_x3.hip)
+TRAIN_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950_train.json')
 
 
 class Act(object):
@@ -81,8 +87,17 @@ class TrainStep(object):
         self.seed = 0
         self.acts = None
         self.flops = 0                      # algorithmic convolution FLOPs (2 * MAC) of the last forward + backward
+        # tile configurations: the measured bf16x3 table of the inference path knows the backbone's shapes; the head's own
+        # (CoordConv channels padded to 32, the data gradients' transposed geometries) are in tuned_gfx950_train.json,
+        # written by autotune() below.  Keys are the geometry the forward kernel sees.
         from .engine import tuned_table
-        self._tuned = tuned_table('bf16x3')
+        self._tuned = dict(tuned_table('bf16x3'))
+        if os.path.exists(TRAIN_TABLE):
+            with open(TRAIN_TABLE) as fh:
+                self._tuned.update(json.load(fh))
+        self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
+        self._measured = {}
+        self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
 
     # ---- constants / buffers -------------------------------------------------------------------------------------
     def _vec(self, name, n, val):
@@ -153,18 +168,59 @@ class TrainStep(object):
         """CoordConv.__call__ (reference model/custom_layers.py:261-272) as a real concatenation, zero-padded to a multiple
         of 32 channels for the implicit GEMM: [x, x_range, y_range, 0 ...]."""
         Cp = _r32(x.C + 2)
-        out = self.new(x.N, x.H, x.W, Cp, req=x.req, zero=True)
-        out.t[..., :x.C].copy_(x.t[..., x.coff:x.coff + x.C])
-        key = ('coord', x.H, x.W)
+        key = ('coord', x.H, x.W, Cp - x.C)
         if key not in self._const:
             xr = torch.arange(0, x.W, dtype=torch.float32, device=self.dev) / (x.W - 1) * 2.0 - 1
             yr = torch.arange(0, x.H, dtype=torch.float32, device=self.dev) / (x.H - 1) * 2.0 - 1
-            g = torch.zeros((x.H, x.W, 2), dtype=torch.float32, device=self.dev)
-            g[:, :, 0] = xr.view(1, x.W)
-            g[:, :, 1] = yr.view(x.H, 1)
+            g = torch.zeros((1, x.H, x.W, Cp - x.C), dtype=torch.float32, device=self.dev)
+            g[0, :, :, 0] = xr.view(1, x.W)
+            g[0, :, :, 1] = yr.view(x.H, 1)
             self._const[key] = g
-        out.t[..., x.C:x.C + 2] = self._const[key]
+        # one launch: [x | x_range, y_range, zeros]
+        out = Act(torch.cat((x.t[..., x.coff:x.coff + x.C], self._const[key].expand(x.N, -1, -1, -1)), dim=3), 0, Cp, x.req)
         return out
+
+    def _choose(self, key, run, chunks):
+        """(tile configuration, split-K) of a convolution launch: the tables; measured on the spot when `self.tune`."""
+        ent = self._tuned.get(key)
+        if ent is None and self.tune:
+            best = None
+            for cfg_id in range(NUM_FP32_CFGS, NUM_FP32_CFGS + 9):          # the nine bf16x3 tiles
+                for splitk in (1, 2, 3, 4, 6, 8):
+                    if splitk > 1 and chunks // splitk < 4:
+                        continue
+                    try:
+                        run(cfg_id, splitk)
+                    except PPYoloHipError:
+                        continue
+                    ms = None
+                    for _ in range(2):
+                        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        st.record()
+                        for _ in range(4):
+                            run(cfg_id, splitk)
+                        en.record()
+                        en.synchronize()
+                        t = st.elapsed_time(en) / 4
+                        ms = t if ms is None else min(ms, t)
+                    if best is None or ms < best[2]:
+                        best = [cfg_id, splitk, round(ms, 4)]
+            if best is not None:
+                ent = self._tuned[key] = self._measured[key] = best
+        return (ent[0], ent[1]) if ent else (-1, 0)
+
+    def autotune(self, x_nchw, gt_box, targets, path=None):
+        """One forward + backward with every convolution geometry the tables do not know measured on the device (nine
+        bf16x3 tiles x split-K); `path`: where to write what was measured (the committed tuned_gfx950_train.json)."""
+        self.tune = True
+        try:
+            self.forward_backward(x_nchw, gt_box, targets)
+        finally:
+            self.tune = False
+        if path:
+            with open(path, 'w') as fh:
+                json.dump(self._measured, fh, indent=0, sort_keys=True)
+        return dict(self._measured)
 
     def conv_unit(self, prefix, x, stride=1, act=None, res=None, coord=False, out=None):
         """Conv2dUnit.forward in training mode (reference model/custom_layers.py:243-253): conv -> BatchNorm on batch
@@ -185,11 +241,12 @@ class TrainStep(object):
         bias = self.param(prefix + '.conv.bias')
         has_bn = prefix + '.bn.weight' in sd
         raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
-        # tile configuration: the measured bf16x3 table of the inference path knows most of these layer shapes
-        tuned = self._tuned.get('conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride))
-        cfg_id, splitk = (tuned[0], tuned[1]) if tuned else (-1, 0)
-        K.conv2d_bn_act(xin.view(), krsc, self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0),
-                        raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws, w_x3=ent['planes'])
+        one, b0 = self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0)
+
+        def run(cfg_id, splitk):
+            K.conv2d_bn_act(xin.view(), krsc, one, b0, raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
+                            w_x3=ent['planes'])
+        run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride), run, R * S * Cp // 32))
         self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
         if not has_bn:
             y = raw
@@ -198,7 +255,7 @@ class TrainStep(object):
             mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
             invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
             K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
-            sd[prefix + '.bn.num_batches_tracked'] += 1
+            self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
             y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
             y.req = trainable
             K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
@@ -227,7 +284,12 @@ class TrainStep(object):
         if x.req:
             self.flops += unit
             dxin = self.new(xin.N, xin.H, xin.W, xin.C)
-            K.conv2d_dgrad(d_raw.view(), ent['krsc'], dxin.view(), stride, pad, self.ws)
+            Kk, R = ent['krsc'].shape[0], ent['krsc'].shape[1]
+
+            def run(cfg_id, splitk):
+                K.conv2d_dgrad(d_raw.view(), ent['krsc'], dxin.view(), stride, pad, self.ws, cfg=cfg_id, splitk=splitk)
+            # the data gradient runs the forward kernel on the transposed geometry: C' = K rounded up to 32, K' = C
+            run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32))
             self.accum(x, dxin.slice(0, x.C))
 
     def _dcn_unit(self, prefix, x, stride, act):
@@ -248,7 +310,7 @@ class TrainStep(object):
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
-        sd[prefix + '.bn.num_batches_tracked'] += 1
+        self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
         y = self.new(x.N, Ho, Wo, Kout)
         K.bn_train_apply(raw.view(), mean, invstd, sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'], y.view(), act)
         return y
@@ -271,7 +333,7 @@ class TrainStep(object):
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], self.ws)
-        sd[p + '.bn.num_batches_tracked'] += 1
+        self._nbt.append(sd[p + '.bn.num_batches_tracked'])
         y = self.new(N, Ho, Wo, Kout)
         K.bn_train_apply(raw.view(), mean, invstd, sd[p + '.bn.weight'], sd[p + '.bn.bias'], y.view(), 'relu')
         y = self.conv_unit('backbone.stage1_conv1_2', y, 1, 'relu')
@@ -427,6 +489,9 @@ class TrainStep(object):
         cfg, hcfg = self.cfg, self.cfg.head
         with torch.no_grad():
             outs = self.head(feats)
+            if self._nbt:      # BatchNorm's num_batches_tracked of every layer this forward normalised: one launch
+                torch._foreach_add_(self._nbt, 1)
+                self._nbt = []
             if self.gflat is None:
                 self._alloc_flat()
             loss6 = torch.zeros(6, dtype=torch.float32, device=self.dev)

@@ -19,12 +19,14 @@ if mode == 'ones': x.fill_(1.0); w.fill_(0.5)
 if mode == 'relu': x.clamp_(min=0)
 sc, sh = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
 y = torch.empty(N, Ho, Wo, K, device='cuda'); ws = torch.empty(64 << 20, device='cuda')
+res = torch.randn(N, Ho, Wo, K, device='cuda') if len(shp) > 7 and shp[7] else None      # residual input (expand layers)
 tr = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
 L = _lib.lib()._handle
 lib = ctypes.CDLL(_lib.LIB_PATH)
 w3 = ops.split_weights_bf16x3(w); wf16 = ops.split_weights_f16x2(w, sc); amax0 = ops.amax_slots(x)
 def run():
-    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', cfg=cfg, splitk=splitk, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0)
+    ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', residual=None if res is None else ops.View(res), cfg=cfg,
+                      splitk=splitk, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0)
 for _ in range(int(os.environ.get('PPY_TRACE_WARM', '3'))): run()
 torch.cuda.synchronize()
 lib.ppy_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
