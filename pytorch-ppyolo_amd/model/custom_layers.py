@@ -58,6 +58,9 @@ class Conv2dUnit(torch.nn.Module):
         self.act_name = act
         self.use_dcn = use_dcn
         self.name = name
+        self.freeze_norm, self.norm_decay, self.lr = freeze_norm, norm_decay, lr      # (reference :94-100)
+        if bias_attr and not use_dcn:
+            self.blr = bias_lr if bias_lr else lr                                     # (reference :112-116)
         if use_dcn:
             self.conv = DCNv2(input_dim, filters, filter_size=filter_size, stride=stride,
                               padding=(filter_size - 1) // 2, bias_attr=False)
@@ -65,6 +68,34 @@ class Conv2dUnit(torch.nn.Module):
             self.conv = torch.nn.Conv2d(input_dim, filters, kernel_size=filter_size, stride=stride,
                                         padding=(filter_size - 1) // 2, bias=bias_attr)
         self.bn = torch.nn.BatchNorm2d(filters) if bn else None
+
+    # ---- training-loop surface (reference :141-243): which tensors train, and their optimizer groups ----
+    def _own_params(self):
+        """[(parameter, lr multiplier, weight decay applies)] in the reference's group order."""
+        if self.use_dcn:
+            c = self.conv
+            ps = [(c.conv_offset.weight, self.lr, True), (c.conv_offset.bias, self.lr, True), (c.dcn_weight, self.lr, True)]
+        else:
+            ps = [(self.conv.weight, self.lr, True)]
+            if self.conv.bias is not None:
+                ps.append((self.conv.bias, self.blr, False))
+        if self.bn is not None:
+            ps += [(self.bn.weight, self.lr, False), (self.bn.bias, self.lr, False)]
+        return ps
+
+    def freeze(self):
+        for prm, _, _ in self._own_params():
+            prm.requires_grad = False
+        if self.use_dcn and self.conv.dcn_bias is not None:
+            self.conv.dcn_bias.requires_grad = False
+
+    def add_param_group(self, param_groups, base_lr, base_wd):
+        """One group per trainable tensor: lr = base_lr * multiplier, L2 decay on convolution weights only (norm scales /
+        offsets and convolution biases: 0) -- what the reference hands to torch.optim.SGD (train.py:270-279)."""
+        for prm, mult, decay in self._own_params():
+            if prm.requires_grad:
+                param_groups.append({'params': [prm], 'lr': base_lr * mult, 'base_lr': base_lr * mult,
+                                     'weight_decay': base_wd if decay else 0.0})
 
     # ---- plan emission -----------------------------------------------------------------------
     def folded(self, device):
@@ -121,7 +152,8 @@ class SPP(torch.nn.Module):
 
 
 class DropBlock(torch.nn.Module):
-    """Identity at inference (reference :304-305); the training branch is out of scope."""
+    """Identity at inference (reference :304-305); in the training step the masks come from ppy_dropblock_mask_f32
+    (ppyolo_hip/train.py)."""
 
     def __init__(self, block_size=3, keep_prob=0.9, is_test=False):
         super(DropBlock, self).__init__()

@@ -47,6 +47,11 @@ class DetectionBlock(torch.nn.Module):
             CoordConv(coord_conv),
             Conv2dUnit(channel + extra, channel * 2, 3, stride=1, name='{}.tip'.format(name), **kw)])
 
+    def add_param_group(self, param_groups, base_lr, base_wd):      # reference model/head.py:233-239
+        for ly in list(self.layers) + list(self.tip_layers):
+            if isinstance(ly, Conv2dUnit):
+                ly.add_param_group(param_groups, base_lr, base_wd)
+
     def _walk(self, b, seq, x):
         coord = False
         for k, ly in enumerate(seq):
@@ -93,6 +98,7 @@ class YOLOv3Head(torch.nn.Module):
         self.anchors, self.anchor_masks = anchors, anchor_masks
         self.downsample, self.in_channels = downsample, in_channels
         self.yolo_loss, self.nms_cfg, self.is_train = yolo_loss, nms_cfg, is_train
+        self.block_size, self.keep_prob, self.norm_decay = block_size, keep_prob, norm_decay
         self._anchors = np.array(copy.deepcopy(anchors)).astype(np.float32)
         assert norm_type in ['bn', 'sync_bn', 'gn', 'affine_channel']
         bn, gn, af = get_norm(norm_type)
@@ -184,6 +190,18 @@ class YOLOv3Head(torch.nn.Module):
         return dict(levels=levels, num_classes=self.num_classes, scale_x_y=self.scale_x_y, iou_aware=self.iou_aware,
                     iou_aware_factor=self.iou_aware_factor, clip_bbox=self.clip_bbox, M_total=M, nms=nms)
 
-    def get_loss(self, *a, **k):
-        raise NotImplementedError('the training step does not run through autograd here: the loss (forward AND backward, one HIP kernel per '
-                                  'level) is part of ppyolo_hip.train.TrainStep.step(images, gt_box, targets, lr) -- INTEGRATION.md section 4')
+    def add_param_group(self, param_groups, base_lr, base_wd):      # reference model/head.py:366-373
+        for blk in self.detection_blocks:
+            blk.add_param_group(param_groups, base_lr, base_wd)
+        for ly in self.yolo_output_convs:
+            ly.add_param_group(param_groups, base_lr, base_wd)
+        for ly in self.upsample_layers:
+            if isinstance(ly, Conv2dUnit):
+                ly.add_param_group(param_groups, base_lr, base_wd)
+
+    def get_loss(self, input, gt_box, gt_label, gt_score, targets):
+        """The reference computes the loss from backbone feature maps with autograd ops (model/head.py:400-423).  Here the
+        training forward, the loss and its backward are HIP kernels driven from the whole model (the frozen backbone runs
+        in training mode too): call `PPYOLO.forward(images, None, False, gt_box, gt_label, gt_score, targets)`."""
+        raise NotImplementedError('call model(images, None, False, gt_box, gt_label, gt_score, targets): the training forward starts '
+                                  'at the images (ppyolo_hip.train), not at torch feature maps')

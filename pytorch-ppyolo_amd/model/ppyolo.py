@@ -19,13 +19,18 @@ class PPYOLO(torch.nn.Module):
 
     def forward(self, x, im_size, eval=True, gt_box=None, gt_label=None, gt_score=None, targets=None):
         if not eval:
-            raise NotImplementedError('forward(eval=False) returns autograd losses in the reference; here the whole training step (forward, '
-                                      'YOLOv3Loss, backward, SGD) is ppyolo_hip.train.TrainStep(model, cfg).step(images, gt_box, targets, lr) -- '
-                                      'INTEGRATION.md section 4')
+            # the reference's training call (train.py:428): a dict of loss terms whose sum can be .backward()ed -- forward, loss
+            # and backward all ran as HIP kernels by the time this returns; backward() hands the finished gradients to autograd
+            from ppyolo_hip.train import loss_dict
+            return loss_dict(self, x, gt_box, targets)
         ex = self._plans.executor(x)
         ex.set_inputs(x, im_size)
         ex.run()
         return self._plans.unpack(ex)
+
+    def add_param_group(self, param_groups, base_lr, base_wd):      # reference model/ppyolo.py:27-29
+        self.backbone.add_param_group(param_groups, base_lr, base_wd)
+        self.head.add_param_group(param_groups, base_lr, base_wd)
 
     def forward_padded(self, x, im_size):
         """Device-resident result without the host sync `forward` needs to build its

@@ -18,7 +18,23 @@ def _norm(norm_type):
     return get_norm(norm_type)
 
 
-class ConvBlock(torch.nn.Module):
+
+class _Units(object):
+    """freeze / add_param_group over the Conv2dUnits of a block, in the reference's order (model/resnet_vd.py:36-46, :71-79)."""
+
+    def _units(self):
+        return [u for u in (getattr(self, 'conv%d' % i, None) for i in (1, 2, 3, 4)) if u is not None]
+
+    def freeze(self):
+        for u in self._units():
+            u.freeze()
+
+    def add_param_group(self, param_groups, base_lr, base_wd):
+        for u in self._units():
+            u.add_param_group(param_groups, base_lr, base_wd)
+
+
+class ConvBlock(_Units, torch.nn.Module):
     def __init__(self, in_c, filters, bn, gn, af, freeze_norm, norm_decay, lr, use_dcn=False, stride=2,
                  downsample_in3x3=True, is_first=False, block_name=''):
         super(ConvBlock, self).__init__()
@@ -43,7 +59,7 @@ class ConvBlock(torch.nn.Module):
         return y
 
 
-class IdentityBlock(torch.nn.Module):
+class IdentityBlock(_Units, torch.nn.Module):
     def __init__(self, in_c, filters, bn, gn, af, freeze_norm, norm_decay, lr, use_dcn=False, block_name=''):
         super(IdentityBlock, self).__init__()
         f1, f2, f3 = filters
@@ -89,6 +105,24 @@ class _Backbone(torch.nn.Module):
         from ppyolo_hip.runtime import run_backbone
         return run_backbone(self, x)
 
+    # ---- training-loop surface (reference model/resnet_vd.py:174-222) ----
+    def _stage_units(self, stage):
+        if stage == 1:
+            return [self.stage1_conv1_1, self.stage1_conv1_2, self.stage1_conv1_3]
+        return self._stage_blocks(stage)
+
+    def freeze(self):
+        """Stages 1 .. freeze_at stop training (their BatchNorm keeps normalising with batch statistics: the reference's
+        loop never leaves train mode)."""
+        for stage in range(1, self.freeze_at + 1):
+            for u in self._stage_units(stage):
+                u.freeze()
+
+    def add_param_group(self, param_groups, base_lr, base_wd):
+        for stage in (1, 2, 3, 4, 5):
+            for u in self._stage_units(stage):
+                u.add_param_group(param_groups, base_lr, base_wd)
+
 
 class Resnet50Vd(_Backbone):
     def __init__(self, norm_type='bn', feature_maps=[3, 4, 5], dcn_v2_stages=[5], downsample_in3x3=True, freeze_at=0,
@@ -123,7 +157,7 @@ class Resnet50Vd(_Backbone):
         return [getattr(self, 'stage%d_%d' % (stage, i)) for i in range(self._depth[stage])]
 
 
-class BasicBlock(torch.nn.Module):
+class BasicBlock(_Units, torch.nn.Module):
     def __init__(self, in_c, filters, bn, gn, af, freeze_norm, norm_decay, lr, stride=1, is_first=False,
                  block_name=''):
         super(BasicBlock, self).__init__()

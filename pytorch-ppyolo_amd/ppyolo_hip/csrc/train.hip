@@ -429,9 +429,11 @@ __global__ void __launch_bounds__(256) chan_sum_final_kernel(const float *part, 
 // ---- ExponentialMovingAverage of the trainable parameters (reference model/EMA.py:29-44): numpy's float32 arithmetic,
 // shadow = decay * shadow + (1 - decay) * param with three separate roundings (no fused multiply-add)
 __global__ void __launch_bounds__(256) ema_kernel(float *shadow, const float *param, long long n, float decay, float one_minus) {
+#pragma clang fp contract(off)      // (HIP's __fmul_rn / __fadd_rn are plain operators: without this the sum contracts into an fma)
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    shadow[i] = __fadd_rn(__fmul_rn(decay, shadow[i]), __fmul_rn(one_minus, param[i]));
+    const float a = decay * shadow[i], b = one_minus * param[i];
+    shadow[i] = a + b;
 }
 
 static int slices_for(int P, int C) {

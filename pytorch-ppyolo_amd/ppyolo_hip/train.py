@@ -62,16 +62,58 @@ def _r32(c):
     return (c + 31) // 32 * 32
 
 
+class ModelSettings(object):
+    """What the training step reads from a configuration object (config/ppyolo_2x.py), taken from the MODEL instead -- as the
+    reference's train.py builds it: backbone(**cfg.backbone), YOLOv3Head(yolo_loss=YOLOv3Loss(iou_loss=..., ...), ...)."""
+
+    def __init__(self, model):
+        bb, hd = model.backbone, model.head
+        yl = hd.yolo_loss
+        if yl is None:
+            raise PPYoloHipError('the head holds no loss settings: build it with yolo_loss=YOLOv3Loss(...) (reference train.py:241-249)')
+        self.backbone_type = type(bb).__name__
+        self.backbone = dict(freeze_at=bb.freeze_at, feature_maps=list(bb.feature_maps))
+        dropping = [m for blk in hd.detection_blocks for m in blk.layers if type(m).__name__ == 'DropBlock']
+        self.head = dict(anchors=hd.anchors, anchor_masks=hd.anchor_masks, num_classes=hd.num_classes, downsample=hd.downsample,
+                         conv_block_num=hd.conv_block_num, coord_conv=hd.coord_conv, spp=hd.use_spp, keep_prob=hd.keep_prob,
+                         drop_block=bool(hd.drop_block), iou_aware=hd.iou_aware,
+                         # head.set_dropblock(is_test=True): the DropBlock modules stay in the layer lists, as identities
+                         drop_active=bool(dropping) and not all(m.is_test for m in dropping))
+        if hd.block_size != 3:
+            raise PPYoloHipError('DropBlock block_size %r: the mask kernel implements the configurations\' 3' % (hd.block_size,))
+        if bool(hd.iou_aware) != (yl._iou_aware_loss is not None):
+            raise PPYoloHipError('head.iou_aware and YOLOv3Loss(iou_aware_loss=...) disagree')
+        self.yolo_loss = dict(scale_x_y=yl.scale_x_y, ignore_thresh=yl._ignore_thresh)
+        self.iou_loss = dict(loss_weight=yl._iou_loss._loss_weight)
+        self.iou_aware_loss = dict(loss_weight=yl._iou_aware_loss._loss_weight if yl._iou_aware_loss is not None else 0.0)
+        self.optimizerBuilder = dict(optimizer=dict(momentum=0.9), regularizer=dict(factor=0.0))      # (unused: torch.optim steps)
+        self.use_ema = False
+
+
 class TrainStep(object):
-    def __init__(self, model, cfg, world_size=1):
+    def __init__(self, model, cfg=None, world_size=1, external_optimizer=False):
+        """cfg: a configuration object (config/ppyolo_2x.py), or None = read the settings from the model's own objects.
+        external_optimizer: the parameters live in the MODULE and something else (torch.optim, the reference's loop) updates
+        them: they are re-read at every forward, step() / sgd() / the fused EMA are off -- see loss_dict()."""
         dev = next(model.parameters()).device
         if dev.type != 'cuda':
             raise PPYoloHipError('the training step needs the model on a ROCm device (got %s); there is no CPU path' % dev)
+        cfg = ModelSettings(model) if cfg is None else cfg
         if cfg.backbone.get('freeze_at', 5) != 5:
             raise PPYoloHipError('only the reference configurations (freeze_at = 5: the head trains) are implemented')
         self.model, self.cfg, self.dev, self.world = model, cfg, dev, world_size
+        self.external = bool(external_optimizer)
         self.sd = model.state_dict()                       # tensors alias the module's parameters / buffers
-        self.train_keys = [k for k, _ in model.named_parameters() if k.startswith('head.')]
+        if self.external:
+            loose = [k for k, q in model.named_parameters() if q.requires_grad and not k.startswith('head.')]
+            if loose:
+                raise PPYoloHipError('%d backbone tensors still train (%s ...): call model.backbone.freeze() -- only the head\'s '
+                                     'backward is implemented (freeze_at = 5, reference train.py:264)' % (len(loose), loose[0]))
+            self.train_keys = [k for k, q in model.named_parameters() if k.startswith('head.') and q.requires_grad]
+            if len(self.train_keys) != sum(1 for k, _ in model.named_parameters() if k.startswith('head.')):
+                raise PPYoloHipError('a partly frozen head is not implemented: all of head.* must require gradients')
+        else:
+            self.train_keys = [k for k, _ in model.named_parameters() if k.startswith('head.')]
         self._wcache = {}
         self._const = {}
         self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
@@ -158,6 +200,17 @@ class TrainStep(object):
             else:
                 self.P[k].copy_(self.sd[k])
         self.sflat = self.pflat.clone() if self.use_ema else None        # EMA.register(): shadow = parameters
+
+    def _pull_params(self):
+        """external_optimizer: the module's parameters are the masters -- bring the kernel-layout copies up to date."""
+        self.sd = self.model.state_dict()      # (a caller may have rebound a parameter's storage, as the reference's EMA.apply does)
+        for k in self.train_keys:
+            src = self.sd[k].detach()
+            ent = self._wcache.get(k)
+            if ent is not None:
+                ent['krsc'][..., :ent['Cin']].copy_(src.permute(0, 2, 3, 1))
+            elif k in self.P:
+                self.P[k].copy_(src)
 
     def param(self, key):
         """A bias / BatchNorm scale or offset as the kernels should read it: the flat master copy once it exists."""
@@ -410,6 +463,7 @@ class TrainStep(object):
         """DetectionBlock.__call__ (reference model/head.py:146-231); layer indices as in the state_dict keys."""
         nblk, coord = hcfg.get('conv_block_num', 2), hcfg.get('coord_conv', True)
         use_spp, drop, keep = hcfg.get('spp', True), hcfg.get('drop_block', True), hcfg.get('keep_prob', 0.9)
+        active = hcfg.get('drop_active', True)
         idx = 0
         for j in range(nblk):
             if use_spp and is_first and j == 1:
@@ -432,10 +486,10 @@ class TrainStep(object):
                 x = self.conv_unit('%s.layers.%d' % (p, idx + 2), x, 1, 'leaky')
                 idx += 3
             if drop and j == 0 and not is_first:
-                x = self.drop_block(x, keep)
+                x = self.drop_block(x, keep) if active else x
                 idx += 1
         if drop and is_first:
-            x = self.drop_block(x, keep)
+            x = self.drop_block(x, keep) if active else x
             idx += 1
         route = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord)
         tip = self.conv_unit('%s.tip_layers.1' % p, route, 1, 'leaky', coord=coord)
@@ -481,6 +535,8 @@ class TrainStep(object):
         self.flops = 0
         self.masks = list(dropblock_masks) if dropblock_masks is not None else None
         with torch.no_grad():
+            if self.external:
+                self._pull_params()
             feats = self.backbone(x_nchw.float().contiguous())
         return self.head_loss_backward(feats, gt_box, targets, inject_douts)
 
@@ -534,6 +590,8 @@ class TrainStep(object):
             self.ema_steps += 1
 
     def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None):
+        if self.external:
+            raise PPYoloHipError('external_optimizer: the caller owns the update (loss.backward(); optimizer.step())')
         loss6 = self.forward_backward(x_nchw, gt_box, targets, dropblock_masks)
         self.all_reduce()
         self.sgd(lr)
@@ -568,6 +626,53 @@ class TrainStep(object):
                     self.sd[k].copy_(t)
         if hasattr(self.model, '_plans'):
             self.model._plans.clear()
+
+
+class _FinishedBackward(torch.autograd.Function):
+    """The loss terms as autograd leaves-with-history: by the time forward() returns, the HIP kernels have already produced
+    d(sum of the terms)/d(parameter) for every trainable tensor; backward() hands those to autograd (scaled by the upstream
+    gradient, which must be the same for every term -- the reference sums them, train.py:429-434)."""
+
+    @staticmethod
+    def forward(ctx, ts, loss6, n_terms, *params):
+        ctx.ts = ts
+        return tuple(loss6[i].clone() for i in range(n_terms))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ts = ctx.ts
+        g = [float(v) for v in gs if v is not None]
+        if not g or any(v != g[0] for v in g) or len(g) != len(gs):
+            raise PPYoloHipError('the HIP training step differentiates the SUM of the loss terms (reference train.py:429-440); '
+                                 'got upstream gradients %s' % g)
+        grads = ts.grads()
+        out = tuple(grads[k] if g[0] == 1.0 else grads[k] * g[0] for k in ts.train_keys)
+        return (None, None, None) + out
+
+
+LOSS_NAMES = ('loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou', 'loss_iou_aware')      # reference model/losses.py:231-240
+
+
+def loss_dict(model, images, gt_box, targets):
+    """`PPYOLO.forward(images, None, False, gt_box, gt_label, gt_score, targets)` of the reference (model/ppyolo.py:19-25):
+    {name: scalar tensor}, whose sum the caller back-propagates and steps with its own torch optimizer.  Training forward
+    (BatchNorm on batch statistics everywhere, DropBlock), loss and the backward through the head run here, as HIP
+    kernels; gt_label / gt_score do not enter the reference's loss either (model/losses.py:113-117)."""
+    ts = getattr(model, '_train_bridge', None)
+    if ts is None:
+        ts = TrainStep(model, None, external_optimizer=True)
+        object.__setattr__(model, '_train_bridge', ts)
+    if isinstance(targets, (list, tuple)):
+        targets = [t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets]
+    dev = ts.dev
+    images = images if torch.is_tensor(images) else torch.as_tensor(images)
+    gt_box = gt_box if torch.is_tensor(gt_box) else torch.as_tensor(gt_box)
+    loss6 = ts.forward_backward(images.to(dev), gt_box.to(dev), [t.to(dev) for t in targets])
+    n = 6 if ts.cfg.head.get('iou_aware', False) else 5
+    params = [p for k, p in model.named_parameters() if k in set(ts.train_keys)]
+    with torch.enable_grad():
+        terms = _FinishedBackward.apply(ts, loss6, n, *params)
+    return {LOSS_NAMES[i]: terms[i] for i in range(n)}
 
 
 def lr_at(iter_id, cfg):

@@ -61,6 +61,24 @@ def build_model(cfg, seed=0, device='cpu'):
     return m, sd
 
 
+def build_train_model(cfg, seed=0, device='cpu'):
+    """The model as the reference's train.py:238-264 builds it -- loss settings, YOLOv3Head(is_train=True),
+    backbone.freeze() -- with the deterministic synthetic weights; left in nn.Module's training mode."""
+    from config import select_backbone, select_head, select_loss
+    from model.ppyolo import PPYOLO
+    from ppyolo_hip import synth
+    bb = select_backbone(cfg.backbone_type)(**cfg.backbone)
+    iou_loss = select_loss(cfg.iou_loss_type)(**cfg.iou_loss)
+    iou_aware = select_loss(cfg.iou_aware_loss_type)(**cfg.iou_aware_loss) if cfg.head['iou_aware'] else None
+    yolo_loss = select_loss(cfg.yolo_loss_type)(iou_loss=iou_loss, iou_aware_loss=iou_aware, **cfg.yolo_loss)
+    hd = select_head(cfg.head_type)(yolo_loss=yolo_loss, is_train=True, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes, seed=seed), strict=True)
+    bb.freeze()
+    return m.to(device) if device != 'cpu' else m
+
+
 @pytest.fixture(scope='session')
 def model_shapes():
     def _shapes(cfg):

@@ -1,0 +1,133 @@
+"""The reference's training LOOP run unchanged on this package (train.py:264-286, :416-444): backbone.freeze(),
+model.add_param_group -> torch.optim.SGD, ExponentialMovingAverage, then `losses = model(images, None, False, gt_bbox, gt_class,
+gt_score, targets); sum(losses).backward(); optimizer.step(); ema.update()` three times -- against golden g14, the same loop
+on the reference itself (tools/make_goldens.py g14)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_train_model
+from config import PPYOLO_2x_Config, PPYOLO_r18vd_Config
+from ppyolo_hip import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def digest(t):
+    d = t.detach().double().reshape(-1).cpu()
+    step = max(1, d.numel() // 64)
+    return np.array([d.sum().item(), d.abs().sum().item(), d.pow(2).sum().sqrt().item()]), d[::step][:64].float().numpy()
+
+
+def test_reference_training_loop_runs_unchanged(golden):
+    from model.EMA import ExponentialMovingAverage
+    g = golden('g14_train_loop')
+    S, N = int(g['meta'][0]), int(g['meta'][1])
+    base_lr, wd, mom, decay = [float(v) for v in g['hyper']]
+    cfg = PPYOLO_r18vd_Config()
+    m = build_train_model(cfg, 0, 'cuda')
+    m.head.set_dropblock(is_test=True)
+    init = {k: v.detach().clone() for k, v in m.named_parameters()}
+    groups = []
+    m.add_param_group(groups, base_lr, wd)
+    opt = torch.optim.SGD(groups, lr=base_lr, momentum=mom, weight_decay=wd)
+    ema = ExponentialMovingAverage(m, decay)
+    ema.register()
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    targets = [T(g['target%d' % i]) for i in range(2)]
+    names = [str(v) for v in g['loss_names']]
+    worst_loss = 0.0
+    for it in range(3):
+        x = synth.synth_images(N, S, seed=1234 + it).cuda()
+        losses = m(x, None, False, T(g['gt_bbox']), T(g['gt_class']), T(g['gt_score']), targets)
+        assert list(losses.keys()) == names
+        all_loss = 0.0
+        for k in losses:
+            all_loss = all_loss + losses[k]
+        lr = base_lr * (1.0 - 0.25 * it)
+        for gr in opt.param_groups:
+            gr['lr'] = lr * gr['base_lr'] / base_lr
+        opt.zero_grad()
+        all_loss.backward()
+        opt.step()
+        ema.update()
+        got = np.array([float(losses[k].detach()) for k in names], np.float32)
+        want = g['losses%d' % it]
+        err = np.abs(got - want).max() / np.abs(want).max()
+        worst_loss = max(worst_loss, float(err))
+        # iteration 0 sees identical parameters; later ones the parameters the previous (fp32-noisy) updates produced
+        assert err <= (1e-4 if it == 0 else 5e-4), (it, got, want)          # measured 6e-6
+    # the parameters after three updates: error relative to how far the loop moved the tensor
+    sd = dict(m.named_parameters())
+    errs = {}
+    for i, k in enumerate(str(v) for v in g['param_names']):
+        _, smp = digest(sd[k])
+        ref = g['param_samples'][i][:len(smp)]
+        moved = float(g['update_l2'][i]) / max(1, sd[k].numel()) ** 0.5          # rms update of an element
+        errs[k] = float(np.abs(smp - ref).max() / max(moved, 1e-12))
+        _, ssm = digest(ema._shadow[k])
+        sref = g['shadow_samples'][i][:len(ssm)]
+        # shadow = init + (1 - decay_t)-weighted steps: same relative bar on its own (smaller) movement
+        smoved = float(np.abs(sref - digest(init[k])[1]).max())
+        assert np.abs(ssm - sref).max() <= 0.05 * smoved + 1e-7, (k, 'shadow')
+    v = np.array(list(errs.values()))
+    print('loss terms: max relative error over 3 iterations %.2e; parameters after 3 SGD steps: max error / rms update: median %.2e, '
+          'max %.2e (%s)' % (worst_loss, np.median(v), v.max(), max(errs, key=errs.get)))
+    assert np.median(v) <= 1e-3 and v.max() <= 2e-2                          # measured 4e-5 / 8e-5
+    assert np.allclose(sd['head.yolo_output_convs.1.conv.bias'].detach().cpu().numpy(), g['after.head.yolo_output_convs.1.conv.bias'],
+                       rtol=0, atol=2e-5)
+    # apply / restore keep the parameters' storage (optimizers and the HIP step hold references to it)
+    ptr = {k: q.data_ptr() for k, q in m.named_parameters()}
+    ema.apply()
+    assert torch.equal(sd['head.yolo_output_convs.0.conv.bias'], ema._shadow['head.yolo_output_convs.0.conv.bias'])
+    ema.restore()
+    assert all(q.data_ptr() == ptr[k] for k, q in m.named_parameters())
+
+
+def test_r50_loss_terms_and_non_uniform_backward_is_refused():
+    """All six terms on the R50vd head (IoU-aware branch); the bridge differentiates the SUM of the terms only."""
+    from ppyolo_hip._lib import PPYoloHipError
+    from ppyolo_hip.targets import gt2yolo_target, synth_ground_truth
+    cfg = PPYOLO_2x_Config()
+    m = build_train_model(cfg, 0, 'cuda')
+    S, N = 128, 2
+    bb, cc, ss = synth_ground_truth(N, 3)
+    hc = cfg.head
+    targets = [torch.from_numpy(t).cuda() for t in gt2yolo_target(bb, cc, ss, hc['anchors'], hc['anchor_masks'], hc['downsample'], 80, S)]
+    x = synth.synth_images(N, S, seed=5).cuda()
+    losses = m(x, None, False, torch.from_numpy(bb).cuda(), torch.from_numpy(cc).cuda(), torch.from_numpy(ss).cuda(), targets)
+    assert list(losses) == ['loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou', 'loss_iou_aware']
+    assert all(torch.isfinite(v) and v.requires_grad for v in losses.values())
+    with pytest.raises(PPYoloHipError):
+        (losses['loss_xy'] * 2.0 + losses['loss_wh']).backward()
+    losses = m(x, None, False, torch.from_numpy(bb).cuda(), None, None, targets)
+    sum(losses.values()).backward()
+    gw = m.head.yolo_output_convs[0].conv.weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().max()) > 0
+    assert m.backbone.stage1_conv1_1.conv.weight.grad is None
+    # a model whose backbone still trains is refused (only the head's backward exists)
+    m2 = build_train_model(cfg, 0, 'cuda')
+    for q in m2.backbone.parameters():
+        q.requires_grad = True
+    with pytest.raises(PPYoloHipError):
+        m2(x, None, False, torch.from_numpy(bb).cuda(), None, None, targets)
+
+
+def test_ema_class_matches_reference(golden):
+    """model/EMA.py on the device against golden g13 (the reference's own class, numpy float32 arithmetic)."""
+    from model.EMA import ExponentialMovingAverage
+    g = golden('g13_ema')
+    m = torch.nn.Module()
+    m.a = torch.nn.Parameter(torch.from_numpy(g['a0']).cuda())
+    m.b = torch.nn.Parameter(torch.from_numpy(g['b0']).cuda())
+    m.frozen = torch.nn.Parameter(torch.zeros(3).cuda(), requires_grad=False)
+    ema = ExponentialMovingAverage(m, 0.9998)
+    ema.register()
+    for t in range(4):
+        with torch.no_grad():
+            m.a.copy_(torch.from_numpy(g['a_param%d' % t]))
+            m.b.copy_(torch.from_numpy(g['b_param%d' % t]))
+        d = ema.update()
+        assert d == g['decays'][t] and 'frozen' not in ema._shadow
+        assert np.array_equal(ema._shadow['a'].cpu().numpy(), g['a_shadow%d' % t])
+        assert np.array_equal(ema._shadow['b'].cpu().numpy(), g['b_shadow%d' % t])

@@ -587,8 +587,73 @@ def g13_ema():
     save('g13_ema', **arrs)
 
 
+def g14_train_loop():
+    """The reference's training LOOP through its public surface (train.py:264-286, :416-444): backbone.freeze(),
+    model.add_param_group -> torch.optim.SGD(momentum, per-group weight decay), ExponentialMovingAverage, then three times
+    `losses = model(images, None, False, gt_bbox, gt_class, gt_score, targets); sum(losses).backward(); optimizer.step();
+    ema.update()` -- the loss terms of every iteration, every head parameter after the third, the EMA shadows, and the
+    parameter groups of both configurations.  DropBlock is switched to its test mode (its masks come from torch's global
+    RNG; the masks themselves are pinned by g12), everything else is the reference's training mode."""
+    from model.EMA import ExponentialMovingAverage
+    arrs = {}
+    for tag, C in (('r18vd', PPYOLO_r18vd_Config), ('r50vd', PPYOLO_2x_Config)):
+        cfg = C()
+        m = build_ref_train(cfg, 0)
+        groups = []
+        m.add_param_group(groups, cfg.learningRate['base_lr'], cfg.optimizerBuilder['regularizer']['factor'])
+        names = {id(q): k for k, q in m.named_parameters()}
+        arrs[tag + '.group_names'] = np.array([names[id(g['params'][0])] for g in groups])
+        arrs[tag + '.group_lr_wd'] = np.array([[g['lr'], g['base_lr'], g['weight_decay']] for g in groups], np.float64)
+        assert all(len(g['params']) == 1 for g in groups)
+    cfg = PPYOLO_r18vd_Config()
+    S, N, base_lr, wd, mom = 96, 2, 0.01, 0.0005, 0.9
+    m = build_ref_train(cfg, 0)
+    m.head.set_dropblock(is_test=True)
+    groups = []
+    m.add_param_group(groups, base_lr, wd)
+    opt = torch.optim.SGD(groups, lr=base_lr, momentum=mom, weight_decay=wd)
+    ema = ExponentialMovingAverage(m, 0.9998)
+    ema.register()
+    gt_bbox, gt_class, gt_score, targets = synth_gt(N, S, cfg, seed=77)
+    arrs.update(meta=np.array([S, N, 0, 77]), hyper=np.array([base_lr, wd, mom, 0.9998]), gt_bbox=gt_bbox, gt_class=gt_class,
+                gt_score=gt_score)
+    for i, t in enumerate(targets):
+        arrs['target%d' % i] = t
+    T = torch.from_numpy
+    for it in range(3):
+        x = synth.synth_images(N, S, seed=1234 + it)
+        losses = m(x, None, False, T(gt_bbox), T(gt_class), T(gt_score), [T(t) for t in targets])
+        all_loss = 0.0
+        for k in losses:
+            all_loss = all_loss + losses[k]
+        lr = base_lr * (1.0 - 0.25 * it)                            # the loop rescales every group's lr each iteration (:437-439)
+        for g in opt.param_groups:
+            g['lr'] = lr * g['base_lr'] / base_lr
+        opt.zero_grad()
+        all_loss.backward()
+        opt.step()
+        ema.update()
+        arrs['loss_names'] = np.array(list(losses.keys()))
+        arrs['losses%d' % it] = np.array([float(losses[k]) for k in losses], np.float32)
+    sd = m.state_dict()
+    heads = [k for k, q in m.named_parameters() if q.requires_grad]
+    arrs['param_names'] = np.array(heads)
+    digs, smp, sdig, ssmp = [], [], [], []
+    for k in heads:
+        a, b = grad_digest(sd[k])
+        digs.append(a); smp.append(np.pad(b, (0, 64 - len(b))))
+        a, b = grad_digest(torch.from_numpy(ema._shadow[k]))
+        sdig.append(a); ssmp.append(np.pad(b, (0, 64 - len(b))))
+    arrs.update(param_digest=np.stack(digs), param_samples=np.stack(smp), shadow_digest=np.stack(sdig), shadow_samples=np.stack(ssmp))
+    m0 = build_ref_train(cfg, 0).state_dict()
+    arrs['update_l2'] = np.array([float((sd[k].double() - m0[k].double()).norm()) for k in heads])
+    for k in ('head.yolo_output_convs.1.conv.bias', 'head.detection_blocks.0.layers.2.bn.weight'):
+        arrs['after.' + k] = sd[k]
+    save('g14_train_loop', **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
