@@ -261,6 +261,21 @@ size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, 
                                  int splitk);
 int ppy_dcnv2_num_configs(void);
 
+/* Backward of the deformable convolution (training with freeze_at < 5; arg order after the reference's only real FFI,
+ * dcn_v2_backward(input, weight, bias, offset, mask, grad_output, ...) -> [dX, dOffset, dMask, dW, dBias],
+ * external/DCNv2/src/dcn_v2.h:41-55; semantics = torch autograd of the pure-PyTorch DCNv2.forward,
+ * model/custom_layers.py:551-677).  dy [N,Ho,Wo,K]: gradient of the contraction output (upstream of BN / activation).
+ * Written: dx [N,H,W,C] -- the SAMPLING path only, conv_offset's own data gradient is a plain convolution backward of
+ * d_offset_mask and the caller's to add --, d_offset_mask [N,Ho,Wo,27] with respect to the RAW conv_offset output (18
+ * offsets, 9 mask logits), dw [K][3][3][C].  dx is accumulated with float atomics (data-dependent scatter, as
+ * external/DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:197-262 does): not bit-reproducible run to run; d_offset_mask and dw are.
+ * ws: ppy_dcnv2_backward_workspace_bytes() bytes, 256-byte aligned (the columns + the inner wgrad / dgrad workspaces). */
+int ppy_dcnv2_backward_f32(const float *x, int x_ld, const float *w_krsc, const float *offset_mask, int om_ld,
+                           const float *dy, int dy_ld, float *dx, int dx_ld, float *d_offset_mask, int dom_ld,
+                           float *dw_krsc, int N, int H, int W, int C, int K, int stride, int pad, void *ws,
+                           size_t ws_bytes, void *stream);
+size_t ppy_dcnv2_backward_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad);
+
 /* ------------------------------------------------------------------------------------
  * get_iou_aware_score + yolo_box for ONE head level (reference model/head.py:21-141),
  * fused with the `scores > score_threshold` candidate extraction of matrix_nms

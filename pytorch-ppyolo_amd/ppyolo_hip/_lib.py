@@ -76,6 +76,9 @@ _PROTOS = {
                               c_void_p, c_int] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_dcnv2_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_dcnv2_num_configs': (c_int, []),
+    'ppy_dcnv2_backward_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]
+                               + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_dcnv2_backward_workspace_bytes': (c_size_t, [c_int] * 7),
     'ppy_yolo_decode_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), c_int,
                                     c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -367,6 +367,21 @@ def dcnv2(x, w_krsc, scale, shift, offset_mask, y, stride, pad, act, ws, cfg=-1,
                               _p(amax_in), _p(amax_out), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_f32')
 
 
+def dcnv2_backward(x, w_krsc, offset_mask, dy, dx, d_offset_mask, dw_krsc, stride, pad, ws=None):
+    """Backward of dcnv2 (see ppy_dcnv2_backward_f32): x, dx Views [N,H,W,C]; offset_mask, d_offset_mask Views [N,Ho,Wo,27];
+    dy View [N,Ho,Wo,K]; dw_krsc [K,3,3,C].  dx = sampling path only."""
+    _dev(x.t, w_krsc, offset_mask.t, dy.t, dx.t, d_offset_mask.t, dw_krsc)
+    K = w_krsc.shape[0]
+    assert dw_krsc.is_contiguous() and tuple(dw_krsc.shape) == tuple(w_krsc.shape) and w_krsc.is_contiguous()
+    need = int(lib().ppy_dcnv2_backward_workspace_bytes(x.N, x.H, x.W, x.C, K, stride, pad))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = _bwd_ws(need, x.t.device)
+    check(lib().ppy_dcnv2_backward_f32(x.ptr, x.ld, w_krsc.data_ptr(), offset_mask.ptr, offset_mask.ld, dy.ptr, dy.ld, dx.ptr, dx.ld,
+                                       d_offset_mask.ptr, d_offset_mask.ld, dw_krsc.data_ptr(), x.N, x.H, x.W, x.C, K, stride, pad,
+                                       ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_dcnv2_backward_f32')
+    return ws
+
+
 def yolo_decode(head_out, anchors_px, downsample, num_classes, scale_x_y, iou_aware, iou_aware_factor, clip_bbox,
                 im_size, boxes, box_offset, score_threshold, cand_key, cand_idx, cand_count, scores_dense=None):
     """head_out: View [N,S,S,nch]; boxes [N,M,4]; cand_* [N,cap] int32-storage; cand_count [N] int32."""

@@ -145,3 +145,35 @@ def test_head_conv_gradients_of_a_training_step(golden, tag):
             assert _rel(dx.cpu().permute(0, 3, 1, 2), dx_ref) <= 3e-5, key
         checked += 1
     assert checked == len(leaves) >= 7
+
+
+def test_dcnv2_backward_matches_the_reference(golden):
+    """ppy_dcnv2_backward_f32 against golden g15 = torch autograd through the REFERENCE's DCNv2 module: d w, d (raw conv_offset
+    output) directly; d x after adding conv_offset's own data gradient (a plain convolution backward of d offset_mask, taken from
+    torch here: it is not part of this entry point)."""
+    from ppyolo_hip import ops
+    g = golden('g15_dcn_backward')
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    for i in range(int(g['ncases'])):
+        p = 'b%d_' % i
+        ci, co, s = [int(v) for v in g[p + 'meta']]
+        x, om, dy = T(g[p + 'x']), T(g[p + 'offset_mask']), T(g[p + 'dy'])
+        N, _, H, W = x.shape
+        xh, omh, dyh = nhwc(x).cuda(), nhwc(om).cuda(), nhwc(dy).cuda()
+        w = T(g[p + 'w_dcn']).permute(0, 2, 3, 1).contiguous().cuda()
+        dx = torch.full_like(xh, float('nan'))
+        dom = torch.full_like(omh, float('nan'))
+        dw = torch.full_like(w, float('nan'))
+        ops.dcnv2_backward(ops.View(xh), w, ops.View(omh), ops.View(dyh), ops.View(dx), ops.View(dom), dw, s, 1)
+        rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max())
+        e_w = rel(dw.permute(0, 3, 1, 2), T(g[p + 'dw_dcn']))
+        e_om = rel(dom.permute(0, 3, 1, 2), T(g[p + 'd_offset_mask']))
+        # the whole d x of the module = sampling path (ours) + conv_offset path
+        via_off = torch.nn.grad.conv2d_input(x.shape, T(g[p + 'w_off']), T(g[p + 'd_offset_mask']), stride=s, padding=1)
+        e_x = rel(dx.permute(0, 3, 1, 2) + via_off.cuda(), T(g[p + 'dx']))
+        print('DCNv2 backward case %d (C %d -> K %d, stride %d): relative max error  d w %.1e  d offset/mask %.1e  d x %.1e'
+              % (i, ci, co, s, e_w, e_om, e_x))
+        assert e_w <= 2e-5 and e_om <= 2e-5 and e_x <= 2e-5, (i, e_w, e_om, e_x)
+        # clamped taps: exactly zero offset gradient, like torch.clamp's backward
+        assert torch.equal(dom.permute(0, 3, 1, 2).cpu()[:, :18] == 0, T(g[p + 'd_offset_mask'])[:, :18] == 0)

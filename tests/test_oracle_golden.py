@@ -46,6 +46,25 @@ def test_g2_dcnv2(golden):
         assert (y - T(g[p + 'y_slow'])).abs().max() < 5e-5
 
 
+def test_g15_dcnv2_backward(golden):
+    """torch autograd through the oracle's DCNv2 = the reference's own gradients (golden g15: autograd through the
+    reference's module): the oracle is the checker of ppy_dcnv2_backward_f32 on the GPU."""
+    g = golden('g15_dcn_backward')
+    for i in range(int(g['ncases'])):
+        p = 'b%d_' % i
+        ci, co, s = [int(v) for v in g[p + 'meta']]
+        sd = {'d.dcn_weight': T(g[p + 'w_dcn']).requires_grad_(), 'd.conv_offset.weight': T(g[p + 'w_off']).requires_grad_(),
+              'd.conv_offset.bias': T(g[p + 'b_off']).requires_grad_()}
+        x = T(g[p + 'x']).requires_grad_()
+        y = orc.dcnv2(sd, 'd', x, stride=s)
+        assert torch.equal(y.detach(), T(g[p + 'y'])), i
+        y.backward(T(g[p + 'dy']))
+        for got, key in ((x.grad, 'dx'), (sd['d.dcn_weight'].grad, 'dw_dcn'), (sd['d.conv_offset.weight'].grad, 'dw_off'),
+                         (sd['d.conv_offset.bias'].grad, 'db_off')):
+            want = T(g[p + key])
+            assert (got - want).abs().max() <= 2e-6 * want.abs().max(), (i, key)
+
+
 def test_g3_coord_spp(golden):
     g = golden('g3_coord_spp')
     assert torch.equal(orc.coord_concat(T(g['coord_x'])), T(g['coord_y']))

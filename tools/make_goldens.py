@@ -652,8 +652,50 @@ def g14_train_loop():
     save('g14_train_loop', **arrs)
 
 
+def g15_dcn_backward():
+    """Backward of the reference's DCNv2 module (model/custom_layers.py:486-677) by torch autograd, the semantics the
+    reference trains with when freeze_at < 5: for a random upstream gradient dy, the gradients of the input (whole: sampling
+    path + conv_offset path), of the raw conv_offset output (18 offsets + 9 mask logits), and of the three parameter tensors.
+    Offsets of ~2 px with a few taps pushed far outside (clamped: zero offset gradient there), mask logits on both tails."""
+    g = gen(1515)
+    out = {}
+    cases = [(32, 64, 1, 2, 9, 9), (64, 32, 2, 3, 10, 12), (32, 32, 1, 1, 6, 5)]
+    for i, (ci, co, s, N, H, W) in enumerate(cases):
+        m = DCNv2(ci, co, filter_size=3, stride=s, padding=1, bias_attr=False)
+        with torch.no_grad():
+            m.conv_offset.weight.copy_(torch.randn(m.conv_offset.weight.shape, generator=g) * (2.0 / (ci * 9) ** 0.5))
+            b = torch.randn(27, generator=g) * 1.0
+            b[3] = 12.3
+            b[10] = -11.7
+            b[20] = 4.0
+            b[25] = -5.0
+            m.conv_offset.bias.copy_(b)
+            m.dcn_weight.copy_(torch.randn(m.dcn_weight.shape, generator=g) * (1.0 / (ci * 9)) ** 0.5)
+        x = torch.randn(N, ci, H, W, generator=g, requires_grad=True)
+        kept = {}
+        def keep(mod, inp, o):
+            o.retain_grad()
+            kept['om'] = o
+        h = m.conv_offset.register_forward_hook(keep)
+        y = m(x)
+        h.remove()
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        p = 'b%d_' % i
+        out[p + 'meta'] = np.array([ci, co, s])
+        out[p + 'x'], out[p + 'dy'], out[p + 'y'] = x.detach(), dy, y.detach()
+        out[p + 'w_off'], out[p + 'b_off'], out[p + 'w_dcn'] = m.conv_offset.weight.detach(), m.conv_offset.bias.detach(), m.dcn_weight.detach()
+        out[p + 'offset_mask'] = kept['om'].detach()
+        out[p + 'dx'] = x.grad
+        out[p + 'd_offset_mask'] = kept['om'].grad
+        out[p + 'dw_off'], out[p + 'db_off'], out[p + 'dw_dcn'] = m.conv_offset.weight.grad, m.conv_offset.bias.grad, m.dcn_weight.grad
+        assert float(kept['om'].grad[:, :18].abs().max()) > 0 and float((kept['om'].grad[:, 3] == 0).float().mean()) > 0.5      # pushed out: clamped
+    out['ncases'] = np.array(len(cases))
+    save('g15_dcn_backward', **out)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
