@@ -154,8 +154,18 @@ size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R
  *  ppy_sgd_momentum_f32: torch.optim.SGD(momentum, weight_decay) as built by train.py:271-280:
  *    d = g + wd * p; v = first_step ? d : mu * v + d; p -= lr * v.
  * All reductions run in a fixed order (no float atomics): results are run-to-run identical.
+ *  ppy_avgpool2x2_bwd_f32 / ppy_maxpool3x3s2_bwd_f32: backward of the vd shortcut's AvgPool2d(2, 2) (resnet_vd.py:29-33) and of
+ *    the stem's MaxPool2d(3, 2, 1) (:103; the gradient of a window goes to its first maximum in scan order, as in torch) --
+ *    training with freeze_at < 5.  dx [N,H,W,C] is written whole.
+ *  ppy_zero_insert_f32: up[n, i*s, j*s, :] = dy[n, i, j, :] into a zeroed [N,H1,W1,C]: the data gradient of a stride-s
+ *    convolution = ppy_conv2d_dgrad_f32 (stride 1) of the zero-inserted gradient with H1 = H + 2*pad - R + 1.
  */
 size_t ppy_bn_train_workspace_bytes(int P, int C);
+int ppy_avgpool2x2_bwd_f32(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C, void *stream);
+int ppy_maxpool3x3s2_bwd_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C,
+                             void *stream);
+int ppy_zero_insert_f32(const float *dy, int dy_ld, float *up, int up_ld, int N, int Ho, int Wo, int C, int H1, int W1, int stride,
+                        void *stream);
 int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, float eps, float momentum, float *mean, float *invstd,
                            float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream);
 int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const float *invstd, const float *gamma,

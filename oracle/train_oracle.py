@@ -24,10 +24,12 @@ from . import ppyolo_oracle as orc
 # training-mode forward
 # ----------------------------------------------------------------------------
 def trainable_keys(sd, freeze_at=5):
-    """Parameters that receive gradients: with freeze_at=5 (both configs, config/ppyolo_2x.py:101) every backbone
-    tensor is frozen (model/resnet_vd.py:174-200) and the whole head trains.  Buffers never do."""
-    assert freeze_at == 5, 'only the reference configurations (freeze_at=5) are restated'
-    return [k for k in sd if k.startswith('head.') and not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    """Parameters that receive gradients: backbone.freeze() stops stages 1 .. freeze_at (model/resnet_vd.py:174-200;
+    freeze_at = 5 in both configurations, config/ppyolo_2x.py:101: the whole backbone), the stages above and the whole head
+    train.  Buffers never do."""
+    def stage(k):
+        return int(k[len('backbone.stage')]) if k.startswith('backbone.stage') else 6
+    return [k for k in sd if stage(k) > freeze_at and not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
 
 
 def forward_train(sd, cfg, x):

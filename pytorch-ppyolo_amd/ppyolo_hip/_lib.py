@@ -55,6 +55,9 @@ _PROTOS = {
                                         c_void_p]),
     'ppy_dropblock_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),
     'ppy_sgd_momentum_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_int, c_void_p]),
+    'ppy_avgpool2x2_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 4 + [c_void_p]),
+    'ppy_maxpool3x3s2_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 4 + [c_void_p]),
+    'ppy_zero_insert_f32': (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     'ppy_ema_update_f32': (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_float, c_void_p]),
     'ppy_add_inplace_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_void_p]),
     'ppy_upsample2x_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -250,6 +250,80 @@ __global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float *dy, in
     *reinterpret_cast<floatx4 *>(o) = r;
 }
 
+// ---- AvgPool2d(2, 2) backward (vd shortcut, reference model/resnet_vd.py:29-33): every input pixel of a complete 2x2 window gets a
+// quarter of the window's gradient; the odd last row / column (floor mode) gets none.
+__global__ void __launch_bounds__(256) avgpool2x2_bwd_kernel(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C) {
+    const int c4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * c4) return;
+    const int c = (int)(i % c4) * 4;
+    long long q = i / c4;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    floatx4 r = {0.f, 0.f, 0.f, 0.f};
+    if ((h >> 1) < Ho && (w >> 1) < Wo) {
+        r = *reinterpret_cast<const floatx4 *>(dy + (((long long)n * Ho + (h >> 1)) * Wo + (w >> 1)) * dy_ld + c);
+        r *= 0.25f;
+    }
+    *reinterpret_cast<floatx4 *>(dx + (((long long)n * H + h) * W + w) * dx_ld + c) = r;
+}
+
+// ---- MaxPool2d(3, 2, 1) backward (stem, reference model/resnet_vd.py:103): torch routes a window's gradient to its FIRST maximum in
+// (h, w) scan order (implicit -inf padding).  Gather form, deterministic: an input pixel collects the gradients of the at most
+// four windows that contain it and whose first maximum it is.
+__global__ void __launch_bounds__(256) maxpool3x3s2_bwd_kernel(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld,
+                                                               int N, int H, int W, int C, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    const float *xn = x + (long long)n * H * W * x_ld + c;
+    const float v = xn[((long long)h * W + w) * x_ld];
+    float acc = 0.f;
+    // windows (ho, wo) with 2*ho - 1 <= h <= 2*ho + 1
+    for (int ho = (h + 1) / 2 - ((h & 1) ? 1 : 0) - 0; ho <= (h + 1) / 2; ++ho) {
+        if (ho < 0 || ho >= Ho || h < 2 * ho - 1 || h > 2 * ho + 1) continue;
+        for (int wo = (w + 1) / 2 - ((w & 1) ? 1 : 0); wo <= (w + 1) / 2; ++wo) {
+            if (wo < 0 || wo >= Wo || w < 2 * wo - 1 || w > 2 * wo + 1) continue;
+            // is (h, w) the first maximum of this window?
+            bool first = true;
+            for (int r = 0; r < 3 && first; ++r) {
+                const int hh = 2 * ho - 1 + r;
+                if ((unsigned)hh >= (unsigned)H) continue;
+                for (int t = 0; t < 3; ++t) {
+                    const int ww = 2 * wo - 1 + t;
+                    if ((unsigned)ww >= (unsigned)W) continue;
+                    const float u = xn[((long long)hh * W + ww) * x_ld];
+                    const bool before = hh < h || (hh == h && ww < w);
+                    if (u > v || (before && u == v) || (u != u && before)) { first = false; break; }      // (a NaN earlier in the scan wins, like torch)
+                }
+            }
+            if (first && v == v) acc += dy[(((long long)n * Ho + ho) * Wo + wo) * dy_ld + c];
+        }
+    }
+    dx[(((long long)n * H + h) * W + w) * dx_ld + c] = acc;
+}
+
+// ---- zero insertion: up[n, i*s, j*s, :] = dy[n, i, j, :], zeros elsewhere -- turns the data gradient of a stride-s convolution into
+// the stride-1 one of the upsampled gradient (ppy_conv2d_dgrad_f32 is stride 1).
+__global__ void __launch_bounds__(256) zero_insert_kernel(const float *dy, int dy_ld, float *up, int up_ld, int N, int Ho, int Wo, int C,
+                                                          int H1, int W1, int s) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H1 * W1 * C) return;
+    const int c = (int)(i % C);
+    long long q = i / C;
+    const int w = (int)(q % W1);
+    q /= W1;
+    const int h = (int)(q % H1), n = (int)(q / H1);
+    float v = 0.f;
+    if (h % s == 0 && w % s == 0 && h / s < Ho && w / s < Wo) v = dy[(((long long)n * Ho + h / s) * Wo + w / s) * dy_ld + c];
+    up[(((long long)n * H1 + h) * W1 + w) * up_ld + c] = v;
+}
+
 // ---- SPP backward.  Forward (custom_layers.py:281-290): cat([x, pool5(x), pool9(x), pool13(x)]), stride 1, implicit -inf
 // padding.  torch's max_pool2d routes a window's gradient to its FIRST maximum in (h, w) scan order.  Deterministic gather
 // form: kernel 1 records every window's argmax position, kernel 2 lets each input element collect the gradients of the
@@ -518,6 +592,34 @@ extern "C" int ppy_upsample2x_bwd_f32(const float *dy, int dy_ld, float *dx, int
     PPY_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dy_ld >= C && dx_ld >= C && dy_ld % 4 == 0 && dx_ld % 4 == 0);
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
                        dx, dx_ld, N, H, W, C, accumulate);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_avgpool2x2_bwd_f32(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && dx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0 && dy_ld >= C && dx_ld >= C && dy_ld % 4 == 0 && dx_ld % 4 == 0);
+    hipLaunchKernelGGL(avgpool2x2_bwd_kernel, dim3(blocks_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       dx, dx_ld, N, H, W, C);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_maxpool3x3s2_bwd_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W,
+                                        int C, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && x_ld >= C && dy_ld >= C && dx_ld >= C);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(blocks_for((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy,
+                       dy_ld, dx, dx_ld, N, H, W, C, Ho, Wo);
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_zero_insert_f32(const float *dy, int dy_ld, float *up, int up_ld, int N, int Ho, int Wo, int C, int H1, int W1,
+                                   int stride, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && up && N > 0 && Ho > 0 && Wo > 0 && C > 0 && stride > 0 && dy_ld >= C && up_ld >= C);
+    PPY_CHECK_ARG(H1 >= (Ho - 1) * stride + 1 && W1 >= (Wo - 1) * stride + 1);
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(blocks_for((long long)N * H1 * W1 * C)), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, up,
+                       up_ld, N, Ho, Wo, C, H1, W1, stride);
     return ppy_launch_status();
 }
 

@@ -207,6 +207,25 @@ def act_bwd(dy, y, dx, act):
           'ppy_act_bwd_f32')
 
 
+def avgpool2x2_bwd(dy, dx):
+    _dev(dy.t, dx.t)
+    assert dy.H == dx.H // 2 and dy.W == dx.W // 2 and dy.C == dx.C
+    check(lib().ppy_avgpool2x2_bwd_f32(dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, _stream()), 'ppy_avgpool2x2_bwd_f32')
+
+
+def maxpool3x3s2_bwd(x, dy, dx):
+    _dev(x.t, dy.t, dx.t)
+    assert (dx.H, dx.W, dx.C) == (x.H, x.W, x.C) and dy.C == x.C
+    check(lib().ppy_maxpool3x3s2_bwd_f32(x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, x.N, x.H, x.W, x.C, _stream()), 'ppy_maxpool3x3s2_bwd_f32')
+
+
+def zero_insert(dy, up, stride):
+    """up[n, i*s, j*s] = dy[n, i, j], zeros elsewhere (see ppy_zero_insert_f32)."""
+    _dev(dy.t, up.t)
+    assert dy.C == up.C and dy.N == up.N
+    check(lib().ppy_zero_insert_f32(dy.ptr, dy.ld, up.ptr, up.ld, dy.N, dy.H, dy.W, dy.C, up.H, up.W, stride, _stream()), 'ppy_zero_insert_f32')
+
+
 def upsample2x_bwd(dy, dx, accumulate=False):
     _dev(dy.t, dx.t)
     assert dy.H == 2 * dx.H and dy.W == 2 * dx.W and dy.C == dx.C

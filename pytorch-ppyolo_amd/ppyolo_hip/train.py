@@ -99,21 +99,24 @@ class TrainStep(object):
         if dev.type != 'cuda':
             raise PPYoloHipError('the training step needs the model on a ROCm device (got %s); there is no CPU path' % dev)
         cfg = ModelSettings(model) if cfg is None else cfg
-        if cfg.backbone.get('freeze_at', 5) != 5:
-            raise PPYoloHipError('only the reference configurations (freeze_at = 5: the head trains) are implemented')
+        self.freeze_at = int(cfg.backbone.get('freeze_at', 5))
+        if not 1 <= self.freeze_at <= 5:
+            raise PPYoloHipError('freeze_at = %d: the stem\'s backward (3-channel NCHW input, freeze_at = 0) is not implemented; the '
+                                 'reference configurations use 5 (the head trains), 1..4 add backbone stages' % self.freeze_at)
+        if any(float(v) != 1.0 for v in cfg.backbone.get('lr_mult_list', [1.0])):
+            raise PPYoloHipError('lr_mult_list other than ones is not implemented (one learning rate for all groups)')
         self.model, self.cfg, self.dev, self.world = model, cfg, dev, world_size
         self.external = bool(external_optimizer)
         self.sd = model.state_dict()                       # tensors alias the module's parameters / buffers
+        want = [k for k, _ in model.named_parameters() if self._stage_of(k) > self.freeze_at]
         if self.external:
-            loose = [k for k, q in model.named_parameters() if q.requires_grad and not k.startswith('head.')]
-            if loose:
-                raise PPYoloHipError('%d backbone tensors still train (%s ...): call model.backbone.freeze() -- only the head\'s '
-                                     'backward is implemented (freeze_at = 5, reference train.py:264)' % (len(loose), loose[0]))
-            self.train_keys = [k for k, q in model.named_parameters() if k.startswith('head.') and q.requires_grad]
-            if len(self.train_keys) != sum(1 for k, _ in model.named_parameters() if k.startswith('head.')):
-                raise PPYoloHipError('a partly frozen head is not implemented: all of head.* must require gradients')
-        else:
-            self.train_keys = [k for k, _ in model.named_parameters() if k.startswith('head.')]
+            got = [k for k, q in model.named_parameters() if q.requires_grad]
+            if got != want:
+                odd = sorted(set(got) ^ set(want))
+                raise PPYoloHipError('the tensors that require gradients must be exactly the stages above freeze_at = %d and the head '
+                                     '(call model.backbone.freeze(), reference train.py:264); %d differ, e.g. %s'
+                                     % (self.freeze_at, len(odd), odd[0]))
+        self.train_keys = want
         self._wcache = {}
         self._const = {}
         self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
@@ -140,6 +143,11 @@ class TrainStep(object):
         self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
         self._measured = {}
         self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
+
+    @staticmethod
+    def _stage_of(key):
+        """Backbone stage (1..5) a state_dict key belongs to; 6 = the head."""
+        return int(key[len('backbone.stage')]) if key.startswith('backbone.stage') else 6
 
     # ---- constants / buffers -------------------------------------------------------------------------------------
     def _vec(self, name, n, val):
@@ -176,8 +184,9 @@ class TrainStep(object):
         convolution weights first (the weight-decay group), then biases and BatchNorm scales / offsets -- so that SGD is two
         launches, the EMA one, and data-parallel ranks average every gradient with ONE all-reduce.  The kernels read the
         parameters through views into `pflat` from now on; sync_to_model() writes them back into the module."""
-        convs = [k for k in self.train_keys if k in self._wcache]
-        rest = [k for k in self.train_keys if k not in self._wcache]
+        # (the reference decays conv_offset's bias like a weight: custom_layers.py:189-194)
+        convs = [k for k in self.train_keys if k in self._wcache] + [k for k in self.train_keys if k.endswith('.conv_offset.bias')]
+        rest = [k for k in self.train_keys if k not in convs]
         offs, total = {}, 0
         for k in convs + rest:
             shp = tuple(self._wcache[k]['krsc'].shape) if k in self._wcache else tuple(self.sd[k].shape)
@@ -314,16 +323,34 @@ class TrainStep(object):
             K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
                              None if res is None else res.view())
         if trainable:
-            self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent))
+            self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res))
         if self.acts is not None:          # debugging / tests: activations (and, after the backward, their gradients) by layer
             self.acts[prefix] = y
         return y
 
-    def _conv_unit_bwd(self, prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent):
+    def _dgrad(self, d_raw, krsc, dxin, stride, pad, cfg_id=-1, splitk=0):
+        """Data gradient of a convolution; stride > 1 as the stride-1 data gradient of the zero-inserted output gradient."""
+        if stride == 1:
+            K.conv2d_dgrad(d_raw.view(), krsc, dxin.view(), 1, pad, self.ws, cfg=cfg_id, splitk=splitk)
+            return
+        R = krsc.shape[1]
+        H1, W1 = dxin.H + 2 * pad - R + 1, dxin.W + 2 * pad - R + 1
+        up = self.new(d_raw.N, H1, W1, d_raw.C, ld=_r32(d_raw.C), zero=d_raw.C % 32 != 0)
+        K.zero_insert(d_raw.view(), up.view(), stride)
+        K.conv2d_dgrad(up.view(), krsc, dxin.view(), 1, pad, self.ws)
+
+    def _conv_unit_bwd(self, prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res=None):
         dy = y.g
         if dy is None:
             raise PPYoloHipError('%s: no gradient reached this layer' % prefix)
         sd = self.sd
+        if res is not None:
+            # y = act(bn(conv) + res): the gradient in front of the activation goes to both branches
+            dz = self.new(y.N, y.H, y.W, y.C)
+            K.act_bwd(dy.view(), y.view(), dz.view(), act)
+            if res.req:
+                self.accum(res, dz)
+            dy, act = dz, None
         if mean is not None:
             d_raw = self.new(raw.N, raw.H, raw.W, raw.C)
             K.bn_train_bwd(raw.view(), y.view(), dy.view(), mean, invstd, self.param(prefix + '.bn.weight'), d_raw.view(),
@@ -339,21 +366,25 @@ class TrainStep(object):
             dxin = self.new(xin.N, xin.H, xin.W, xin.C)
             Kk, R = ent['krsc'].shape[0], ent['krsc'].shape[1]
 
-            def run(cfg_id, splitk):
-                K.conv2d_dgrad(d_raw.view(), ent['krsc'], dxin.view(), stride, pad, self.ws, cfg=cfg_id, splitk=splitk)
-            # the data gradient runs the forward kernel on the transposed geometry: C' = K rounded up to 32, K' = C
-            run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32))
+            if stride == 1:
+                def run(cfg_id, splitk):
+                    self._dgrad(d_raw, ent['krsc'], dxin, 1, pad, cfg_id, splitk)
+                # the data gradient runs the forward kernel on the transposed geometry: C' = K rounded up to 32, K' = C
+                run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32))
+            else:
+                self._dgrad(d_raw, ent['krsc'], dxin, stride, pad)
             self.accum(x, dxin.slice(0, x.C))
 
     def _dcn_unit(self, prefix, x, stride, act):
-        """DCNv2 inside a (frozen) backbone unit: offsets / masks from conv_offset, deformable contraction, BatchNorm on batch
-        statistics (reference model/custom_layers.py:551-677)."""
+        """DCNv2 inside a backbone unit: offsets / masks from conv_offset, deformable contraction, BatchNorm on batch statistics
+        (reference model/custom_layers.py:551-677); records its backward when stage 5 trains (freeze_at < 5)."""
         sd = self.sd
         co = self.weight(prefix + '.conv.conv_offset.weight')
+        trainable = co['trainable']
         Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
         om = self.new(x.N, Ho, Wo, 27, ld=32, zero=True)
-        K.conv2d_bn_act(x.view(), co['krsc'], self._vec('one', 27, 1.0), sd[prefix + '.conv.conv_offset.bias'], om.view(), stride, 1, None,
-                        ws=self.ws, w_x3=co['planes'])
+        K.conv2d_bn_act(x.view(), co['krsc'], self._vec('one', 27, 1.0), self.param(prefix + '.conv.conv_offset.bias'), om.view(), stride, 1,
+                        None, ws=self.ws, w_x3=co['planes'])
         w = self.weight(prefix + '.conv.dcn_weight')
         Kout = w['krsc'].shape[0]
         raw = self.new(x.N, Ho, Wo, Kout)
@@ -364,8 +395,30 @@ class TrainStep(object):
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
         self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
-        y = self.new(x.N, Ho, Wo, Kout)
-        K.bn_train_apply(raw.view(), mean, invstd, sd[prefix + '.bn.weight'], sd[prefix + '.bn.bias'], y.view(), act)
+        y = self.new(x.N, Ho, Wo, Kout, req=trainable)
+        K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act)
+
+        def bwd():
+            if y.g is None:
+                raise PPYoloHipError('%s: no gradient reached this layer' % prefix)
+            d_raw = self.new(raw.N, raw.H, raw.W, raw.C)
+            K.bn_train_bwd(raw.view(), y.view(), y.g.view(), mean, invstd, self.param(prefix + '.bn.weight'), d_raw.view(),
+                           self.G[prefix + '.bn.weight'], self.G[prefix + '.bn.bias'], act, self.ws)
+            dxs = self.new(x.N, x.H, x.W, x.C)
+            d_om = self.new(x.N, Ho, Wo, 27, ld=32, zero=True)
+            K.dcnv2_backward(x.view(), w['krsc'], om.view(), d_raw.view(), dxs.view(), d_om.view(), self.G[prefix + '.conv.dcn_weight'],
+                             stride, 1, self.ws)
+            # conv_offset: a plain 3x3 convolution with bias, same stride, whose output gradient is d_om
+            K.conv2d_wgrad(x.view(), d_om.view(), self.G[prefix + '.conv.conv_offset.weight'], stride, 1, self.ws)
+            K.channel_sum(d_om.view(), self.G[prefix + '.conv.conv_offset.bias'], self.ws)
+            self.flops += 2 * 2 * x.N * Ho * Wo * (Kout * 9 * x.C + 27 * 9 * x.C)
+            if x.req:
+                self.accum(x, dxs)
+                dxo = self.new(x.N, x.H, x.W, x.C)
+                self._dgrad(d_om, co['krsc'], dxo, stride, 1)
+                self.accum(x, dxo)
+        if trainable:
+            self.tape.append(bwd)
         return y
 
     def accum(self, x, g):
@@ -374,7 +427,7 @@ class TrainStep(object):
         else:
             K.add_inplace(x.g.view(), g.view())
 
-    # ---- backbone (forward only: frozen) ----------------------------------------------------------------------------------
+    # ---- backbone (stages 1 .. freeze_at forward only; the stages above record their backward like the head) -----------------
     def _stem(self, x_nchw):
         sd, p = self.sd, 'backbone.stage1_conv1_1'
         w = sd[p + '.conv.weight']
@@ -397,8 +450,14 @@ class TrainStep(object):
         return o
 
     def _avgpool(self, x):
-        o = self.new(x.N, x.H // 2, x.W // 2, x.C)
+        o = self.new(x.N, x.H // 2, x.W // 2, x.C, req=x.req)
         K.avgpool2x2(x.view(), o.view())
+        if x.req:
+            def bwd():
+                g = self.new(x.N, x.H, x.W, x.C)
+                K.avgpool2x2_bwd(o.g.view(), g.view())
+                self.accum(x, g)
+            self.tape.append(bwd)
         return o
 
     def _bottleneck(self, p, x, stride, has_proj, is_first):
@@ -509,10 +568,14 @@ class TrainStep(object):
                 K.upsample2x(route.view(), up.view())
                 wide.t[..., Cr:].copy_(feat.t[..., feat.coff:feat.coff + feat.C])
 
-                def up_bwd(route=route, wide=wide, Cr=Cr):
+                def up_bwd(route=route, wide=wide, Cr=Cr, feat=feat):
                     g = self.new(route.N, route.H, route.W, Cr)
                     K.upsample2x_bwd(wide.g.slice(0, Cr).view(), g.view())
                     self.accum(route, g)
+                    if feat.req:           # the backbone stage behind this feature map trains (freeze_at < 5)
+                        gf = self.new(feat.N, feat.H, feat.W, feat.C)
+                        gf.t.copy_(wide.g.t[..., wide.g.coff + Cr:wide.g.coff + Cr + feat.C])
+                        self.accum(feat, gf)
                 self.tape.append(up_bwd)
                 blk = wide
             else:

@@ -113,6 +113,41 @@ def test_r50_loss_terms_and_non_uniform_backward_is_refused():
         m2(x, None, False, torch.from_numpy(bb).cuda(), None, None, targets)
 
 
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_96_fa2', PPYOLO_r18vd_Config), ('r50vd_128_fa3', PPYOLO_2x_Config)])
+def test_backbone_stages_train_through_the_reference_surface(golden, tag, cfgc):
+    """freeze_at < 5 through the reference's calls: backbone.freeze() leaves the stages above freeze_at trainable, forward(eval=False)
+    + backward() fills their .grad too (DCNv2, strided 3x3, avg-pool shortcuts) -- against golden g16, the reference's own
+    loss terms and gradient norms for the same inputs."""
+    g = golden('g16_train_' + tag)
+    S, N, wseed, iseed, fa = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    cfg.backbone['freeze_at'] = fa
+    m = build_train_model(cfg, wseed, 'cuda')
+    m.head.set_dropblock(is_test=True)
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    x = synth.synth_images(N, S, seed=iseed).cuda()
+    targets = [T(g['target%d' % i]) for i in range(len(cfg.head['anchor_masks']))]
+    losses = m(x, None, False, T(g['gt_bbox']), T(g['gt_class']), T(g['gt_score']), targets)
+    names = [str(v) for v in g['loss_names']]
+    got = np.array([float(losses[k].detach()) for k in names], np.float32)
+    err = float(np.abs(got - g['loss_values']).max() / np.abs(g['loss_values']).max())
+    sum(losses.values()).backward()
+    sd = dict(m.named_parameters())
+    gn = [str(v) for v in g['grad_names']]
+    assert [k for k, q in sd.items() if q.grad is not None] == gn
+    ratio = np.array([float(sd[k].grad.double().norm()) / max(float(g['grad_digest'][i][2]), 1e-30) for i, k in enumerate(gn)])
+    print('%s: loss terms within %.1e; gradient norms / reference: median %.4f, range %.3f .. %.3f over %d tensors (%d backbone)'
+          % (tag, err, np.median(ratio), ratio.min(), ratio.max(), len(gn), sum(k.startswith('backbone.') for k in gn)))
+    assert err <= 2e-3
+    if tag.startswith('r18'):
+        assert np.abs(ratio - 1.0).max() <= 2e-3          # measured: 1.000 for all 64 tensors
+    else:
+        # R50vd at a size the CPU reference can run: stage 5 is 4x4 -- BatchNorm over 32 samples per channel, the chaotic regime
+        # described in test_gpu_train_step.py (the reference on another CPU moves as much); its blocks are held to fp32 tolerance on
+        # well-conditioned inputs in test_stage5_blocks_backward_strict.  Here: same tensors, same scale.
+        assert abs(np.median(ratio) - 1.0) <= 0.15 and ratio.min() >= 0.6 and ratio.max() <= 1.6
+
+
 def test_ema_class_matches_reference(golden):
     """model/EMA.py on the device against golden g13 (the reference's own class, numpy float32 arithmetic)."""
     from model.EMA import ExponentialMovingAverage

@@ -192,3 +192,41 @@ def test_loss_plain_yolov3_branch_and_ignore_mask():
     assert rel(nchw(db), out.grad) <= 2e-5
     for j, nme in enumerate(['loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou']):
         assert abs(float(loss6[j]) - float(losses[nme])) <= 2e-5 * abs(float(losses[nme])), nme
+
+
+def test_pool_backward_and_strided_data_gradient():
+    """Backward pieces of a training backbone (freeze_at < 5) against torch autograd: AvgPool2d(2, 2) (odd sizes: floor mode),
+    MaxPool2d(3, 2, 1) incl. ties (first maximum in scan order), and the data gradient of a STRIDED convolution as the
+    stride-1 data gradient of the zero-inserted output gradient."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(8)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    for N, C, H, W in ((2, 8, 6, 6), (1, 4, 7, 5), (3, 12, 9, 10)):
+        x = torch.randn(N, C, H, W, generator=g).requires_grad_()
+        y = F.avg_pool2d(x, 2, 2)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        dx = torch.full((N, H, W, C), float('nan'), device='cuda')
+        ops.avgpool2x2_bwd(ops.View(nhwc(dy).cuda()), ops.View(dx))
+        assert torch.equal(dx.cpu(), nhwc(x.grad)), (N, C, H, W)
+        xm = torch.randint(-2, 3, (N, C, H, W), generator=g).float().requires_grad_()        # many exact ties
+        ym = F.max_pool2d(xm, 3, 2, 1)
+        dym = torch.randn(ym.shape, generator=g)
+        ym.backward(dym)
+        dxm = torch.full((N, H, W, C), float('nan'), device='cuda')
+        ops.maxpool3x3s2_bwd(ops.View(nhwc(xm.detach()).cuda()), ops.View(nhwc(dym).cuda()), ops.View(dxm))
+        assert torch.allclose(dxm.cpu(), nhwc(xm.grad), rtol=0, atol=1e-6), (N, C, H, W)
+    for N, C, K, H, W, R, s in ((2, 32, 27, 10, 12, 3, 2), (1, 64, 64, 9, 9, 3, 2), (2, 32, 64, 8, 8, 1, 2)):
+        pad = (R - 1) // 2
+        w = torch.randn(K, C, R, R, generator=g) * 0.1
+        Ho, Wo = (H + 2 * pad - R) // s + 1, (W + 2 * pad - R) // s + 1
+        dy = torch.randn(N, K, Ho, Wo, generator=g)
+        want = torch.nn.grad.conv2d_input((N, C, H, W), w, dy, stride=s, padding=pad)
+        H1, W1 = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+        Kp = (K + 31) // 32 * 32
+        up = torch.zeros(N, H1, W1, Kp, device='cuda')
+        ops.zero_insert(ops.View(nhwc(dy).cuda()), ops.View(up, 0, K), s)
+        dx = torch.empty(N, H, W, C, device='cuda')
+        ops.conv2d_dgrad(ops.View(up, 0, K), w.permute(0, 2, 3, 1).contiguous().cuda(), ops.View(dx), 1, pad)
+        err = float((dx.cpu() - nhwc(want)).abs().max() / want.abs().max())
+        assert err <= 2e-6, ((N, C, K, H, W, R, s), err)

@@ -58,6 +58,38 @@ def test_train_step_matches_reference(golden, tag, cfgc):
     assert all(int(v) == 1 for k, v in r['state'].items() if k.endswith('num_batches_tracked'))
 
 
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_96_fa2', PPYOLO_r18vd_Config), ('r50vd_128_fa3', PPYOLO_2x_Config)])
+def test_backbone_stages_training_matches_reference(golden, tag, cfgc, monkeypatch):
+    """freeze_at < 5 (golden g16: the reference with stages above freeze_at training -- DCNv2 bottlenecks, strided 3x3,
+    avg-pool shortcuts): loss terms and the gradient of every trainable tensor, backbone included."""
+    from oracle import ppyolo_oracle as orc
+    g = golden('g16_train_' + tag)
+    S, N, wseed, iseed, fa = [int(v) for v in g['meta']]
+    cfg = cfgc()
+    _, sd = build_model(cfg, wseed, 'cpu')
+    cfg.backbone['freeze_at'] = fa
+    monkeypatch.setattr(orc, 'drop_block_train', lambda x, *a, **k: x)        # the golden ran DropBlock in test mode
+    x = synth.synth_images(N, S, seed=iseed)
+    targets = [T(g['target%d' % i]) for i in range(len(cfg.head['anchor_masks']))]
+    torch.set_num_threads(8)
+    r = trn.train_step(sd, cfg, x, T(g['gt_bbox']), targets)
+    names = [str(n) for n in g['loss_names']]
+    got = np.array([float(r['losses'][k]) for k in names], np.float32)
+    assert np.array_equal(got, g['loss_values']), (got, g['loss_values'])
+    gnames = [str(n) for n in g['grad_names']]
+    assert gnames == list(r['grads']) and any(k.startswith('backbone.stage%d' % (fa + 1)) for k in gnames)
+    assert not any(k.startswith('backbone.stage%d' % fa) for k in gnames)
+    for k, dig, smp in zip(gnames, g['grad_digest'], g['grad_samples']):
+        d = r['grads'][k].double().reshape(-1)
+        mine = np.array([d.sum().item(), d.abs().sum().item(), d.pow(2).sum().sqrt().item()])
+        # (head: bit-equal as in g12; backbone tensors: autograd accumulates the two consumers of a block input and DCNv2's
+        # corner scatter in another order than the reference's module graph -- 1e-7 apart)
+        assert np.allclose(mine[2], dig[2], rtol=1e-5, atol=0), k
+        step = max(1, d.numel() // 64)
+        mine_s = d[::step][:64].float().numpy()
+        assert np.abs(mine_s - smp[:len(mine_s)]).max() <= 1e-5 * float(d.abs().max()), k
+
+
 def test_loss_pieces_have_the_documented_shape_quirks():
     """The IoU-aware term is summed over grid x and broadcast back (reference model/iou_losses.py:241-242); the ignore mask
     uses boxes in (anchor, h, w) order with IoU computed without eps (model/losses.py:56-60, model/matrix_nms.py:31-47)."""

@@ -694,8 +694,41 @@ def g15_dcn_backward():
     save('g15_dcn_backward', **out)
 
 
+def g16_train_step_backbone():
+    """One training forward + backward of the reference with backbone stages training too (freeze_at = 3: stages 4 and 5,
+    i.e. the three DCNv2 bottlenecks, the strided 3x3 of stage4_0, both avg-pool shortcuts; r18vd with freeze_at = 2): as g12
+    -- loss terms, digests of every parameter gradient -- with DropBlock in test mode (masks: g12)."""
+    for tag, C, S, N, fa in (('r50vd_128_fa3', PPYOLO_2x_Config, 128, 2, 3), ('r18vd_96_fa2', PPYOLO_r18vd_Config, 96, 2, 2)):
+        cfg = C()
+        cfg.backbone['freeze_at'] = fa
+        m = build_ref_train(cfg, 0)
+        m.head.set_dropblock(is_test=True)
+        x = synth.synth_images(N, S, seed=1234)
+        gt_bbox, gt_class, gt_score, targets = synth_gt(N, S, cfg, seed=77)
+        T = torch.from_numpy
+        losses = m(x, None, False, T(gt_bbox), T(gt_class), T(gt_score), [T(t) for t in targets])
+        all_loss = 0.0
+        for k in losses:
+            all_loss = all_loss + losses[k]
+        all_loss.backward()
+        arrs = dict(meta=np.array([S, N, 0, 1234, fa]), gt_bbox=gt_bbox, gt_class=gt_class, gt_score=gt_score,
+                    loss_names=np.array(list(losses.keys())), loss_values=np.array([float(losses[k].detach()) for k in losses], np.float32))
+        for i, t in enumerate(targets):
+            arrs['target%d' % i] = t
+        names, digs, samples = [], [], []
+        for k, q in m.named_parameters():
+            stage = int(k[len('backbone.stage')]) if k.startswith('backbone.stage') else 6
+            assert (q.grad is not None) == (stage > fa), k
+            if q.grad is None:
+                continue
+            a, b = grad_digest(q.grad)
+            names.append(k); digs.append(a); samples.append(np.pad(b, (0, 64 - len(b))))
+        arrs.update(grad_names=np.array(names), grad_digest=np.stack(digs), grad_samples=np.stack(samples))
+        save('g16_train_' + tag, **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward, g16=g16_train_step_backbone)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
