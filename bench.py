@@ -406,6 +406,8 @@ def train_bench(a, wl, dev, rank, world):
     from ppyolo_hip.targets import gt2yolo_target, synth_ground_truth
     from ppyolo_hip.train import TrainStep, lr_at
     model, sd, cfg = build_model(wl['cfg'], dev)
+    if a.freeze_at is not None:
+        cfg.backbone['freeze_at'] = a.freeze_at
     S, hc = wl['size'], None
     hc = cfg.head
     x = synth.synth_images(a.batch, S, seed=1234 + rank + a.seed_offset).to(dev)
@@ -446,8 +448,8 @@ def train_bench(a, wl, dev, rank, world):
                    value=round(world * a.batch * a.steps / dt, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=max(1, a.warmup),
                    ms_per_step=round(dt / a.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
                    data='synthetic (randn images, synthetic boxes through Gt2YoloTarget, deterministic random weights)',
-                   config=dict(workload='%s %dx%d training step (reference train.py:416-443, freeze_at=5: the head trains), %d images per '
-                                        'GPU' % (wl['model'], S, S, a.batch), global_batch=world * a.batch,
+                   config=dict(workload='%s %dx%d training step (reference train.py:416-443, freeze_at=%d), %d images per '
+                                        'GPU' % (wl['model'], S, S, ts.freeze_at, a.batch), global_batch=world * a.batch,
                                parallelism=('data parallel x%d, one all-reduce of %.1f MB of gradients per step' % (world, ts.gflat.numel() * 4 / 1e6))
                                if world > 1 else 'single GPU', math='bf16x3 (exact 3-term bf16 split, fp32 accumulate) for every convolution, '
                                'bf16x3 weight gradients (LDS-transposed operands)', eager=True),
@@ -475,6 +477,8 @@ def main():
     ap.add_argument('--no-alt-math', action='store_true', help='skip the side measurement of the other math modes')
     ap.add_argument('--autotune', action='store_true', help='re-measure tile configs instead of using the '
                     'committed tuned_gfx950.json table')
+    ap.add_argument('--freeze-at', type=int, default=None, help='--train: backbone stages 1..N frozen (default: the configuration\'s 5 = the '
+                    'head trains; 1..4 add stages, incl. the DCNv2 backward of stage 5)')
     ap.add_argument('--tune-kinds', default='conv,dcn', help='with --autotune: plan op kinds to re-measure (conv,dcn)')
     ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
                     'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
