@@ -100,9 +100,8 @@ class TrainStep(object):
             raise PPYoloHipError('the training step needs the model on a ROCm device (got %s); there is no CPU path' % dev)
         cfg = ModelSettings(model) if cfg is None else cfg
         self.freeze_at = int(cfg.backbone.get('freeze_at', 5))
-        if not 1 <= self.freeze_at <= 5:
-            raise PPYoloHipError('freeze_at = %d: the stem\'s backward (3-channel NCHW input, freeze_at = 0) is not implemented; the '
-                                 'reference configurations use 5 (the head trains), 1..4 add backbone stages' % self.freeze_at)
+        if not 0 <= self.freeze_at <= 5:
+            raise PPYoloHipError('freeze_at = %d: 0..5 (the reference configurations use 5: the head trains)' % self.freeze_at)
         if any(float(v) != 1.0 for v in cfg.backbone.get('lr_mult_list', [1.0])):
             raise PPYoloHipError('lr_mult_list other than ones is not implemented (one learning rate for all groups)')
         self.model, self.cfg, self.dev, self.world = model, cfg, dev, world_size
@@ -430,23 +429,44 @@ class TrainStep(object):
     # ---- backbone (stages 1 .. freeze_at forward only; the stages above record their backward like the head) -----------------
     def _stem(self, x_nchw):
         sd, p = self.sd, 'backbone.stage1_conv1_1'
-        w = sd[p + '.conv.weight']
+        ent = self.weight(p + '.conv.weight')                  # (KRSC master, 3 channels padded to 32; the stem kernel reads KCRS)
+        trainable = ent['trainable']
         N, _, H, W = x_nchw.shape
         Ho, Wo = K.conv_out_hw(H, W, 3, 3, 2, 1)
-        Kout = w.shape[0]
+        Kout = ent['krsc'].shape[0]
         raw = self.new(N, Ho, Wo, Kout)
-        K.stem_conv(x_nchw, w.detach().float().contiguous(), self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), raw.view(), None)
+        K.stem_conv(x_nchw, ent['krsc'][..., :3].permute(0, 3, 1, 2).contiguous(), self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0),
+                    raw.view(), None)
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], self.ws)
         self._nbt.append(sd[p + '.bn.num_batches_tracked'])
-        y = self.new(N, Ho, Wo, Kout)
-        K.bn_train_apply(raw.view(), mean, invstd, sd[p + '.bn.weight'], sd[p + '.bn.bias'], y.view(), 'relu')
-        y = self.conv_unit('backbone.stage1_conv1_2', y, 1, 'relu')
+        y0 = self.new(N, Ho, Wo, Kout, req=trainable)
+        K.bn_train_apply(raw.view(), mean, invstd, self.param(p + '.bn.weight'), self.param(p + '.bn.bias'), y0.view(), 'relu')
+        if trainable:                                          # freeze_at = 0: the first convolution's weight gradient (no data gradient: the image)
+            def bwd():
+                d_raw = self.new(N, Ho, Wo, Kout)
+                K.bn_train_bwd(raw.view(), y0.view(), y0.g.view(), mean, invstd, self.param(p + '.bn.weight'), d_raw.view(),
+                               self.G[p + '.bn.weight'], self.G[p + '.bn.bias'], 'relu', self.ws)
+                x4 = torch.zeros((N, H, W, 4), dtype=torch.float32, device=self.dev)
+                x4[..., :3] = x_nchw.permute(0, 2, 3, 1)
+                dw3 = torch.empty((Kout, 3, 3, 3), dtype=torch.float32, device=self.dev)
+                K.conv2d_wgrad(K.View(x4, 0, 3), d_raw.view(), dw3, 2, 1, self.ws)
+                g = self.G[p + '.conv.weight']
+                g.zero_()
+                g[..., :3] = dw3
+            self.tape.append(bwd)
+        y = self.conv_unit('backbone.stage1_conv1_2', y0, 1, 'relu')
         y = self.conv_unit('backbone.stage1_conv1_3', y, 1, 'relu')
         Hp, Wp = K.conv_out_hw(y.H, y.W, 3, 3, 2, 1)
-        o = self.new(N, Hp, Wp, y.C)
+        o = self.new(N, Hp, Wp, y.C, req=y.req)
         K.maxpool3x3s2(y.view(), o.view())
+        if y.req:
+            def pool_bwd():
+                g = self.new(y.N, y.H, y.W, y.C)
+                K.maxpool3x3s2_bwd(y.view(), o.g.view(), g.view())
+                self.accum(y, g)
+            self.tape.append(pool_bwd)
         return o
 
     def _avgpool(self, x):

@@ -113,7 +113,7 @@ def test_r50_loss_terms_and_non_uniform_backward_is_refused():
         m2(x, None, False, torch.from_numpy(bb).cuda(), None, None, targets)
 
 
-@pytest.mark.parametrize('tag,cfgc', [('r18vd_96_fa2', PPYOLO_r18vd_Config), ('r50vd_128_fa3', PPYOLO_2x_Config)])
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_96_fa2', PPYOLO_r18vd_Config), ('r18vd_96_fa0', PPYOLO_r18vd_Config), ('r50vd_128_fa3', PPYOLO_2x_Config), ('r50vd_320_fa3', PPYOLO_2x_Config)])
 def test_backbone_stages_train_through_the_reference_surface(golden, tag, cfgc):
     """freeze_at < 5 through the reference's calls: backbone.freeze() leaves the stages above freeze_at trainable, forward(eval=False)
     + backward() fills their .grad too (DCNv2, strided 3x3, avg-pool shortcuts) -- against golden g16, the reference's own
@@ -142,9 +142,13 @@ def test_backbone_stages_train_through_the_reference_surface(golden, tag, cfgc):
     if tag.startswith('r18'):
         assert np.abs(ratio - 1.0).max() <= 2e-3          # measured: 1.000 for all 64 tensors
     else:
-        # R50vd at a size the CPU reference can run: stage 5 is 4x4 -- BatchNorm over 32 samples per channel, the chaotic regime
-        # described in test_gpu_train_step.py (the reference on another CPU moves as much); its blocks are held to fp32 tolerance on
-        # well-conditioned inputs in test_stage5_blocks_backward_strict.  Here: same tensors, same scale.
+        # R50vd at sizes the CPU reference can run: stage 5 is 4x4 / 10x10 -- BatchNorm over 32..200 samples per channel amplifies
+        # fp32 rounding to 3e-3 of the head outputs (the reference's own fp32 gradient norms are 0.90..1.03 of a float64 run), and
+        # at 320 px ONE level-0 cell then sits on a kink of the IoU loss: the predicted box edge crosses the ground-truth edge
+        # between the two forwards (t_w = 0.128 vs 0.121), d loss / d t_w jumps from -1.49 to +0.03, and everything upstream of
+        # level 0 carries 0.92..0.95 of the reference's norm (tools/probes/chain_probe.py; levels 1 and 2: 0.995..1.004).  The
+        # loss kernel on the reference's own head outputs is exact (7e-7, tools/probes/loss_probe.py), r18vd matches tensor by
+        # tensor, and the R50 blocks are held to fp32 tolerance on well-conditioned inputs in test_stage5_blocks_backward_strict.
         assert abs(np.median(ratio) - 1.0) <= 0.15 and ratio.min() >= 0.6 and ratio.max() <= 1.6
 
 

@@ -286,7 +286,7 @@ def test_stage5_blocks_backward_strict():
     assert max(worst.values()) <= 0.12 and float(np.median(list(worst.values()))) <= 1.5e-2, {k: v for k, v in worst.items() if v > 1.5e-2}
 
 
-@pytest.mark.parametrize('cfgc,S,fa', [(PPYOLO_r18vd_Config, 256, 2), (PPYOLO_2x_Config, 192, 3)])
+@pytest.mark.parametrize('cfgc,S,fa', [(PPYOLO_r18vd_Config, 256, 2), (PPYOLO_r18vd_Config, 192, 0), (PPYOLO_2x_Config, 192, 3)])
 def test_train_step_with_backbone_stages(cfgc, S, fa):
     """freeze_at < 5: the stages above it train with the head (reference model/resnet_vd.py:174-200) -- strided 3x3 data gradients,
     avg-pool shortcuts, DCNv2 backward in the loop; against the oracle's autograd on the same inputs, DropBlock off, the loss

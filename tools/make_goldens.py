@@ -696,9 +696,11 @@ def g15_dcn_backward():
 
 def g16_train_step_backbone():
     """One training forward + backward of the reference with backbone stages training too (freeze_at = 3: stages 4 and 5,
-    i.e. the three DCNv2 bottlenecks, the strided 3x3 of stage4_0, both avg-pool shortcuts; r18vd with freeze_at = 2): as g12
+    i.e. the three DCNv2 bottlenecks, the strided 3x3 of stage4_0, both avg-pool shortcuts; r18vd with freeze_at = 2, and 0 = the
+    whole network incl. the stem and its max-pool): as g12
     -- loss terms, digests of every parameter gradient -- with DropBlock in test mode (masks: g12)."""
-    for tag, C, S, N, fa in (('r50vd_128_fa3', PPYOLO_2x_Config, 128, 2, 3), ('r18vd_96_fa2', PPYOLO_r18vd_Config, 96, 2, 2)):
+    for tag, C, S, N, fa in (('r50vd_128_fa3', PPYOLO_2x_Config, 128, 2, 3), ('r50vd_320_fa3', PPYOLO_2x_Config, 320, 2, 3), ('r18vd_96_fa2', PPYOLO_r18vd_Config, 96, 2, 2),
+                             ('r18vd_96_fa0', PPYOLO_r18vd_Config, 96, 2, 0)):
         cfg = C()
         cfg.backbone['freeze_at'] = fa
         m = build_ref_train(cfg, 0)
