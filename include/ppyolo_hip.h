@@ -139,7 +139,8 @@ size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R
  *  ppy_bn_train_stats_f32 / _apply_f32: torch.nn.BatchNorm2d in TRAINING mode (the reference trains with every BatchNorm
  *    on batch statistics: train.py never calls .eval(); model/custom_layers.py:122): per-channel mean and
  *    invstd = 1/sqrt(biased var + eps) of x, running statistics updated in place with `momentum` (unbiased variance), then
- *    y = act((x - mean) * invstd * gamma + beta [+ residual]).
+ *    y = act((x - mean) * invstd * gamma + beta [+ residual]); amax_out (or NULL): per-image max|y| slots as the convolution
+ *    entry point tracks them (zeroed by the caller; pixels_per_image = H*W) -- the operand scale of a following f16x2 kernel.
  *  ppy_bn_train_bwd_f32: given dy = d loss / d y: dz = dy * act'(y), dbeta = sum dz, dgamma = sum dz * xhat,
  *    dx = gamma * invstd * (dz - (dbeta + xhat * dgamma) / P).
  *  ppy_act_bwd_f32: dx = dy * act'(y) alone.
@@ -170,7 +171,7 @@ int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, float eps, fl
                            float *running_mean, float *running_var, void *ws, size_t ws_bytes, void *stream);
 int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const float *invstd, const float *gamma,
                            const float *beta, const float *residual, int res_ld, float *y, int y_ld, int P, int C, int act,
-                           void *stream);
+                           int pixels_per_image, float *amax_out, void *stream);
 int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, int y_ld, const float *dy, int dy_ld, const float *mean,
                          const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P,
                          int C, int act, void *ws, size_t ws_bytes, void *stream);

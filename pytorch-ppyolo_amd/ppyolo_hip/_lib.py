@@ -42,7 +42,7 @@ _PROTOS = {
     'ppy_bn_train_stats_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
     'ppy_bn_train_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                        c_int, c_int, c_void_p]),
+                                        c_int, c_int, c_int, c_void_p, c_void_p]),
     'ppy_bn_train_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'ppy_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),

@@ -117,23 +117,34 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, 
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
 }
 
-// ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread, the per-channel
-// parameters as 16-byte loads (L1 / L2 resident)
-__global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p) {
+// ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per element of work, the per-channel
+// parameters as 16-byte loads (L1 / L2 resident).  A workgroup owns a run of pixels (at most two images), so that the optional
+// per-image max|y| (the operand scale of a following f16x2 convolution, amax_track2 in common.h) costs one or two atomics per wave.
+__global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p, int pix_per_block, int hw, float *amax_out) {
     const int c4 = p.C >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)p.P * c4) return;
-    const int c = (int)(i % c4) * 4;
-    const long long q = i / c4;
-    const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
-    floatx4 r = {0.f, 0.f, 0.f, 0.f};
-    if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + q * p.res_ld + c);
-    const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), is = *reinterpret_cast<const floatx4 *>(p.invstd + c);
-    const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), be = *reinterpret_cast<const floatx4 *>(p.beta + c);
-    floatx4 o;
+    const long long q0 = (long long)blockIdx.x * pix_per_block;
+    const long long q1 = q0 + pix_per_block < p.P ? q0 + pix_per_block : p.P;
+    const long long total = (q1 - q0) * c4;
+    const int n_lo = (int)(q0 / hw), n_hi = (int)((q1 - 1) / hw);
+    const long long bnd = (long long)(n_lo + 1) * hw;
+    float amx_lo = 0.f, amx_hi = 0.f;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const int c = (int)(i % c4) * 4;
+        const long long q = q0 + i / c4;
+        const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
+        floatx4 r = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + q * p.res_ld + c);
+        const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), is = *reinterpret_cast<const floatx4 *>(p.invstd + c);
+        const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), be = *reinterpret_cast<const floatx4 *>(p.beta + c);
+        floatx4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = ppy_apply_act((v[k] - mu[k]) * (is[k] * ga[k]) + be[k] + r[k], p.act);
-    *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+        for (int k = 0; k < 4; ++k) o[k] = ppy_apply_act((v[k] - mu[k]) * (is[k] * ga[k]) + be[k] + r[k], p.act);
+        *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+        const float rmx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        amx_lo = fmaxf(amx_lo, q < bnd ? rmx : 0.0f);
+        amx_hi = fmaxf(amx_hi, q < bnd ? 0.0f : rmx);
+    }
+    if (amax_out) amax_track2(amx_lo, amx_hi, n_lo, n_hi, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 __device__ __forceinline__ float act_grad(float y, int act) {      // derivative from the OUTPUT: y > 0 <=> pre-activation > 0
@@ -543,15 +554,21 @@ extern "C" int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, fl
 
 extern "C" int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const float *invstd, const float *gamma,
                                       const float *beta, const float *residual, int res_ld, float *y, int y_ld, int P, int C, int act,
-                                      void *stream) {
+                                      int pixels_per_image, float *amax_out, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && mean && invstd && gamma && beta && y && P > 0 && C > 0 && C % 4 == 0 && x_ld >= C && y_ld >= C);
     PPY_CHECK_ARG(x_ld % 4 == 0 && y_ld % 4 == 0 && (!residual || (res_ld >= C && res_ld % 4 == 0)));
     PPY_CHECK_ARG((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);      // 16-byte parameter loads
+    PPY_CHECK_ARG(!amax_out || (pixels_per_image > 0 && P % pixels_per_image == 0));
     BnArgs p = {};
     p.x = x; p.x_ld = x_ld; p.out = y; p.out_ld = y_ld; p.P = P; p.C = C; p.act = act;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.res = residual; p.res_ld = res_ld;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((long long)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, p);
+    const int hw = amax_out ? pixels_per_image : P;
+    int ppb = ceil_div(P, 4096);                      // ~16 workgroups per CU
+    const int floor_ppb = ceil_div(4096, C);          // ... of at least 1024 16-byte elements each
+    if (ppb < floor_ppb) ppb = floor_ppb;
+    if (ppb > hw) ppb = hw;                           // a workgroup's pixels lie in at most two images
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ceil_div(P, ppb)), dim3(256), 0, (hipStream_t)stream, p, ppb, hw, amax_out);
     return ppy_launch_status();
 }
 

@@ -184,11 +184,12 @@ def bn_train_stats(x, eps, momentum, mean, invstd, running_mean=None, running_va
     return ws
 
 
-def bn_train_apply(x, mean, invstd, gamma, beta, y, act=None, residual=None):
+def bn_train_apply(x, mean, invstd, gamma, beta, y, act=None, residual=None, amax_out=None):
+    """amax_out: zeroed amax_slots(N) block that receives the per-image max|y| (operand scale of a following f16x2 convolution)."""
     _dev(x.t, mean, invstd, gamma, beta, y.t)
     check(lib().ppy_bn_train_apply_f32(x.ptr, x.ld, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                        None if residual is None else residual.ptr, 0 if residual is None else residual.ld, y.ptr,
-                                       y.ld, x.N * x.H * x.W, x.C, ACT[act], _stream()), 'ppy_bn_train_apply_f32')
+                                       y.ld, x.N * x.H * x.W, x.C, ACT[act], x.H * x.W, _p(amax_out), _stream()), 'ppy_bn_train_apply_f32')
 
 
 def bn_train_bwd(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, act=None, ws=None):

@@ -26,15 +26,18 @@ from ._lib import PPYoloHipError
 
 NUM_FP32_CFGS = 31      # ids below: exact-fp32 MFMA tiles; the next nine: bf16x3 (csrc/conv_igemm.hip, conv_x3.hip)
 TRAIN_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950_train.json')
+TRAIN_TABLE_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_gfx950_train_f16x2.json')
+NUM_X3_F16_FIRST, NUM_X3_F16_LAST = 40, 66      # ids of the f16x2 tiles with 2 / 3 / 4 LDS stages (csrc/conv_x3.hip)
 
 
 class Act(object):
     """NHWC activation: channel slice [coff, coff + C) of a buffer [N, H, W, ld]; `g` = its gradient (an Act) once a
     consumer has produced one; `req` = whether anything upstream wants that gradient."""
-    __slots__ = ('t', 'coff', 'C', 'g', 'req')
+    __slots__ = ('t', 'coff', 'C', 'g', 'req', 'amax')
 
-    def __init__(self, t, coff=0, C=None, req=False):
+    def __init__(self, t, coff=0, C=None, req=False, amax=None):
         self.t, self.coff, self.C, self.g, self.req = t, coff, (t.shape[3] - coff if C is None else C), None, req
+        self.amax = amax          # tracked per-image max|.| (ops.amax_slots block) or None: the operand scale of an f16x2 convolution
 
     @property
     def N(self):
@@ -52,7 +55,7 @@ class Act(object):
         return K.View(self.t, self.coff, self.C)
 
     def slice(self, coff, C):
-        return Act(self.t, self.coff + coff, C, self.req)
+        return Act(self.t, self.coff + coff, C, self.req, self.amax)
 
     def dense_nchw(self):
         return self.t[..., self.coff:self.coff + self.C].permute(0, 3, 1, 2).contiguous()
@@ -139,6 +142,15 @@ class TrainStep(object):
         if os.path.exists(TRAIN_TABLE):
             with open(TRAIN_TABLE) as fh:
                 self._tuned.update(json.load(fh))
+        # forward convolutions on the f16x2 kernels (3 MFMA products instead of 6) where the input's maximum is tracked -- by
+        # bn_train_apply for every normalised activation, propagated through concatenations / pooling / DropBlock here;
+        # PPYOLO_HIP_TRAIN_MATH=bf16x3 keeps every convolution on the exact bf16 split
+        self.f16 = os.environ.get('PPYOLO_HIP_TRAIN_MATH', 'f16x2') == 'f16x2'
+        self._tuned_f = dict(tuned_table('f16x2')) if self.f16 else {}
+        if self.f16 and os.path.exists(TRAIN_TABLE_F16):
+            with open(TRAIN_TABLE_F16) as fh:
+                self._tuned_f.update(json.load(fh))
+        self._amax_arena, self._amax_next = None, 0
         self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
         self._measured = {}
         self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
@@ -160,6 +172,16 @@ class TrainStep(object):
         t = (torch.zeros if zero else torch.empty)((N, H, W, ld), dtype=torch.float32, device=self.dev)
         return Act(t, 0, C, req)
 
+    def new_amax(self, N):
+        """A zeroed block of per-image maximum slots (one arena, zeroed once per step)."""
+        n = N * K.AMAX_FLOATS_PER_IMAGE
+        if self._amax_arena is None or self._amax_next + n > self._amax_arena.numel():
+            self._amax_arena = torch.zeros(max(384 * n, 1 << 16), dtype=torch.float32, device=self.dev)
+            self._amax_next = 0
+        a = self._amax_arena[self._amax_next:self._amax_next + n]
+        self._amax_next += n
+        return a
+
     # ---- parameters in kernel layout ---------------------------------------------------------------------------------
     def weight(self, key, coord=False):
         """-> dict(krsc, planes, Cin): the convolution weight `key` ([K, C, R, S] in the state_dict) as KRSC, padded to a
@@ -172,10 +194,12 @@ class TrainStep(object):
             Cp = _r32(Cin) if (coord or Cin % 32) else Cin
             krsc = torch.zeros((Kout, R, S, Cp), dtype=torch.float32, device=self.dev)
             krsc[..., :Cin] = w.permute(0, 2, 3, 1)
-            ent = dict(krsc=krsc, planes=None, Cin=Cin, trainable=key in self.train_keys)
+            ent = dict(krsc=krsc, planes=None, f16=None, Cin=Cin, trainable=key in self.train_keys)
             self._wcache[key] = ent
         if ent['planes'] is None or ent['trainable']:
             ent['planes'] = K.split_weights_bf16x3(ent['krsc'])
+            if self.f16:      # (planes, per-channel epilogue scale with the weight scale folded in) for a unit scale
+                ent['f16'] = K.split_weights_f16x2(ent['krsc'], self._vec('one', ent['krsc'].shape[0], 1.0))
         return ent
 
     def _alloc_flat(self):
@@ -238,15 +262,22 @@ class TrainStep(object):
             g[0, :, :, 1] = yr.view(x.H, 1)
             self._const[key] = g
         # one launch: [x | x_range, y_range, zeros]
-        out = Act(torch.cat((x.t[..., x.coff:x.coff + x.C], self._const[key].expand(x.N, -1, -1, -1)), dim=3), 0, Cp, x.req)
+        out = Act(torch.cat((x.t[..., x.coff:x.coff + x.C], self._const[key].expand(x.N, -1, -1, -1)), dim=3), 0, Cp, x.req,
+                  None if x.amax is None else torch.clamp_min(x.amax, 1.0))          # (the coordinates lie in [-1, 1])
         return out
 
-    def _choose(self, key, run, chunks):
-        """(tile configuration, split-K) of a convolution launch: the tables; measured on the spot when `self.tune`."""
-        ent = self._tuned.get(key)
+    def _choose(self, key, run, chunks, f16=False):
+        """(tile configuration, split-K) of a convolution launch: the tables; measured on the spot when `self.tune`.  f16: the
+        launch has the operands of the f16x2 kernels (split fp16 weights, tracked input maximum) -- its entries carry ':f'."""
+        tab = self._tuned_f if f16 else self._tuned
+        tkey = key + ':f' if f16 else key
+        ent = tab.get(tkey)
         if ent is None and self.tune:
+            ids = list(range(NUM_FP32_CFGS, NUM_FP32_CFGS + 9))                 # the nine bf16x3 tiles
+            if f16:
+                ids = list(range(NUM_X3_F16_FIRST, NUM_X3_F16_LAST + 1))        # the nine f16x2 tiles x {2, 3, 4} LDS stages
             best = None
-            for cfg_id in range(NUM_FP32_CFGS, NUM_FP32_CFGS + 9):          # the nine bf16x3 tiles
+            for cfg_id in ids:
                 for splitk in (1, 2, 3, 4, 6, 8):
                     if splitk > 1 and chunks // splitk < 4:
                         continue
@@ -267,7 +298,7 @@ class TrainStep(object):
                     if best is None or ms < best[2]:
                         best = [cfg_id, splitk, round(ms, 4)]
             if best is not None:
-                ent = self._tuned[key] = self._measured[key] = best
+                ent = tab[tkey] = self._measured[tkey] = best
         return (ent[0], ent[1]) if ent else (-1, 0)
 
     def autotune(self, x_nchw, gt_box, targets, path=None):
@@ -278,9 +309,13 @@ class TrainStep(object):
             self.forward_backward(x_nchw, gt_box, targets)
         finally:
             self.tune = False
-        if path:
-            with open(path, 'w') as fh:
-                json.dump(self._measured, fh, indent=0, sort_keys=True)
+        if path:       # bf16x3 geometries -> path, f16x2 ones (':f') -> path with '_f16x2' before the extension
+            for suffix, sel in (('', False), ('_f16x2', True)):
+                part = {k: v for k, v in self._measured.items() if k.endswith(':f') == sel}
+                if part:
+                    root, ext = os.path.splitext(path)
+                    with open(root + suffix + ext, 'w') as fh:
+                        json.dump(part, fh, indent=0, sort_keys=True)
         return dict(self._measured)
 
     def conv_unit(self, prefix, x, stride=1, act=None, res=None, coord=False, out=None):
@@ -303,11 +338,13 @@ class TrainStep(object):
         has_bn = prefix + '.bn.weight' in sd
         raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
         one, b0 = self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0)
+        use_f16 = self.f16 and xin.amax is not None and ent['f16'] is not None
 
         def run(cfg_id, splitk):
             K.conv2d_bn_act(xin.view(), krsc, one, b0, raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
-                            w_x3=ent['planes'])
-        run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride), run, R * S * Cp // 32))
+                            w_x3=ent['planes'], w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
+        key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
+        run(*self._choose(key, run, R * S * Cp // 32, use_f16))
         self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
         if not has_bn:
             y = raw
@@ -319,8 +356,9 @@ class TrainStep(object):
             self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
             y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
             y.req = trainable
+            y.amax = self.new_amax(xin.N) if self.f16 else None
             K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
-                             None if res is None else res.view())
+                             None if res is None else res.view(), y.amax)
         if trainable:
             self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res))
         if self.acts is not None:          # debugging / tests: activations (and, after the backward, their gradients) by layer
@@ -387,15 +425,21 @@ class TrainStep(object):
         w = self.weight(prefix + '.conv.dcn_weight')
         Kout = w['krsc'].shape[0]
         raw = self.new(x.N, Ho, Wo, Kout)
+        use_f16 = self.f16 and x.amax is not None and w['f16'] is not None
+        ent = (self._tuned_f if use_f16 else self._tuned).get('dcnf:N%d:H%d:W%d:C%d:K%d:R3:s%d%s' % (x.N, x.H, x.W, x.C, Kout, stride,
+                                                                                                ':f' if use_f16 else ''))
         K.dcnv2(x.view(), w['krsc'], self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), om.view(), raw.view(), stride, 1, None,
-                self.ws, w_x3=w['planes'])
+                self.ws, cfg=ent[0] if ent else -1, splitk=ent[1] if ent else 0, w_x3=w['planes'], w_f16=w['f16'] if use_f16 else None,
+                amax_in=x.amax if use_f16 else None)
         self.flops += 2 * x.N * Ho * Wo * (Kout * 9 * x.C + 27 * 9 * x.C)
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
         self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
         y = self.new(x.N, Ho, Wo, Kout, req=trainable)
-        K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act)
+        y.amax = self.new_amax(x.N) if self.f16 else None
+        K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act, None,
+                         y.amax)
 
         def bwd():
             if y.g is None:
@@ -442,7 +486,8 @@ class TrainStep(object):
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], self.ws)
         self._nbt.append(sd[p + '.bn.num_batches_tracked'])
         y0 = self.new(N, Ho, Wo, Kout, req=trainable)
-        K.bn_train_apply(raw.view(), mean, invstd, self.param(p + '.bn.weight'), self.param(p + '.bn.bias'), y0.view(), 'relu')
+        y0.amax = self.new_amax(N) if self.f16 else None
+        K.bn_train_apply(raw.view(), mean, invstd, self.param(p + '.bn.weight'), self.param(p + '.bn.bias'), y0.view(), 'relu', None, y0.amax)
         if trainable:                                          # freeze_at = 0: the first convolution's weight gradient (no data gradient: the image)
             def bwd():
                 d_raw = self.new(N, Ho, Wo, Kout)
@@ -460,6 +505,7 @@ class TrainStep(object):
         y = self.conv_unit('backbone.stage1_conv1_3', y, 1, 'relu')
         Hp, Wp = K.conv_out_hw(y.H, y.W, 3, 3, 2, 1)
         o = self.new(N, Hp, Wp, y.C, req=y.req)
+        o.amax = y.amax                                        # (a maximum of inputs)
         K.maxpool3x3s2(y.view(), o.view())
         if y.req:
             def pool_bwd():
@@ -471,6 +517,7 @@ class TrainStep(object):
 
     def _avgpool(self, x):
         o = self.new(x.N, x.H // 2, x.W // 2, x.C, req=x.req)
+        o.amax = x.amax                                        # (an average of inputs)
         K.avgpool2x2(x.view(), o.view())
         if x.req:
             def bwd():
@@ -529,6 +576,7 @@ class TrainStep(object):
             self.seed += 1
             K.dropblock_mask(m, scale, keep_prob, (self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
         y = self.new(x.N, x.H, x.W, x.C, req=True)
+        y.amax = None if x.amax is None else x.amax * scale     # y = x * mask * scale, mask in {0, 1}
         K.dropblock_apply(x.view(), m, scale, y.view())
 
         def bwd():
@@ -551,6 +599,7 @@ class TrainStep(object):
                 slot0 = wide.slice(0, Cw)
                 self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord, out=slot0)
                 K.spp(slot0.view(), wide.slice(Cw, Cw).view(), wide.slice(2 * Cw, Cw).view(), wide.slice(3 * Cw, Cw).view())
+                wide.amax = slot0.amax                             # (max-pooled copies of slot 0)
 
                 def spp_bwd(wide=wide, slot0=slot0, Cw=Cw):
                     g = self.new(wide.N, wide.H, wide.W, Cw)
@@ -587,6 +636,7 @@ class TrainStep(object):
                 up = wide.slice(0, Cr)
                 K.upsample2x(route.view(), up.view())
                 wide.t[..., Cr:].copy_(feat.t[..., feat.coff:feat.coff + feat.C])
+                wide.amax = None if (route.amax is None or feat.amax is None) else torch.maximum(route.amax, feat.amax)
 
                 def up_bwd(route=route, wide=wide, Cr=Cr, feat=feat):
                     g = self.new(route.N, route.H, route.W, Cr)
@@ -616,6 +666,9 @@ class TrainStep(object):
             raise PPYoloHipError('the training step needs ROCm device tensors; there is no CPU path')
         self.tape = []
         self.flops = 0
+        if self._amax_arena is not None:
+            self._amax_arena.zero_()
+            self._amax_next = 0
         self.masks = list(dropblock_masks) if dropblock_masks is not None else None
         with torch.no_grad():
             if self.external:
