@@ -120,8 +120,10 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  *     configuration of that forward kernel for the geometry (N, Ho, Wo, C' = K rounded up to 32, K' = C), as in
  *     ppy_conv2d_bn_act_f32 (-1 / 0 = heuristic).
  *   ppy_conv2d_wgrad_f32: dw[k,r,s,c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
- *     (written, not accumulated; any stride / C / K).  Exact fp32 MFMA; pixel slices are combined in a fixed order, so
- *     results are run-to-run identical.
+ *     (written, not accumulated; any stride / C / K).  bf16x3 on the 16-bit MFMA (exact fp32 MFMA where alignment rules it
+ *     out); with amax_x / amax_dy -- tracked per-image maxima of both operands, as ppy_bn_train_apply_f32 / _bwd_f32 and the
+ *     convolution entry point record them -- the f16x2 scheme (one power-of-two scale per operand, 3 products instead of 6).
+ *     Pixel slices are combined in a fixed order, so results are run-to-run identical.
  * ws: ppy_conv2d_{dgrad,wgrad}_workspace_bytes() bytes, 256-byte aligned.
  */
 int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H, int W,
@@ -130,7 +132,8 @@ int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float 
 size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int cfg,
                                         int splitk);
 int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
-                         int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
+                         int C, int K, int R, int S, int stride, int pad, const float *amax_x, const float *amax_dy, void *ws,
+                         size_t ws_bytes, void *stream);
 size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 
 /* ------------------------------------------------------------------------------------
@@ -141,7 +144,7 @@ size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R
  *    invstd = 1/sqrt(biased var + eps) of x, running statistics updated in place with `momentum` (unbiased variance), then
  *    y = act((x - mean) * invstd * gamma + beta [+ residual]); amax_out (or NULL): per-image max|y| slots as the convolution
  *    entry point tracks them (zeroed by the caller; pixels_per_image = H*W) -- the operand scale of a following f16x2 kernel.
- *  ppy_bn_train_bwd_f32: given dy = d loss / d y: dz = dy * act'(y), dbeta = sum dz, dgamma = sum dz * xhat,
+ *  ppy_bn_train_bwd_f32 (amax_dx or NULL: per-image max|dx| slots, as amax_out above): given dy = d loss / d y: dz = dy * act'(y), dbeta = sum dz, dgamma = sum dz * xhat,
  *    dx = gamma * invstd * (dz - (dbeta + xhat * dgamma) / P).
  *  ppy_act_bwd_f32: dx = dy * act'(y) alone.
  *  ppy_upsample2x_bwd_f32: backward of the nearest x2 upsample of the head routes (model/head.py:396-397): dx = sum of the
@@ -173,8 +176,8 @@ int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mean, const fl
                            const float *beta, const float *residual, int res_ld, float *y, int y_ld, int P, int C, int act,
                            int pixels_per_image, float *amax_out, void *stream);
 int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, int y_ld, const float *dy, int dy_ld, const float *mean,
-                         const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P,
-                         int C, int act, void *ws, size_t ws_bytes, void *stream);
+                         const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P, int C,
+                         int act, int pixels_per_image, float *amax_dx, void *ws, size_t ws_bytes, void *stream);
 int ppy_act_bwd_f32(const float *dy, int dy_ld, const float *y, int y_ld, float *dx, int dx_ld, long long P, int C, int act,
                     void *stream);
 int ppy_upsample2x_bwd_f32(const float *dy, int dy_ld, float *dx, int dx_ld, int N, int H, int W, int C, int accumulate,

@@ -36,7 +36,7 @@ _PROTOS = {
     'ppy_conv2d_pick': (c_int, [c_int] * 9 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'ppy_conv2d_dgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int] * 11),
-    'ppy_conv2d_wgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    'ppy_conv2d_wgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_bn_train_workspace_bytes': (c_size_t, [c_int, c_int]),
     'ppy_bn_train_stats_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -44,7 +44,7 @@ _PROTOS = {
     'ppy_bn_train_apply_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_void_p, c_void_p]),
     'ppy_bn_train_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_act_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
     'ppy_upsample2x_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ppy_spp_bwd_workspace_bytes': (c_size_t, [c_int] * 4),

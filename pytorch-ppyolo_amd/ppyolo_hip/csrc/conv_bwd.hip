@@ -53,6 +53,7 @@ struct WgradArgs {
     int x_ld, dy_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad;
     int P, pix_per_slice, tiles_c;
+    const float *amax_x, *amax_dy;      // f16x2 kernel: tracked per-image maxima of x and dy (N * AMAX_SLOTS slots each)
 };
 
 constexpr int WG_TK = 128, WG_TC = 128;       // workgroup tile: output channels x input channels
@@ -158,7 +159,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned uintx4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned uintx2_t;
 constexpr int X3_PIX = 32;                 // pixels per step
 constexpr int X3_PITCH = 80;               // bytes per channel row: 32 pixels x 2 B + 16 B
-constexpr int X3_TILE = 3 * 128 * X3_PITCH;        // one operand: 3 planes x 128 channels
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // RNE, a -> low half
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -180,8 +180,34 @@ __device__ __forceinline__ void split4(const float (&v)[4], uintx2_t (&out)[3]) 
     }
 }
 
-__global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p) {
+// 4 pixels of one channel, scaled by a power of two into the fp16 range -> two fp16 terms (the residual of the SCALED value is
+// exact: conv_x3.hip), each as 4 x fp16 = 8 bytes
+__device__ __forceinline__ void split4_f16(const float (&v)[4], float sc, uintx2_t (&out)[2]) {
+    const unsigned lo = cvt_pk_f16(v[0] * sc, v[1] * sc), hi = cvt_pk_f16(v[2] * sc, v[3] * sc);
+    out[0] = uintx2_t{lo, hi};
+    out[1] = uintx2_t{cvt_pk_f16(fmaf(v[0], sc, -f16_lo(lo)), fmaf(v[1], sc, -f16_hi(lo))),
+                      cvt_pk_f16(fmaf(v[2], sc, -f16_lo(hi)), fmaf(v[3], sc, -f16_hi(hi)))};
+}
+// the power of two that puts max|tensor| (the maximum over its per-image tracked maxima) into [2^13, 2^14), and its inverse
+__device__ __forceinline__ float tensor_scale(const float *amax, int slots, int lane, float *inv) {
+    float mx = 0.0f;
+    for (int i = lane; i < slots; i += 64) mx = fmaxf(mx, fabsf(amax[(long long)i * AMAX_STRIDE]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    int f = 267 - e;
+    f = f < 103 ? 103 : (f > 167 ? 167 : f);
+    *inv = __uint_as_float((unsigned)(254 - f) << 23);
+    return __uint_as_float((unsigned)f << 23);
+}
+
+// F16 = false: bf16x3 (3 planes, 6 products).  F16 = true: f16x2 (2 planes, 3 products on v_mfma_f32_32x32x16_f16); the sum
+// runs over the pixels of ALL images, so each operand gets ONE scale, from the maximum over its per-image maxima.
+template <bool F16>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p) {      // (three f16x2 workgroups per CU -- 40 KB of LDS each -- measured no faster: 17.55 vs 17.31 ms per step)
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NP = F16 ? 2 : 3;
+    constexpr int X3_TILE = NP * 128 * X3_PITCH;                // one operand: NP planes x 128 channels
     __shared__ __attribute__((aligned(16))) char smem[2 * X3_TILE];
     char *sA = smem, *sB = smem + X3_TILE;                      // dy (k rows), x (c rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,16 +247,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
             }
         }
     };
-    auto stage = [&]() {        // registers -> three bf16 planes, transposed: [plane][channel][pixel]
+    float s_dy = 1.0f, s_x = 1.0f, inv_dy = 1.0f, inv_x = 1.0f;
+    if constexpr (F16) {
+        s_dy = tensor_scale(p.amax_dy, p.N * AMAX_SLOTS, tid & 63, &inv_dy);
+        s_x = tensor_scale(p.amax_x, p.N * AMAX_SLOTS, tid & 63, &inv_x);
+    }
+    auto stage = [&]() {        // registers -> NP 16-bit planes, transposed: [plane][channel][pixel]
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float va[4] = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]}, vb[4] = {rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
-            uintx2_t ta[3], tb[3];
-            split4(va, ta);
-            split4(vb, tb);
+            uintx2_t ta[NP], tb[NP];
+            if constexpr (F16) {
+                split4_f16(va, s_dy, ta);
+                split4_f16(vb, s_x, tb);
+            } else {
+                split4(va, ta);
+                split4(vb, tb);
+            }
             const int row = cg * 4 + e;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NP; ++t) {
                 *reinterpret_cast<uintx2_t *>(sA + (t * 128 + row) * X3_PITCH + pq * 8) = ta[t];
                 *reinterpret_cast<uintx2_t *>(sB + (t * 128 + row) * X3_PITCH + pq * 8) = tb[t];
             }
@@ -245,24 +281,29 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
         fetch(p0 + X3_PIX);                     // next step's global loads fly under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uintx4_t fa[2][3], fb[2][3];
+            uintx4_t fa[2][NP], fb[2][NP];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NP; ++t) {
                     fa[i][t] = *reinterpret_cast<const uintx4_t *>(sA + (t * 128 + wk * 64 + i * 32 + frow) * X3_PITCH + ks * 32 + fh * 16);
                     fb[i][t] = *reinterpret_cast<const uintx4_t *>(sB + (t * 128 + wc * 64 + i * 32 + frow) * X3_PITCH + ks * 32 + fh * 16);
                 }
-            // the six leading products, smallest first
+            // the six (bf16x3) / three (f16x2: pieces {0, 1}) leading products, smallest first
             constexpr int ta_[6] = {2, 1, 0, 1, 0, 0}, tb_[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = F16 ? 3 : 0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i][ta_[t]]),
-                                                                           __builtin_bit_cast(bf16x8_t, fb[j][tb_[t]]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (F16)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][ta_[t]]),
+                                                                              __builtin_bit_cast(f16x8, fb[j][tb_[t]]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i][ta_[t]]),
+                                                                               __builtin_bit_cast(bf16x8_t, fb[j][tb_[t]]), acc[i][j], 0, 0, 0);
+                    }
         }
     }
     float *out = p.out + (long long)blockIdx.z * p.K * p.R * p.S * p.C;
@@ -274,7 +315,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = k0 + wk * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (k < p.K && c < p.C) out[(((long long)k * p.R + r) * p.S + s) * p.C + c] = acc[i][j][e];
+                if (k < p.K && c < p.C) out[(((long long)k * p.R + r) * p.S + s) * p.C + c] = F16 ? acc[i][j][e] * (inv_dy * inv_x) : acc[i][j][e];
             }
         }
 #endif
@@ -391,7 +432,8 @@ extern "C" size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, i
 }
 
 extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
-                                    int C, int K, int R, int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream) {
+                                    int C, int K, int R, int S, int stride, int pad, const float *amax_x, const float *amax_dy,
+                                    void *ws, size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && dy && dw_krsc && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
     PPY_CHECK_ARG(x_ld >= C && dy_ld >= K);
@@ -401,6 +443,7 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     p.x = x; p.dy = dy; p.x_ld = x_ld; p.dy_ld = dy_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.P = N * Ho * Wo;
+    p.amax_x = amax_x; p.amax_dy = amax_dy;
     const int sl = wgrad_slices(K, C, R, S, p.P);
     const size_t need = sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
     if (need && (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0)) return PPY_ERR_WORKSPACE;
@@ -418,8 +461,10 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     p.out = slices > 1 ? (float *)ws : dw_krsc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ceil_div(K, WG_TK) * p.tiles_c, R * S, slices);
-    if (x3) {
-        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), 0, st, p);
+    if (x3 && amax_x && amax_dy) {
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(256), 0, st, p);
+    } else if (x3) {
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<false>, grid, dim3(256), 0, st, p);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
     }

@@ -209,7 +209,7 @@ extern "C" int ppy_dcnv2_backward_f32(const float *x, int x_ld, const float *w_k
     // (1) the columns again, (2) d w = dy^T . columns, (3) d columns = dy . w (over the columns buffer), (4) back through the sampling
     int rc = ppy_dcnv2_sample_f32(x, x_ld, offset_mask, om_ld, cols, N, H, W, C, Ho, Wo, stride, pad, stream);
     if (rc != PPY_OK) return rc;
-    rc = ppy_conv2d_wgrad_f32(cols, 9 * C, dy, dy_ld, dw_krsc, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, rest, rest_bytes, stream);
+    rc = ppy_conv2d_wgrad_f32(cols, 9 * C, dy, dy_ld, dw_krsc, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, nullptr, nullptr, rest, rest_bytes, stream);
     if (rc != PPY_OK) return rc;
     rc = ppy_conv2d_dgrad_f32(dy, dy_ld, w_krsc, cols, 9 * C, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, -1, 0, rest, rest_bytes, stream);
     if (rc != PPY_OK) return rc;

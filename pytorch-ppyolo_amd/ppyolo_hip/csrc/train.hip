@@ -201,28 +201,39 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float *part, in
         dgamma[c] = s_b[0][cl];
     }
 }
-// dx = gamma * invstd * (dz - (sum_dz + xhat * sum_dzx) / P)
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p) {
+// dx = gamma * invstd * (dz - (sum_dz + xhat * sum_dzx) / P); a workgroup owns a run of pixels, as bn_apply_kernel, so that the
+// optional per-image max|dx| (operand scale of an f16x2 weight gradient) costs one or two atomics per wave
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p, int pix_per_block, int hw, float *amax_out) {
     const int c4 = p.C >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)p.P * c4) return;
-    const int c = (int)(i % c4) * 4;
-    const long long q = i / c4;
-    const floatx4 x = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
-    const floatx4 dy = *reinterpret_cast<const floatx4 *>(p.dy + q * p.dy_ld + c);
-    const floatx4 y = *reinterpret_cast<const floatx4 *>(p.y + q * p.y_ld + c);
+    const long long q0 = (long long)blockIdx.x * pix_per_block;
+    const long long q1 = q0 + pix_per_block < p.P ? q0 + pix_per_block : p.P;
+    const long long total = (q1 - q0) * c4;
+    const int n_lo = (int)(q0 / hw), n_hi = (int)((q1 - 1) / hw);
+    const long long bnd = (long long)(n_lo + 1) * hw;
     const float invP = 1.0f / (float)p.P;
-    const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), isv = *reinterpret_cast<const floatx4 *>(p.invstd + c);
-    const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), sa = *reinterpret_cast<const floatx4 *>(p.sum_dz + c);
-    const floatx4 sb = *reinterpret_cast<const floatx4 *>(p.sum_dzx + c);
-    floatx4 o;
+    float amx_lo = 0.f, amx_hi = 0.f;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const int c = (int)(i % c4) * 4;
+        const long long q = q0 + i / c4;
+        const floatx4 x = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
+        const floatx4 dy = *reinterpret_cast<const floatx4 *>(p.dy + q * p.dy_ld + c);
+        const floatx4 y = *reinterpret_cast<const floatx4 *>(p.y + q * p.y_ld + c);
+        const floatx4 mu = *reinterpret_cast<const floatx4 *>(p.mean + c), isv = *reinterpret_cast<const floatx4 *>(p.invstd + c);
+        const floatx4 ga = *reinterpret_cast<const floatx4 *>(p.gamma + c), sa = *reinterpret_cast<const floatx4 *>(p.sum_dz + c);
+        const floatx4 sb = *reinterpret_cast<const floatx4 *>(p.sum_dzx + c);
+        floatx4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float xh = (x[k] - mu[k]) * isv[k];
-        const float dz = dy[k] * act_grad(y[k], p.act);
-        o[k] = ga[k] * isv[k] * (dz - (sa[k] + xh * sb[k]) * invP);
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (x[k] - mu[k]) * isv[k];
+            const float dz = dy[k] * act_grad(y[k], p.act);
+            o[k] = ga[k] * isv[k] * (dz - (sa[k] + xh * sb[k]) * invP);
+        }
+        *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+        const float rmx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        amx_lo = fmaxf(amx_lo, q < bnd ? rmx : 0.0f);
+        amx_hi = fmaxf(amx_hi, q < bnd ? 0.0f : rmx);
     }
-    *reinterpret_cast<floatx4 *>(p.out + q * p.out_ld + c) = o;
+    if (amax_out) amax_track2(amx_lo, amx_hi, n_lo, n_hi, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ---- activation backward alone (convolutions with bias and no BatchNorm have none in PP-YOLO; kept for completeness)
@@ -574,7 +585,7 @@ extern "C" int ppy_bn_train_apply_f32(const float *x, int x_ld, const float *mea
 
 extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, int y_ld, const float *dy, int dy_ld, const float *mean,
                                     const float *invstd, const float *gamma, float *dx, int dx_ld, float *dgamma, float *dbeta, int P,
-                                    int C, int act, void *ws, size_t ws_bytes, void *stream) {
+                                    int C, int act, int pixels_per_image, float *amax_dx, void *ws, size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && y && dy && mean && invstd && gamma && dx && dgamma && dbeta && P > 0 && C > 0 && C % 4 == 0);
     PPY_CHECK_ARG(x_ld >= C && y_ld >= C && dy_ld >= C && dx_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0);
@@ -590,7 +601,13 @@ extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((long long)P * (C / 4))), dim3(256), 0, st, p);
+    const int hw = amax_dx ? pixels_per_image : P;
+    if (amax_dx && (pixels_per_image <= 0 || P % pixels_per_image != 0)) return PPY_ERR_BAD_ARG;
+    int ppb = ceil_div(P, 4096);
+    const int floor_ppb = ceil_div(4096, C);
+    if (ppb < floor_ppb) ppb = floor_ppb;
+    if (ppb > hw) ppb = hw;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(P, ppb)), dim3(256), 0, st, p, ppb, hw, amax_dx);
     return ppy_launch_status();
 }
 

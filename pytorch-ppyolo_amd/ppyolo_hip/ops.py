@@ -152,8 +152,10 @@ def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None, cfg=-1, splitk=0):
     return ws
 
 
-def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None):
-    """x: View [N,H,W,C]; dy: View [N,Ho,Wo,K]; dw_krsc [K,R,S,C] (written).  See ppy_conv2d_wgrad_f32."""
+def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None, amax_x=None, amax_dy=None):
+    """x: View [N,H,W,C]; dy: View [N,Ho,Wo,K]; dw_krsc [K,R,S,C] (written); amax_x / amax_dy (both or neither): tracked per-image
+    maxima of the operands (amax_slots blocks) -> the f16x2 kernel.  See ppy_conv2d_wgrad_f32."""
+    assert (amax_x is None) == (amax_dy is None)
     _dev(x.t, dy.t, dw_krsc)
     K, R, S, C = dw_krsc.shape
     assert K == dy.C and C == x.C and dw_krsc.is_contiguous() and dw_krsc.dtype == torch.float32
@@ -161,7 +163,7 @@ def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None):
     if need and (ws is None or ws.numel() * ws.element_size() < need):
         ws = _bwd_ws(need, x.t.device)
     check(lib().ppy_conv2d_wgrad_f32(x.ptr, x.ld, dy.ptr, dy.ld, dw_krsc.data_ptr(), x.N, x.H, x.W, C, K, R, S, stride, pad,
-                                     _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream()),
+                                     _p(amax_x), _p(amax_dy), _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream()),
           'ppy_conv2d_wgrad_f32')
     return ws
 
@@ -192,13 +194,14 @@ def bn_train_apply(x, mean, invstd, gamma, beta, y, act=None, residual=None, ama
                                        y.ld, x.N * x.H * x.W, x.C, ACT[act], x.H * x.W, _p(amax_out), _stream()), 'ppy_bn_train_apply_f32')
 
 
-def bn_train_bwd(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, act=None, ws=None):
+def bn_train_bwd(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, act=None, ws=None, amax_dx=None):
+    """amax_dx: zeroed amax_slots(N) block that receives the per-image max|dx| (operand scale of an f16x2 weight gradient)."""
     _dev(x.t, y.t, dy.t, mean, invstd, gamma, dx.t, dgamma, dbeta)
     P = x.N * x.H * x.W
     ws = _ws_for(int(lib().ppy_bn_train_workspace_bytes(P, x.C)), ws, x.t.device)
     check(lib().ppy_bn_train_bwd_f32(x.ptr, x.ld, y.ptr, y.ld, dy.ptr, dy.ld, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                     dx.ptr, dx.ld, dgamma.data_ptr(), dbeta.data_ptr(), P, x.C, ACT[act], ws.data_ptr(),
-                                     ws.numel() * 4, _stream()), 'ppy_bn_train_bwd_f32')
+                                     dx.ptr, dx.ld, dgamma.data_ptr(), dbeta.data_ptr(), P, x.C, ACT[act], x.H * x.W, _p(amax_dx),
+                                     ws.data_ptr(), ws.numel() * 4, _stream()), 'ppy_bn_train_bwd_f32')
     return ws
 
 

@@ -388,14 +388,19 @@ class TrainStep(object):
             if res.req:
                 self.accum(res, dz)
             dy, act = dz, None
+        f16 = self.f16 and xin.amax is not None       # weight gradient on the f16x2 kernel: both operands' maxima are tracked
         if mean is not None:
             d_raw = self.new(raw.N, raw.H, raw.W, raw.C)
+            d_raw.amax = self.new_amax(raw.N) if f16 else None
             K.bn_train_bwd(raw.view(), y.view(), dy.view(), mean, invstd, self.param(prefix + '.bn.weight'), d_raw.view(),
-                           self.G[prefix + '.bn.weight'], self.G[prefix + '.bn.bias'], act, self.ws)
+                           self.G[prefix + '.bn.weight'], self.G[prefix + '.bn.bias'], act, self.ws, d_raw.amax)
         else:
             d_raw = dy
+            if f16 and d_raw.amax is None:
+                d_raw.amax = K.amax_slots(d_raw.t)      # (the loss gradient of an output convolution: three small tensors per step)
             K.channel_sum(dy.view(), self.G[prefix + '.conv.bias'], self.ws)
-        K.conv2d_wgrad(xin.view(), d_raw.view(), self.G[prefix + '.conv.weight'], stride, pad, self.ws)
+        K.conv2d_wgrad(xin.view(), d_raw.view(), self.G[prefix + '.conv.weight'], stride, pad, self.ws,
+                       xin.amax if f16 and d_raw.amax is not None else None, d_raw.amax if f16 else None)
         unit = 2 * raw.N * raw.H * raw.W * raw.C * ent['krsc'].shape[1] * ent['krsc'].shape[2] * ent['Cin']
         self.flops += unit
         if x.req:

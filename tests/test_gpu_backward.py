@@ -79,6 +79,29 @@ def test_wgrad_strided_and_channel_slices():
     assert _rel(dw.cpu().permute(0, 3, 1, 2), dw_ref) <= 2e-5
 
 
+def test_wgrad_f16x2_with_tracked_maxima():
+    """The weight gradient on the f16x2 kernel (two fp16 terms after ONE power-of-two scale per operand from the tracked
+    maxima, 3 MFMA products) against float64: not worse than the bf16x3 kernel, on operands with the dynamic range of real
+    gradients (a few large values, most tiny) and with images of very different magnitude."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(17)
+    for N, H, W, C, K, R, stride in ((4, 19, 19, 256, 512, 3, 1), (2, 38, 38, 288, 128, 1, 1), (3, 13, 10, 64, 48, 3, 2)):
+        pad = (R - 1) // 2
+        x = torch.randn(N, H, W, C, generator=g) * torch.tensor([1.0, 30.0, 0.02, 5.0][:N]).view(N, 1, 1, 1)
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        dy = torch.randn(N, Ho, Wo, K, generator=g) * torch.exp(torch.randn(N, Ho, Wo, K, generator=g) * 3.0) * 1e-4
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (K, C, R, R), dy.permute(0, 3, 1, 2).double(), stride=stride,
+                                          padding=pad).permute(0, 2, 3, 1)
+        xd, dyd = x.cuda(), dy.cuda()
+        err = {}
+        for name, kw in (('bf16x3', {}), ('f16x2', dict(amax_x=ops.amax_slots(xd), amax_dy=ops.amax_slots(dyd)))):
+            dw = torch.full((K, R, R, C), float('nan'), device='cuda')
+            ops.conv2d_wgrad(ops.View(xd), ops.View(dyd), dw, stride, pad, **kw)
+            err[name] = float((dw.cpu().double() - ref).abs().max() / ref.abs().max())
+        print('wgrad N%d %dx%d C%d K%d R%d s%d: max error / max|dw| vs float64: %s' % (N, H, W, C, K, R, stride, err))
+        assert err['f16x2'] <= max(2.0 * err['bf16x3'], 2e-6) and err['f16x2'] <= 1e-5
+
+
 def test_dgrad_refuses_stride2():
     from ppyolo_hip import ops
     from ppyolo_hip._lib import PPYoloHipError
