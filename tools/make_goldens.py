@@ -729,8 +729,55 @@ def g16_train_step_backbone():
         save('g16_train_' + tag, **arrs)
 
 
+def g17_paddle_names():
+    """SURVEY 8f rank 3, the optional Paddle checkpoint mapping: which PaddleDetection variable feeds which state_dict entry, taken
+    from the reference's converter scripts (1_ppyolo_2x_2pytorch.py:63-317, 1_ppyolo_r18vd_2pytorch.py) by RUNNING them on a
+    recording dict: `fluid.io.load_program_state` (paddle is not in this image; the scripts use it for exactly this one call,
+    which returns {variable name: ndarray}) is replaced by a dict that hands out a one-element array carrying the index of the
+    requested name, so that after the script every parameter / buffer it filled holds the index of its source.  Only the names
+    are pinned here -- no Paddle arithmetic is involved in the conversion."""
+    import runpy
+    import types
+
+    class Recorder(dict):
+        def __init__(self):
+            self.names = []
+
+        def __getitem__(self, k):
+            self.names.append(k)
+            return np.full((1,), len(self.names) - 1, np.float32)
+    out = {}
+    for tag, script, C in (('r50vd', '1_ppyolo_2x_2pytorch.py', PPYOLO_2x_Config), ('r18vd', '1_ppyolo_r18vd_2pytorch.py', PPYOLO_r18vd_Config)):
+        rec = Recorder()
+        paddle, fluid = types.ModuleType('paddle'), types.ModuleType('paddle.fluid')
+        fluid.io = types.SimpleNamespace(load_program_state=lambda path: rec)
+        paddle.fluid = fluid
+        sys.modules['paddle'], sys.modules['paddle.fluid'] = paddle, fluid
+        real_save, cwd = torch.save, os.getcwd()
+        kept = {}
+        torch.save = lambda obj, path: kept.__setitem__('sd', obj)
+        os.chdir('/tmp')
+        try:
+            runpy.run_path(os.path.join(REF, script), run_name='__main__')
+        finally:
+            torch.save = real_save
+            os.chdir(cwd)
+            del sys.modules['paddle'], sys.modules['paddle.fluid']
+        sd = kept['sd']
+        keys, names = [], []
+        for k, v in sd.items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            assert v.numel() == 1, (k, tuple(v.shape))          # every entry was filled by the script
+            keys.append(k)
+            names.append(rec.names[int(v.reshape(-1)[0])])
+        assert len(set(names)) == len(names) == len(rec.names)
+        out[tag + '.keys'], out[tag + '.paddle'] = np.array(keys), np.array(names)
+    save('g17_paddle_names', **out)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward, g16=g16_train_step_backbone)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward, g16=g16_train_step_backbone, g17=g17_paddle_names)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
