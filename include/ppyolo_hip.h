@@ -118,7 +118,8 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  *     no strided convolution).  Runs the forward implicit-GEMM kernels on the flipped / transposed weights; K need not
  *     be a multiple of 32 (the 258-channel output convolutions are zero-padded in the workspace).  cfg / splitk: tile
  *     configuration of that forward kernel for the geometry (N, Ho, Wo, C' = K rounded up to 32, K' = C), as in
- *     ppy_conv2d_bn_act_f32 (-1 / 0 = heuristic).
+ *     ppy_conv2d_bn_act_f32 (-1 / 0 = heuristic).  amax_dy (or NULL): tracked per-image maxima of dy -> the f16x2 kernels
+ *     (cfg then names an f16x2 tile), else bf16x3.
  *   ppy_conv2d_wgrad_f32: dw[k,r,s,c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
  *     (written, not accumulated; any stride / C / K).  bf16x3 on the 16-bit MFMA (exact fp32 MFMA where alignment rules it
  *     out); with amax_x / amax_dy -- tracked per-image maxima of both operands, as ppy_bn_train_apply_f32 / _bwd_f32 and the
@@ -127,8 +128,8 @@ int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride,
  * ws: ppy_conv2d_{dgrad,wgrad}_workspace_bytes() bytes, 256-byte aligned.
  */
 int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H, int W,
-                         int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, void *ws, size_t ws_bytes,
-                         void *stream);
+                         int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, const float *amax_dy, void *ws,
+                         size_t ws_bytes, void *stream);
 size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int cfg,
                                         int splitk);
 int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,

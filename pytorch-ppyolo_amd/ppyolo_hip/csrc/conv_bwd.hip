@@ -369,14 +369,15 @@ extern "C" size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, i
     if (stride != 1 || !bwd_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
     const int Kp = (K + 31) / 32 * 32;
     size_t b = align256((size_t)C * R * S * Kp * 4) + align256((size_t)C * 4) * 2;      // w', ones, zeros
-    b += align256((size_t)C * R * S * Kp * 6);                                          // three bf16 planes of w'
+    b += align256((size_t)C * R * S * Kp * 6);                                          // three bf16 planes of w' (or two fp16 planes)
+    b += align256((size_t)C * 4);                                                       // f16x2: epilogue scale with the weight scale folded in
     if (Kp != K) b += align256((size_t)g.M * Kp * 4);                                   // channel-padded dy
     return b + align256(ppy_conv2d_workspace_bytes(N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, cfg, splitk));
 }
 
 extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H,
-                                    int W, int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, void *ws,
-                                    size_t ws_bytes, void *stream) {
+                                    int W, int C, int K, int R, int S, int stride, int pad, int cfg, int splitk,
+                                    const float *amax_dy, void *ws, size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(dy && w_krsc && dx && N > 0 && C > 0 && K > 0 && dy_ld >= K && dx_ld >= C);
     if (stride != 1) return PPY_ERR_UNSUPPORTED;           // (the trainable head has no strided convolution)
@@ -396,12 +397,17 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     base += align256((size_t)C * 4);
     void *planes = base;
     base += align256((size_t)C * R * S * Kp * 6);
+    float *scale_f16 = (float *)base;
+    base += align256((size_t)C * 4);
     const long long total = (long long)C * R * S * Kp;
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_krsc, wt, ones, zeros,
                        K, Kp, R, S, C);
     int rc = ppy_launch_status();
     if (rc != PPY_OK) return rc;
-    rc = ppy_conv2d_split_weights_bf16x3(wt, total, planes, stream);
+    // amax_dy (tracked per-image maxima of dy, as ppy_bn_train_bwd_f32 records them): the f16x2 kernels -- w' as two fp16 planes
+    // scaled per output channel (= input channel of the layer), dy scaled per image; else the exact bf16x3 split
+    rc = amax_dy ? ppy_conv2d_split_weights_f16x2(wt, C, (long long)R * S * Kp, ones, planes, scale_f16, stream)
+                 : ppy_conv2d_split_weights_bf16x3(wt, total, planes, stream);
     if (rc != PPY_OK) return rc;
     const float *src = dy;
     int src_ld = dy_ld;
@@ -418,9 +424,9 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     }
     const size_t rest = ws_bytes - (size_t)(base - (char *)ws);
     // dy is [N, Ho, Wo, K]; for stride 1 the forward convolution with pad' = R-1-pad maps it back onto [N, H, W, C]
-    return ppy_conv2d_bn_act_f32(src, src_ld, wt, planes, nullptr, ones, nullptr, zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N,
-                                 g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, cfg, splitk, nullptr, nullptr, base, rest,
-                                 stream);
+    return ppy_conv2d_bn_act_f32(src, src_ld, wt, amax_dy ? nullptr : planes, amax_dy ? planes : nullptr, ones, amax_dy ? scale_f16 : nullptr,
+                                 zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0,
+                                 cfg, splitk, amax_dy, nullptr, base, rest, stream);
 }
 
 extern "C" size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {

@@ -211,7 +211,7 @@ extern "C" int ppy_dcnv2_backward_f32(const float *x, int x_ld, const float *w_k
     if (rc != PPY_OK) return rc;
     rc = ppy_conv2d_wgrad_f32(cols, 9 * C, dy, dy_ld, dw_krsc, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, nullptr, nullptr, rest, rest_bytes, stream);
     if (rc != PPY_OK) return rc;
-    rc = ppy_conv2d_dgrad_f32(dy, dy_ld, w_krsc, cols, 9 * C, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, -1, 0, rest, rest_bytes, stream);
+    rc = ppy_conv2d_dgrad_f32(dy, dy_ld, w_krsc, cols, 9 * C, N, Ho, Wo, 9 * C, K, 1, 1, 1, 0, -1, 0, nullptr, rest, rest_bytes, stream);
     if (rc != PPY_OK) return rc;
     if (hipMemset2DAsync(dx, (size_t)dx_ld * 4, 0, (size_t)C * 4, (size_t)N * H * W, st) != hipSuccess) return PPY_ERR_LAUNCH;
     const long long waves = (long long)N * Ho * Wo * 9;

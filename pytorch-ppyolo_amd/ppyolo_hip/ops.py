@@ -139,7 +139,7 @@ def _bwd_ws(nbytes, device):
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device)
 
 
-def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None, cfg=-1, splitk=0):
+def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None, cfg=-1, splitk=0, amax_dy=None):
     """dy: View [N,Ho,Wo,K]; w_krsc [K,R,S,C]; dx: View [N,H,W,C] (written).  See ppy_conv2d_dgrad_f32."""
     _dev(dy.t, w_krsc, dx.t)
     K, R, S, C = w_krsc.shape
@@ -148,7 +148,7 @@ def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None, cfg=-1, splitk=0):
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = _bwd_ws(need, dx.t.device)
     check(lib().ppy_conv2d_dgrad_f32(dy.ptr, dy.ld, w_krsc.data_ptr(), dx.ptr, dx.ld, dx.N, dx.H, dx.W, C, K, R, S, stride, pad,
-                                     cfg, splitk, ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_conv2d_dgrad_f32')
+                                     cfg, splitk, _p(amax_dy), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), 'ppy_conv2d_dgrad_f32')
     return ws
 
 

@@ -365,16 +365,18 @@ class TrainStep(object):
             self.acts[prefix] = y
         return y
 
-    def _dgrad(self, d_raw, krsc, dxin, stride, pad, cfg_id=-1, splitk=0):
-        """Data gradient of a convolution; stride > 1 as the stride-1 data gradient of the zero-inserted output gradient."""
+    def _dgrad(self, d_raw, krsc, dxin, stride, pad, cfg_id=-1, splitk=0, f16=False):
+        """Data gradient of a convolution; stride > 1 as the stride-1 data gradient of the zero-inserted output gradient.
+        f16: on the f16x2 kernels, scaled by the tracked maxima of d_raw."""
+        amax = d_raw.amax if f16 else None
         if stride == 1:
-            K.conv2d_dgrad(d_raw.view(), krsc, dxin.view(), 1, pad, self.ws, cfg=cfg_id, splitk=splitk)
+            K.conv2d_dgrad(d_raw.view(), krsc, dxin.view(), 1, pad, self.ws, cfg=cfg_id, splitk=splitk, amax_dy=amax)
             return
         R = krsc.shape[1]
         H1, W1 = dxin.H + 2 * pad - R + 1, dxin.W + 2 * pad - R + 1
         up = self.new(d_raw.N, H1, W1, d_raw.C, ld=_r32(d_raw.C), zero=d_raw.C % 32 != 0)
         K.zero_insert(d_raw.view(), up.view(), stride)
-        K.conv2d_dgrad(up.view(), krsc, dxin.view(), 1, pad, self.ws)
+        K.conv2d_dgrad(up.view(), krsc, dxin.view(), 1, pad, self.ws, amax_dy=amax)       # (zeros do not raise the maximum)
 
     def _conv_unit_bwd(self, prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res=None):
         dy = y.g
@@ -408,13 +410,15 @@ class TrainStep(object):
             dxin = self.new(xin.N, xin.H, xin.W, xin.C)
             Kk, R = ent['krsc'].shape[0], ent['krsc'].shape[1]
 
+            df16 = self.f16 and d_raw.amax is not None
             if stride == 1:
                 def run(cfg_id, splitk):
-                    self._dgrad(d_raw, ent['krsc'], dxin, 1, pad, cfg_id, splitk)
+                    self._dgrad(d_raw, ent['krsc'], dxin, 1, pad, cfg_id, splitk, df16)
                 # the data gradient runs the forward kernel on the transposed geometry: C' = K rounded up to 32, K' = C
-                run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32))
+                run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32,
+                                  df16))
             else:
-                self._dgrad(d_raw, ent['krsc'], dxin, stride, pad)
+                self._dgrad(d_raw, ent['krsc'], dxin, stride, pad, f16=df16)
             self.accum(x, dxin.slice(0, x.C))
 
     def _dcn_unit(self, prefix, x, stride, act):

@@ -102,6 +102,28 @@ def test_wgrad_f16x2_with_tracked_maxima():
         assert err['f16x2'] <= max(2.0 * err['bf16x3'], 2e-6) and err['f16x2'] <= 1e-5
 
 
+def test_dgrad_f16x2_with_tracked_maxima():
+    """The data gradient on the f16x2 kernels (dy scaled per image by its tracked maximum, the flipped weights per channel)
+    against float64: at the level of the bf16x3 path, incl. a 258-channel dy (padded copy) and images of very different scale."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(23)
+    for N, H, W, C, K, R in ((4, 19, 19, 512, 258, 1), (2, 38, 38, 256, 512, 3), (3, 16, 12, 96, 64, 3)):
+        pad = (R - 1) // 2
+        w = torch.randn(K, C, R, R, generator=g) * (1.0 / (C * R * R)) ** 0.5
+        dy = torch.randn(N, K, H, W, generator=g) * torch.tensor([1.0, 300.0, 0.003, 20.0][:N]).view(N, 1, 1, 1) * 1e-3
+        ref = torch.nn.grad.conv2d_input((N, C, H, W), w.double(), dy.double(), stride=1, padding=pad).permute(0, 2, 3, 1)
+        dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        err = {}
+        for name, kw in (('bf16x3', {}), ('f16x2', dict(amax_dy=ops.amax_slots(dyd)))):
+            dx = torch.full((N, H, W, C), float('nan'), device='cuda')
+            ops.conv2d_dgrad(ops.View(dyd), wk, ops.View(dx), 1, pad, **kw)
+            # per image: every image is scaled on its own
+            err[name] = max(float((dx[n].cpu().double() - ref[n]).abs().max() / ref[n].abs().max()) for n in range(N))
+        print('dgrad N%d %dx%d C%d K%d R%d: max error / max|dx| per image vs float64: %s' % (N, H, W, C, K, R, err))
+        assert err['f16x2'] <= max(2.0 * err['bf16x3'], 2e-6) and err['f16x2'] <= 1e-5
+
+
 def test_dgrad_refuses_stride2():
     from ppyolo_hip import ops
     from ppyolo_hip._lib import PPYoloHipError
