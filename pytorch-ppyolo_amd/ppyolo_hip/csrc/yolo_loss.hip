@@ -19,6 +19,7 @@ namespace {
 struct LossArgs {
     const float *out, *target, *gt;
     float *dout, *part;
+    float *amax_dout;      // per-image max|dout| slots (operand scale of the f16x2 gradient kernels of the output convolution) or NULL
     int out_ld, dout_ld;
     int N, S, an, C, G, iou_aware;
     float aw[4], ah[4];
@@ -33,13 +34,20 @@ __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f :
 
 __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
     const int cells = p.S * p.S;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)p.N * p.an * cells) return;
+    const long long total = (long long)p.N * p.an * cells;
+    // (threads past the end redo the last element -- identical values to identical addresses -- so that whole waves reach
+    // the maximum reduction at the end)
+    const long long i = min((long long)blockIdx.x * 256 + threadIdx.x, total - 1);
     const int cell = (int)(i % cells), a = (int)((i / cells) % p.an), n = (int)(i / ((long long)cells * p.an));
     const int h = cell / p.S, w = cell - h * p.S;
     const float S = (float)p.S;
     const float *o = p.out + (((long long)n * p.S + h) * p.S + w) * p.out_ld;
     float *d = p.dout + (((long long)n * p.S + h) * p.S + w) * p.dout_ld;
+    float dmax = 0.f;
+    auto put = [&](int idx, float v) {
+        d[idx] = v;
+        dmax = fmaxf(dmax, fabsf(v));
+    };
     const int base = (p.iou_aware ? p.an : 0) + a * (5 + p.C);
     const float *t = p.target + ((long long)(n * p.an + a) * (6 + p.C)) * cells + cell;
     const float tx = t[0], ty = t[cells], tw = t[2 * cells], th = t[3 * cells], tscale = t[4 * cells], tobj = t[5 * cells];
@@ -145,17 +153,18 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
     for (int c = 0; c < p.C; ++c) {
         const float sc = sigm(o[base + 5 + c]), tc = t[(long long)(6 + c) * cells];
         l_cls += tc * (0.f - logf(sc + 1e-9f)) + (1.f - tc) * (0.f - logf(1.f - sc + 1e-9f));
-        d[base + 5 + c] = tobj * (-tc / (sc + 1e-9f) + (1.f - tc) / (1.f - sc + 1e-9f)) * sc * (1.f - sc) * p.inv_n;
+        put(base + 5 + c, tobj * (-tc / (sc + 1e-9f) + (1.f - tc) / (1.f - sc + 1e-9f)) * sc * (1.f - sc) * p.inv_n);
     }
     l_cls *= tobj;
-    d[base] = g_x * p.inv_n;
-    d[base + 1] = g_y * p.inv_n;
-    d[base + 2] = g_w * p.inv_n;
-    d[base + 3] = g_h * p.inv_n;
-    d[base + 4] = g_obj * p.inv_n;
-    if (p.iou_aware) d[a] = g_ioup * p.inv_n;
+    put(base, g_x * p.inv_n);
+    put(base + 1, g_y * p.inv_n);
+    put(base + 2, g_w * p.inv_n);
+    put(base + 3, g_h * p.inv_n);
+    put(base + 4, g_obj * p.inv_n);
+    if (p.iou_aware) put(a, g_ioup * p.inv_n);
     float *lp = p.part + i * 6;
     lp[0] = l_xy; lp[1] = l_wh; lp[2] = l_obj; lp[3] = l_cls; lp[4] = l_iou; lp[5] = l_ia;
+    if (p.amax_dout) amax_track(dmax, n, p.amax_dout, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // loss[j] = inv_n * sum over the cells, fixed order: one workgroup, strided partial sums, tree
@@ -184,14 +193,15 @@ extern "C" size_t ppy_yolov3_loss_workspace_bytes(int N, int S, int an) { return
 extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const float *target, const float *gt_box, int num_gt,
                                    const float *h_anchors_px, int an, int num_classes, int N, int S, int downsample, double scale_x_y,
                                    double ignore_thresh, double iou_loss_weight, int iou_aware, double iou_aware_loss_weight,
-                                   float *dout, int dout_ld, float *loss6, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+                                   float *dout, int dout_ld, float *loss6, int accumulate, float *amax_dout, void *ws, size_t ws_bytes,
+                                   void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(head_out && target && gt_box && h_anchors_px && dout && loss6 && N > 0 && S > 0 && an > 0 && an <= 4 && num_classes > 0);
     const int nch = an * (5 + num_classes) + (iou_aware ? an : 0);
     PPY_CHECK_ARG(out_ld >= nch && dout_ld >= nch && num_gt >= 0 && downsample > 0);
     if (!ws || ws_bytes < ppy_yolov3_loss_workspace_bytes(N, S, an)) return PPY_ERR_WORKSPACE;
     LossArgs p;
-    p.out = head_out; p.target = target; p.gt = gt_box; p.dout = dout; p.part = (float *)ws;
+    p.out = head_out; p.target = target; p.gt = gt_box; p.dout = dout; p.part = (float *)ws; p.amax_dout = amax_dout;
     p.out_ld = out_ld; p.dout_ld = dout_ld; p.N = N; p.S = S; p.an = an; p.C = num_classes; p.G = num_gt; p.iou_aware = iou_aware ? 1 : 0;
     for (int a = 0; a < an; ++a) {
         p.aw[a] = h_anchors_px[2 * a];

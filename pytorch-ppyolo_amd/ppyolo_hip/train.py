@@ -700,10 +700,12 @@ class TrainStep(object):
             for i, out in enumerate(outs):
                 anchors = [hcfg['anchors'][m] for m in hcfg['anchor_masks'][i]]
                 dout = Act(torch.zeros_like(out.t), 0, out.C)
+                if self.f16 and inject_douts is None:
+                    dout.amax = self.new_amax(out.N)          # the loss kernel records max|dout| per image
                 K.yolov3_loss(out.view(), targets[i].float().contiguous(), gt_box.float().contiguous(), anchors, hcfg['num_classes'],
                               hcfg['downsample'][i], cfg.yolo_loss['scale_x_y'], cfg.yolo_loss['ignore_thresh'], cfg.iou_loss['loss_weight'],
                               iou_aware, cfg.iou_aware_loss['loss_weight'] if iou_aware else 0.0, dout.view(), loss6, accumulate=i > 0,
-                              ws=self.ws)
+                              ws=self.ws, amax_dout=dout.amax)
                 if inject_douts is not None:
                     dout.t[..., :out.C].copy_(inject_douts[i].to(self.dev).permute(0, 2, 3, 1))
                 out.g = dout

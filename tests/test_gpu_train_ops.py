@@ -145,8 +145,11 @@ def test_loss_and_dout_match_the_reference_step(golden, tag):
         anchors = [hc['anchors'][m] for m in hc['anchor_masks'][i]]
         ops.yolov3_loss(ops.View(ob, 0, nch), torch.from_numpy(g['target%d' % i]).cuda(), gt, anchors, 80, hc['downsample'][i],
                         cfg.yolo_loss['scale_x_y'], cfg.yolo_loss['ignore_thresh'], cfg.iou_loss['loss_weight'], hc['iou_aware'],
-                        cfg.iou_aware_loss['loss_weight'] if hc['iou_aware'] else 0.0, ops.View(db, 0, nch), loss6, accumulate=i > 0)
+                        cfg.iou_aware_loss['loss_weight'] if hc['iou_aware'] else 0.0, ops.View(db, 0, nch), loss6, accumulate=i > 0,
+                        amax_dout=(amax := ops.amax_slots(device='cuda', N=N)))
         torch.cuda.synchronize()
+        # the tracked per-image maximum of the gradient (operand scale of the f16x2 gradient kernels) is exactly max|dout|
+        assert torch.equal(amax.view(N, -1).amax(dim=1), db.reshape(N, -1).abs().amax(dim=1))
         want = torch.from_numpy(g['dout%d' % i])
         e = rel(nchw(db[..., :nch]), want)
         assert e <= 2e-5, 'level %d: d loss / d head output off by %.3e of its maximum' % (i, e)
