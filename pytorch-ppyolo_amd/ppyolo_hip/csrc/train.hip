@@ -128,9 +128,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p, int pix_p
     const int n_lo = (int)(q0 / hw), n_hi = (int)((q1 - 1) / hw);
     const long long bnd = (long long)(n_lo + 1) * hw;
     float amx_lo = 0.f, amx_hi = 0.f;
+    // (element i = (pixel, channel group): advanced by 256 per iteration without a division in the loop)
+    const int dq = 256 / c4, dr = 256 - dq * c4;
+    int cg = (int)(threadIdx.x % c4);
+    long long q = q0 + threadIdx.x / c4;
     for (long long i = threadIdx.x; i < total; i += 256) {
-        const int c = (int)(i % c4) * 4;
-        const long long q = q0 + i / c4;
+        const int c = cg * 4;
         const floatx4 v = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
         floatx4 r = {0.f, 0.f, 0.f, 0.f};
         if (p.res) r = *reinterpret_cast<const floatx4 *>(p.res + q * p.res_ld + c);
@@ -143,6 +146,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs p, int pix_p
         const float rmx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
         amx_lo = fmaxf(amx_lo, q < bnd ? rmx : 0.0f);
         amx_hi = fmaxf(amx_hi, q < bnd ? 0.0f : rmx);
+        q += dq;
+        cg += dr;
+        if (cg >= c4) { cg -= c4; ++q; }
     }
     if (amax_out) amax_track2(amx_lo, amx_hi, n_lo, n_hi, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
@@ -212,9 +218,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p, int p
     const long long bnd = (long long)(n_lo + 1) * hw;
     const float invP = 1.0f / (float)p.P;
     float amx_lo = 0.f, amx_hi = 0.f;
+    const int dq = 256 / c4, dr = 256 - dq * c4;
+    int cg = (int)(threadIdx.x % c4);
+    long long q = q0 + threadIdx.x / c4;
     for (long long i = threadIdx.x; i < total; i += 256) {
-        const int c = (int)(i % c4) * 4;
-        const long long q = q0 + i / c4;
+        const int c = cg * 4;
         const floatx4 x = *reinterpret_cast<const floatx4 *>(p.x + q * p.x_ld + c);
         const floatx4 dy = *reinterpret_cast<const floatx4 *>(p.dy + q * p.dy_ld + c);
         const floatx4 y = *reinterpret_cast<const floatx4 *>(p.y + q * p.y_ld + c);
@@ -232,6 +240,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs p, int p
         const float rmx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
         amx_lo = fmaxf(amx_lo, q < bnd ? rmx : 0.0f);
         amx_hi = fmaxf(amx_hi, q < bnd ? 0.0f : rmx);
+        q += dq;
+        cg += dr;
+        if (cg >= c4) { cg -= c4; ++q; }
     }
     if (amax_out) amax_track2(amx_lo, amx_hi, n_lo, n_hi, amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
 }

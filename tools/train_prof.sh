@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of the training step (bench.py --train), per step.  usage: tools/train_prof.sh [out.txt] [steps]
 OUT=${1:-/root/repo/gpurun_out/train_kernel_stats.txt}; STEPS=${2:-5}
+mkdir -p "$(dirname "$OUT")"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tprof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tprof -o t -- python /root/repo/bench.py --train --steps $STEPS --warmup 2 > /tmp/tprof_bench.json 2>/dev/null
 python - "$OUT" $((STEPS + 2)) <<'P'
