@@ -25,7 +25,9 @@ struct BnArgs {
 // ---- forward statistics: per channel (n, mean, M2) of a pixel slice.  256 threads = 16 pixel lanes x 16 groups of 4 channels
 // (16-byte loads).  Two passes over the slice -- its mean first, then the squared deviations from it (the slice is a few dozen
 // KB, so the second pass is served by L2) -- which is as accurate as Welford's update without a division per element; slices
-// are merged with Chan's formula.
+// are merged with Chan's formula.  (Measured alternative: ONE pass with every thread shifting by its own first sample and a
+// Chan merge of the 16 pixel lanes -- 16.07 instead of 16.13 ms per R50 step, the second pass costs that little, and noisier
+// gradients in tests/test_gpu_train_step.py; not kept.)
 __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const BnArgs p) {
     __shared__ float s_1[16][BN_CH], s_mean[BN_CH];
     const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;
