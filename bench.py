@@ -451,14 +451,17 @@ def train_bench(a, wl, dev, rank, world):
                    config=dict(workload='%s %dx%d training step (reference train.py:416-443, freeze_at=%d), %d images per '
                                         'GPU' % (wl['model'], S, S, ts.freeze_at, a.batch), global_batch=world * a.batch,
                                parallelism=('data parallel x%d, one all-reduce of %.1f MB of gradients per step' % (world, ts.gflat.numel() * 4 / 1e6))
-                               if world > 1 else 'single GPU', math='bf16x3 (exact 3-term bf16 split, fp32 accumulate) for every convolution, '
-                               'bf16x3 weight gradients (LDS-transposed operands)', eager=True),
+                               if world > 1 else 'single GPU',
+                               math=('f16x2 (two fp16 terms after power-of-two scaling by tracked maxima, 3 MFMA products, fp32 accumulate) for the '
+                                     'forward convolutions, the data and the weight gradients' if ts.f16 else
+                                     'bf16x3 (exact 3-term bf16 split, 6 products) for every convolution and gradient'), eager=True),
                    loss_first=round(tot[0], 4), loss_last=round(tot[-1], 4),
-                   roofline=dict(bound='mfma', achieved=round(ach, 2), peak=round(X3_PEAK_TFLOPS, 1), unit='TFLOP/s',
-                                 frac=round(ach / X3_PEAK_TFLOPS, 4), traffic=None, flops_per_step=flops,
-                                 kernel='conv_igemm_x3_kernel<*> (bf16x3) forward + dgrad, conv_wgrad_x3_kernel (bf16x3)',
-                                 peak_note='achieved = algorithmic convolution FLOPs of forward + head backward / WHOLE step time (BatchNorm, loss, '
-                                           'SGD and launch gaps included: the step is not graph-captured yet); peak = dense bf16 MFMA / 6'))
+                   roofline=dict(bound='mfma', achieved=round(ach, 2), peak=round(F16X2_PEAK_TFLOPS if ts.f16 else X3_PEAK_TFLOPS, 1), unit='TFLOP/s',
+                                 frac=round(ach / (F16X2_PEAK_TFLOPS if ts.f16 else X3_PEAK_TFLOPS), 4), traffic=None, flops_per_step=flops,
+                                 kernel='conv_igemm_x3_kernel<*> forward + dgrad, conv_wgrad_x3_kernel<F16> (%s)' % ('f16x2' if ts.f16 else 'bf16x3'),
+                                 peak_note='achieved = algorithmic convolution FLOPs of forward + backward / WHOLE step time (BatchNorm, loss, '
+                                           'SGD, EMA and launch gaps included: the step is not graph-captured); peak = dense 16-bit MFMA / %d '
+                                           'products per multiply-add' % (3 if ts.f16 else 6)))
         print(json.dumps(out), flush=True)
 
 
