@@ -450,7 +450,9 @@ def train_bench(a, wl, dev, rank, world):
                    data='synthetic (randn images, synthetic boxes through Gt2YoloTarget, deterministic random weights)',
                    config=dict(workload='%s %dx%d training step (reference train.py:416-443, freeze_at=%d), %d images per '
                                         'GPU' % (wl['model'], S, S, ts.freeze_at, a.batch), global_batch=world * a.batch,
-                               parallelism=('data parallel x%d, one all-reduce of %.1f MB of gradients per step' % (world, ts.gflat.numel() * 4 / 1e6))
+                               parallelism=('data parallel x%d, %.1f MB of gradients per step averaged in %d collectives started during the backward '
+                                            '(one per finished bucket range)' % (world, ts.gflat.numel() * 4 / 1e6,
+                                                                                  sum(len(v['ranges']) for v in ts._buckets.values()) if ts._buckets else 1))
                                if world > 1 else 'single GPU',
                                math=('f16x2 (two fp16 terms after power-of-two scaling by tracked maxima, 3 MFMA products, fp32 accumulate) for the '
                                      'forward convolutions, the data and the weight gradients' if ts.f16 else

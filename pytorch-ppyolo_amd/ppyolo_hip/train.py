@@ -10,7 +10,7 @@ gt_score, targets)`, `all_loss.backward()`, `optimizer.step()` -- as a sequence 
   * backward through the head only (freeze_at = 5 in both configs): BatchNorm / LeakyReLU backward, conv wgrad and dgrad
     (csrc/conv_bwd.hip), nearest-upsample, SPP and DropBlock backward -- a tape recorded during the forward, replayed in
     reverse;
-  * one RCCL all-reduce of ALL gradients (they live in one flat buffer) when several ranks train data-parallel, then
+  * RCCL all-reduces of the gradients (one flat buffer, bucket by bucket as the backward finishes them) when several ranks train data-parallel, then
     SGD-momentum with the reference's parameter groups (weight decay on convolution weights only: custom_layers.py:167-215).
 
 The convolutions run on the exact bf16x3 split (no tracked maxima needed); torch supplies memory, streams and
@@ -151,6 +151,8 @@ class TrainStep(object):
             with open(TRAIN_TABLE_F16) as fh:
                 self._tuned_f.update(json.load(fh))
         self._amax_arena, self._amax_next = None, 0
+        self.overlap = os.environ.get('PPYOLO_HIP_TRAIN_OVERLAP', '1') != '0' and not self.external
+        self._buckets, self._pending, self._works, self._reduced = None, {}, [], []
         self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
         self._measured = {}
         self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
@@ -360,7 +362,10 @@ class TrainStep(object):
             K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
                              None if res is None else res.view(), y.amax)
         if trainable:
-            self.tape.append(lambda: self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res))
+            def bwd_unit():
+                self._conv_unit_bwd(prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res)
+                self._grads_done(prefix)
+            self.tape.append(bwd_unit)
         if self.acts is not None:          # debugging / tests: activations (and, after the backward, their gradients) by layer
             self.acts[prefix] = y
         return y
@@ -469,6 +474,7 @@ class TrainStep(object):
                 dxo = self.new(x.N, x.H, x.W, x.C)
                 self._dgrad(d_om, co['krsc'], dxo, stride, 1)
                 self.accum(x, dxo)
+            self._grads_done(prefix)
         if trainable:
             self.tape.append(bwd)
         return y
@@ -509,6 +515,7 @@ class TrainStep(object):
                 g = self.G[p + '.conv.weight']
                 g.zero_()
                 g[..., :3] = dw3
+                self._grads_done(p)
             self.tape.append(bwd)
         y = self.conv_unit('backbone.stage1_conv1_2', y0, 1, 'relu')
         y = self.conv_unit('backbone.stage1_conv1_3', y, 1, 'relu')
@@ -715,11 +722,81 @@ class TrainStep(object):
         self.tape = []
         return loss6
 
+    # ---- data parallelism: gradient averaging overlapped with the backward --------------------------------------------------------
+    @staticmethod
+    def _bucket_of(key):
+        """Gradient bucket of a parameter: a detection block, the head's output / transition convolutions, a backbone stage --
+        the units in which the backward finishes its gradients (last layers first)."""
+        q = key.split('.')
+        if q[0] == 'backbone':
+            return q[1][:6]                      # 'stage5'
+        return '.'.join(q[:3]) if q[1] == 'detection_blocks' else 'head.tail'
+
+    def _make_buckets(self):
+        """{bucket: [pending unit count, [(start, end) ranges of gflat]]}: the keys of a bucket are (nearly) contiguous in
+        both parameter groups of the flat layout, so a bucket is two or three ranges."""
+        base = self.gflat.data_ptr()
+        spans, units = {}, {}
+        for k in self.train_keys:
+            b = self._bucket_of(k)
+            o = (self.G[k].data_ptr() - base) // 4
+            spans.setdefault(b, []).append((o, o + (self.G[k].numel() + 63) // 64 * 64))
+            units.setdefault(b, set()).add(self._unit_of(k))
+        self._buckets = {}
+        for b, iv in spans.items():
+            iv.sort()
+            merged = [list(iv[0])]
+            for a, e in iv[1:]:
+                if a <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], e)
+                else:
+                    merged.append([a, e])
+            self._buckets[b] = dict(units=units[b], ranges=[(a, min(e, self.gflat.numel())) for a, e in merged])
+
+    @staticmethod
+    def _unit_of(key):
+        """The Conv2dUnit prefix a parameter key belongs to ('....conv.weight' / '.bn.bias' / '.conv.conv_offset.bias' ...)."""
+        for tail in ('.conv.conv_offset.weight', '.conv.conv_offset.bias', '.conv.dcn_weight', '.conv.weight', '.conv.bias', '.bn.weight',
+                     '.bn.bias'):
+            if key.endswith(tail):
+                return key[:-len(tail)]
+        return key
+
+    def _grads_done(self, prefix):
+        """All gradients of unit `prefix` are written: when that completes a bucket, start its all-reduce while the rest of
+        the backward runs (the collective is queued behind the kernels issued so far and proceeds on RCCL's own stream)."""
+        if self.world <= 1 or not self.overlap or self.gflat is None:
+            return
+        if self._buckets is None:
+            self._make_buckets()
+        if not self._pending:
+            self._pending = {b: set(v['units']) for b, v in self._buckets.items()}
+        b = self._bucket_of(prefix + '.conv.weight')
+        left = self._pending.get(b)
+        if left is None:
+            return
+        left.discard(prefix)
+        if not left:
+            del self._pending[b]
+            for a, e in self._buckets[b]['ranges']:
+                self._works.append(torch.distributed.all_reduce(self.gflat[a:e], async_op=True))
+            self._reduced.append(b)
+
     def all_reduce(self):
-        """Data-parallel ranks: average ALL gradients with one collective (RCCL over xGMI; BatchNorm stays per GPU, like
-        the reference's 'sync_bn' -> 'bn' alias, model/custom_layers.py:28-29)."""
+        """Data-parallel ranks: average ALL gradients (RCCL over xGMI; BatchNorm stays per GPU, like the reference's
+        'sync_bn' -> 'bn' alias, model/custom_layers.py:28-29).  Buckets whose gradients were complete during the backward are
+        already in flight (_grads_done); whatever is left goes in one collective; PPYOLO_HIP_TRAIN_OVERLAP=0: one collective
+        for everything, after the backward."""
         if self.world > 1:
-            torch.distributed.all_reduce(self.gflat)
+            if self._works:
+                rest = [r for b, v in self._buckets.items() if b not in self._reduced for r in v['ranges']]
+                for a, e in rest:
+                    self._works.append(torch.distributed.all_reduce(self.gflat[a:e], async_op=True))
+                for w in self._works:
+                    w.wait()
+            else:
+                torch.distributed.all_reduce(self.gflat)
+            self._works, self._reduced, self._pending = [], [], {}
             self.gflat.mul_(1.0 / self.world)
 
     def sgd(self, lr):

@@ -94,6 +94,9 @@ def test_train_step_two_ranks_average_their_gradients(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 8 and 'TRAIN' in line['metric'] and np.isfinite(line['loss_last'])
+    # the averaging ran as several collectives started during the backward (one per finished bucket range), not one at the end
+    import re
+    assert int(re.search(r'averaged in (\d+) collectives', line['config']['parallelism']).group(1)) >= 3, line['config']['parallelism']
     singles = []
     for off in (0, 1):
         f = str(tmp_path / ('g1_%d.npy' % off))
