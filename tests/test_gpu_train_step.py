@@ -325,3 +325,35 @@ def test_train_step_with_backbone_stages(cfgc, S, fa):
     ts.sync_to_model()
     k0 = bb[0]
     assert not torch.equal(model.state_dict()[k0].cpu(), sd[k0])
+
+
+def test_multi_scale_steps():
+    """The reference trains at a different input size every few iterations (config/ppyolo_2x.py: random shapes 320..608): the same
+    TrainStep takes batches of different sizes and batch counts back to back; loss and every gradient stay finite, the parameters
+    move, and a size seen before gives the same loss for the same parameters (no state leaks between shapes)."""
+    from ppyolo_hip.train import TrainStep
+    from ppyolo_hip.targets import gt2yolo_target, synth_ground_truth
+    cfg = PPYOLO_2x_Config()
+    model, sd = build_model(cfg, 0, 'cuda')
+    cfg.head['drop_active'] = False
+    ts = TrainStep(model, cfg)
+    hc = cfg.head
+
+    def batch(N, S, seed):
+        bb, cc, ss = synth_ground_truth(N, seed)
+        tg = [torch.from_numpy(t).cuda() for t in gt2yolo_target(bb, cc, ss, hc['anchors'], hc['anchor_masks'], hc['downsample'], 80, S)]
+        return synth.synth_images(N, S, seed=seed).cuda(), torch.from_numpy(bb).cuda(), tg
+    first = None
+    for N, S, seed in ((2, 320, 1), (3, 416, 2), (1, 352, 3), (2, 320, 1)):
+        x, gt, tg = batch(N, S, seed)
+        loss6 = ts.forward_backward(x, gt, tg)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss6).all() and float(loss6.sum()) > 0
+        assert torch.isfinite(ts.gflat).all() and float(ts.gflat.abs().max()) > 0
+        if first is None:
+            first = loss6.clone()
+    # the last batch repeats the first with unchanged parameters (no sgd() in between): identical loss terms
+    assert torch.equal(loss6, first)
+    ts.sgd(1e-3)
+    x, gt, tg = batch(2, 320, 1)
+    assert not torch.equal(ts.forward_backward(x, gt, tg), first)
