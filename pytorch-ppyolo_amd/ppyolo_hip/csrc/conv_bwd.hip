@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 // stores [plane][channel][pixel] bf16 with 8-byte LDS writes; a fragment is then one 16-byte LDS read per plane
 // (row pitch 80 B: conflict-free for the 16-lane groups of ds_read_b128).  One LDS buffer, two barriers per step; two
 // workgroups per CU overlap each other's store / MFMA phases.  Tile 128 (k) x 128 (c) of one tap over a pixel slice.
+// (Measured and not kept: global loads TWO steps ahead in a second register set -- 102 instead of 96 us per launch on the R50 head,
+// the loop is bound by the split + LDS store + barrier phase, not by the latency of the loads.)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned uintx4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned uintx2_t;
