@@ -108,6 +108,19 @@ int ppy_conv2d_num_configs(void);
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);
 
+/* The HBM-bound 1x1 "expand" convolutions (ResNet-vd BottleNeck conv3 + shortcut + ReLU, reference
+ * model/resnet_vd.py:55-91; C64 -> K256 at 152x152 moves 425 MB for 6 GFLOP) as a persistent streaming kernel
+ * (csrc/conv_stream.hip): 1x1, stride 1, C == 64, K % 64 == 0, f16x2 operands (w_f16x2 / scale_f16x2 / amax_in as above),
+ * results bit-identical to the f16x2 tiles of ppy_conv2d_bn_act_f32.  The same kernel is selectable there as the LAST
+ * ppy_conv2d_num_configs() - 2 .. - 1 cfg ids (variant 0: two workgroups per CU, 1: one); this entry point adds the second
+ * output: pooled (or NULL) = [N][H/2][W/2] rows of ld pooled_ld holding the 2x2 / stride-2 average of y -- the AvgPool2d(2, 2)
+ * in front of the vd projection shortcut (reference model/resnet_vd.py:29-33) written from the same epilogue, evaluated
+ * (((a + b) + c) + d) * 0.25 exactly as ppy_avgpool2x2_f32 does (H, W even).  PPY_ERR_BAD_ARG for any other geometry:
+ * there is no silent fall-back to another kernel. */
+int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *shift,
+                           const float *residual, int res_ld, float *y, int y_ld, float *pooled, int pooled_ld, int N, int H,
+                           int W, int C, int K, int act, int variant, const float *amax_in, float *amax_out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Backward of the convolution -- training step, SURVEY 8f rank 2 / BASELINE config 5: what torch autograd computes for
  * the F.conv2d inside Conv2dUnit.forward (reference model/custom_layers.py:243-253) when train.py:441 calls

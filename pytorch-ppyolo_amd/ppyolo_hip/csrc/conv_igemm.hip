@@ -519,8 +519,9 @@ void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
 
 }  // namespace
 
-// configuration ids [kNumCfgs, kNumCfgs + ppy_x3_num_configs()) select the split-bf16 kernels of conv_x3.hip
-extern "C" int ppy_conv2d_num_configs(void) { return kNumCfgs + ppy_x3_num_configs(); }
+// configuration ids [kNumCfgs, kNumCfgs + ppy_x3_num_configs()) select the split-bf16 kernels of conv_x3.hip, the ids after
+// them the streaming kernel of conv_stream.hip (1x1, C = 64, f16x2 operands)
+extern "C" int ppy_conv2d_num_configs(void) { return kNumCfgs + ppy_x3_num_configs() + ppy_stream_num_configs(); }
 
 extern "C" int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                int *cfg_out, int *splitk_out) {
@@ -534,7 +535,7 @@ extern "C" int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, 
 }
 
 static int resolve(const Geometry &g, int K, int cfg, int splitk, int *c, int *s) {
-    if (cfg >= kNumCfgs + ppy_x3_num_configs()) return PPY_ERR_BAD_ARG;
+    if (cfg >= kNumCfgs + ppy_x3_num_configs() + ppy_stream_num_configs()) return PPY_ERR_BAD_ARG;
     int hc, hs;
     pick_config(g, K, &hc, &hs);
     *c = cfg < 0 ? hc : cfg;
@@ -610,6 +611,8 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (c >= kNumCfgs + ppy_x3_num_configs())
+        return s == 1 ? ppy_stream_dispatch(p, c - kNumCfgs - ppy_x3_num_configs(), nullptr, 0, st) : PPY_ERR_BAD_ARG;
     if (c >= kNumCfgs) return ppy_x3_dispatch(p, c - kNumCfgs, s, st);
     switch (c) {
         case 0: return launch_cfg<128, 128, 64, 64>(p, s, st);
@@ -645,4 +648,30 @@ static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 30: return launch_glds<64, 64, 32, 32, 3, 16>(p, s, st);
     }
     return PPY_ERR_BAD_ARG;
+}
+
+// The streaming 1x1 kernel with its second output: y as ppy_conv2d_bn_act_f32 gives it (f16x2 operands, C = 64, stride 1),
+// and `pooled` = the 2x2 / stride 2 average of y (the AvgPool2d of the ResNet-vd shortcut, reference model/resnet_vd.py:29-33)
+// written from the same epilogue.  pooled == NULL: y only.
+extern "C" int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2,
+                                      const float *shift, const float *residual, int res_ld, float *y, int y_ld,
+                                      float *pooled, int pooled_ld, int N, int H, int W, int C, int K, int act, int variant,
+                                      const float *amax_in, float *amax_out, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && w_f16x2 && scale_f16x2 && shift && y && amax_in);
+    Geometry g;
+    if (!conv_geometry(N, H, W, C, K, 1, 1, 1, 0, &g)) return PPY_ERR_BAD_ARG;
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= K && (!residual || res_ld >= K));
+    PPY_CHECK_ARG(act == PPY_ACT_NONE || act == PPY_ACT_RELU || act == PPY_ACT_LEAKY);
+    ConvArgs p;
+    p.x = x; p.w = nullptr; p.w3 = nullptr; p.wf16 = (const unsigned short *)w_f16x2;
+    p.scale_f16 = scale_f16x2; p.posb_f16 = nullptr; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale_f16x2; p.shift = shift;
+    p.res = residual; p.posb = nullptr; p.y = y; p.part = nullptr;
+    p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = H; p.Wo = W; p.K = K; p.R = 1; p.S = 1;
+    p.stride = 1; p.pad = 0; p.act = act; p.ups = 0;
+    p.M = g.M; p.Kred = C; p.cchunks = C / BK; p.chunks_total = g.chunks; p.chunks_per_split = g.chunks;
+    p.nstages = 2;
+    p.trace = nullptr;
+    return ppy_stream_dispatch(p, variant, pooled, pooled_ld, (hipStream_t)stream);
 }

@@ -27,6 +27,9 @@ struct Geometry {
 int ppy_x3_num_configs();
 int ppy_x3_f16_base();        // first local id of the f16x2 scheme
 int ppy_x3_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
+// conv_stream.hip: persistent streaming kernel for 1x1 convolutions with C = 64 (f16x2 operands), optional 2x2 average output
+int ppy_stream_num_configs();
+int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_ld, hipStream_t stream);
 
 namespace {
 

@@ -73,8 +73,9 @@ def tune_key(op):
     Kout, R, S, C = op['w'].shape
     f16 = op.get('wf16') is not None and op.get('amax_in_id') is not None
     # ('dcnf': ids of the fused DCNv2 kernel, ops.dcnv2_num_configs -- not the convolution's numbering)
-    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s' % ('dcnf' if op['op'] == 'dcn' else op['op'], x.N, x.H, x.W, C, Kout, R,
-                                                 op['stride'], ':f' if f16 else '')
+    # ':p': the layer also owns the 2x2 average of its output (HipExecutor._link_pools)
+    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s%s' % ('dcnf' if op['op'] == 'dcn' else op['op'], x.N, x.H, x.W, C, Kout, R,
+                                                   op['stride'], ':f' if f16 else '', ':p' if op.get('pool') is not None else '')
 
 
 def tuned_table(mode=None):
@@ -301,11 +302,15 @@ class HipExecutor(object):
                             if self.math == 'f16x2':
                                 op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
         self._assign_amax()
+        self._link_pools()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
         for op in p.ops:
             if op['op'] in ('conv', 'dcn') and op['cfg'] < 0:
                 ent = tab.get(tune_key(op)) or tab_x3.get(tune_key(op))      # (a layer without ':f' behaves as in bf16x3 mode)
+                if not ent and op.get('pool') is not None:                   # no entry for the pooled form: the plain shape's
+                    k0 = tune_key(dict(op, pool=None))
+                    ent = tab.get(k0) or tab_x3.get(k0)
                 if ent:
                     op['cfg'], op['splitk'] = ent[:2]
         self.ws = None
@@ -354,6 +359,32 @@ class HipExecutor(object):
         self._amax_block = self.plan.N * K.AMAX_FLOATS_PER_IMAGE
         self.amax = torch.zeros(max(1, nblocks) * self._amax_block, dtype=torch.float32, device=self.device)
 
+    def _link_pools(self):
+        """The vd shortcut's AvgPool2d(2, 2) (reference model/resnet_vd.py:29-33) belongs to the launch that produces its
+        input where that is a 1x1 convolution the streaming kernel (csrc/conv_stream.hip) can run: the producer then
+        writes the 2x2 average from its own epilogue (cfg = a streaming id) or, on any other tile, the pooling launch
+        follows it immediately; the 'avgpool' op of the plan is skipped either way."""
+        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_POOL_FOLD', '1') != '1':
+            return
+        ops = self.plan.ops
+        for i, op in enumerate(ops):
+            if op['op'] != 'avgpool':
+                continue
+            x = op['x']
+            prods = [o for o in ops[:i] if o['op'] in ('conv', 'dcn', 'stem', 'maxpool', 'avgpool', 'spp')
+                     and x.buf in self._op_io(o)[1]]
+            if len(prods) != 1 or prods[0]['op'] != 'conv':
+                continue
+            c = prods[0]
+            Kout, R, S, C = c['w'].shape
+            y = c['y']
+            if (R, S, c['stride'], C) != (1, 1, 1, 64) or Kout % 64 or c['ups'] or c['posb'] is not None \
+                    or c.get('wf16') is None or c.get('amax_in_id') is None or c.get('stream', 0) != op.get('stream', 0) \
+                    or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.H % 2 or x.W % 2 or x.H * x.W < 32:
+                continue
+            c['pool'] = op['y']
+            op['owner'] = c
+
     def _amax(self, idx):
         return None if idx is None else self.amax[idx * self._amax_block:(idx + 1) * self._amax_block]
 
@@ -397,9 +428,11 @@ class HipExecutor(object):
         t = op['op']
         if t == 'conv':
             ins = [op['x'].buf] + ([op['res'].buf] if op['res'] is not None else [])
-            return ins, [op['y'].buf]
+            return ins, [op['y'].buf] + ([op['pool'].buf] if op.get('pool') is not None else [])
         if t == 'stem':
             return [], [op['y'].buf]
+        if t == 'avgpool' and op.get('owner') is not None:      # written by its producer's launch (_link_pools)
+            return [], []
         if t in ('maxpool', 'avgpool'):
             return [op['x'].buf], [op['y'].buf]
         if t == 'spp':
@@ -431,23 +464,36 @@ class HipExecutor(object):
         self._side_tail = max([i for i, op in enumerate(ops) if op.get('stream', 0)], default=None) \
             if self.multi_stream else None
 
+    @staticmethod
+    def _stream_first():
+        """First tile-configuration id of the streaming 1x1 kernel (the last ops.NUM_STREAM_CFGS ids)."""
+        from ._lib import lib
+        return lib().ppy_conv2d_num_configs() - K.NUM_STREAM_CFGS
+
     def _run_op(self, op, ws=None):
         t = op['op']
         ws = self.ws if ws is None else ws
-        if t == 'conv':
+        if t == 'conv' and op.get('pool') is not None and op['cfg'] >= self._stream_first():
+            K.conv1x1_expand(self.view(op['x']), op['wf16'], op['shift'], self.view(op['y']), op['act'],
+                             None if op['res'] is None else self.view(op['res']), self.view(op['pool']),
+                             op['cfg'] - self._stream_first(), self._amax(op.get('amax_in_id')), self._amax(op.get('amax_out_id')))
+        elif t == 'conv':
             posb = op['posb']
             K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
                             ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
                             self._amax(op.get('amax_out_id')), op.get('posb_f16'))
+            if op.get('pool') is not None:
+                K.avgpool2x2(self.view(op['y']), self.view(op['pool']))
         elif t == 'stem':
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'],
                         self._amax(op.get('amax_out_id')))
         elif t == 'maxpool':
             K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
         elif t == 'avgpool':
-            K.avgpool2x2(self.view(op['x']), self.view(op['y']))
+            if op.get('owner') is None:          # (else: written by the producer's launch, _link_pools)
+                K.avgpool2x2(self.view(op['x']), self.view(op['y']))
         elif t == 'spp':
             K.spp(self.view(op['x']), self.view(op['y5']), self.view(op['y9']), self.view(op['y13']))
         elif t == 'dcn':

@@ -135,6 +135,22 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
+NUM_STREAM_CFGS = 2          # the last ids of ppy_conv2d_num_configs(): csrc/conv_stream.hip, variants 0 / 1
+
+
+def conv1x1_expand(x, w_f16, shift, y, act=None, residual=None, pooled=None, variant=0, amax_in=None, amax_out=None):
+    """The streaming 1x1 kernel (C == 64, f16x2 operands): y as conv2d_bn_act gives it and, with `pooled` (a View of
+    [N, H/2, W/2, K]), the 2x2 average of y from the same epilogue.  w_f16: split_weights_f16x2(w_krsc, scale).
+    See ppy_conv1x1_expand_f32."""
+    _dev(x.t, w_f16[0], w_f16[1], shift, y.t)
+    rc = lib().ppy_conv1x1_expand_f32(
+        x.ptr, x.ld, w_f16[0].data_ptr(), w_f16[1].data_ptr(), shift.data_ptr(),
+        None if residual is None else residual.ptr, 0 if residual is None else residual.ld, y.ptr, y.ld,
+        None if pooled is None else pooled.ptr, 0 if pooled is None else pooled.ld, x.N, x.H, x.W, x.C, y.C, ACT[act], variant,
+        _p(amax_in), _p(amax_out), _stream())
+    check(rc, 'ppy_conv1x1_expand_f32')
+
+
 def _bwd_ws(nbytes, device):
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device)
 

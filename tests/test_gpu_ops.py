@@ -669,3 +669,97 @@ def test_slab_reuse_edge_shapes(cfg):
         close(nchw(outs[0]), ref, what='slab cfg %d: N%d %dx%d C%d K%d split %d' % (cfg, N, H, W, C, K, splitk))
         if splitk == 1:
             assert torch.equal(outs[0], outs[1]), 'slab cfg %d differs from the plain kernel (N%d %dx%d C%d K%d)' % (cfg, N, H, W, C, K)
+
+
+def _amax_per_image(a, N):
+    return a.view(N, -1).amax(dim=1)
+
+
+@pytest.mark.parametrize('variant', (0, 1))
+def test_stream_1x1_is_bit_identical_to_the_f16x2_tiles(variant):
+    """csrc/conv_stream.hip (persistent streaming kernel for the C = 64 1x1 layers) against the 128x128 f16x2 tile of
+    conv_x3.hip: same products in the same order, so y must be EQUAL (and the tracked per-image maxima exact) -- maps whose pixel
+    count is no multiple of 32, tiles that straddle images, one / two / four / eight channel slices, with and without the
+    shortcut, all activations, outputs that are slices of a wider buffer."""
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import lib
+    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    g = torch.Generator().manual_seed(4100 + variant)
+    for N, H, W, K, res, act, y_extra in ((2, 24, 20, 256, True, 'relu', 0), (3, 9, 7, 256, True, 'relu', 0), (1, 6, 6, 64, False, None, 0),
+                                          (5, 8, 5, 128, True, 'leaky', 64), (2, 40, 40, 512, False, 'relu', 0), (8, 7, 5, 256, True, None, 32)):
+        C = 64
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, 1, 1, generator=g) * 0.125
+        sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        r = (torch.randn(N, H, W, K, generator=g) * 2).cuda() if res else None
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc)
+        outs, maxima = [], []
+        for c in (first + variant, 41):
+            y = torch.full((N, H, W, K + y_extra), 9.0).cuda()
+            am = ops.amax_slots(N=N, device=y.device)
+            ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y, 0, K), 1, 0, act, residual=None if r is None else ops.View(r),
+                              cfg=c, splitk=1, w_f16=wf, amax_in=ops.amax_slots(xd), amax_out=am)
+            torch.cuda.synchronize()
+            outs.append(y)
+            maxima.append(_amax_per_image(am, N))
+        what = 'N%d %dx%d K%d res %s act %s' % (N, H, W, K, res, act)
+        ref = F.conv2d(x, w) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+        if res:
+            ref = ref + nchw(r.cpu())
+        ref = {'relu': F.relu, 'leaky': lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](ref)
+        close(nchw(outs[0][..., :K]), ref, what=what)
+        assert torch.equal(outs[0], outs[1]), what                      # (including the untouched columns of a wider buffer)
+        exact = outs[0][..., :K].reshape(N, -1).abs().amax(dim=1)
+        assert torch.equal(maxima[0], exact), what           # (32-row tiles touch at most two images: exact per image)
+        assert bool((maxima[1] >= exact).all()), what        # (a 128-row tile over more than two images records an upper bound)
+
+
+def test_stream_1x1_writes_the_2x2_average_of_its_output():
+    """ppy_conv1x1_expand_f32 with `pooled`: y equals the plain f16x2 tile's, pooled equals ppy_avgpool2x2_f32 of it (same
+    order of additions) -- blocks of 2x2 pixels as tile rows, images of 9 / 15 / 400 blocks (tiles that straddle images,
+    a last tile with fewer than eight blocks), pooled as a slice of a wider buffer."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(4200)
+    for N, H, W, K, res, variant in ((2, 6, 6, 256, True, 0), (3, 6, 10, 128, True, 1), (2, 40, 40, 256, True, 0), (5, 8, 6, 64, False, 0)):
+        C = 64
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, 1, 1, generator=g) * 0.125
+        sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        r = (torch.randn(N, H, W, K, generator=g) * 2).cuda() if res else None
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc)
+        y0 = torch.full((N, H, W, K), 9.0).cuda()
+        am0 = ops.amax_slots(N=N, device=y0.device)
+        ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y0), 1, 0, 'relu', residual=None if r is None else ops.View(r),
+                          cfg=41, splitk=1, w_f16=wf, amax_in=ops.amax_slots(xd), amax_out=am0)
+        p0 = torch.zeros(N, H // 2, W // 2, K).cuda()
+        ops.avgpool2x2(ops.View(y0), ops.View(p0))
+        y1 = torch.full((N, H, W, K), 9.0).cuda()
+        p1 = torch.full((N, H // 2, W // 2, K + 32), 5.0).cuda()
+        am1 = ops.amax_slots(N=N, device=y0.device)
+        ops.conv1x1_expand(ops.View(xd), wf, sh, ops.View(y1), 'relu', None if r is None else ops.View(r), ops.View(p1, 0, K), variant,
+                           ops.amax_slots(xd), am1)
+        torch.cuda.synchronize()
+        what = 'N%d %dx%d K%d' % (N, H, W, K)
+        assert torch.equal(y0, y1), what
+        assert torch.equal(p0, p1[..., :K]), what
+        assert bool((p1[..., K:] == 5.0).all()), what
+        assert torch.equal(_amax_per_image(am1, N), y1.reshape(N, -1).abs().amax(dim=1)), what
+
+
+def test_stream_1x1_refuses_what_it_cannot_run():
+    """An explicit streaming id on another geometry is an error (PPY_ERR_BAD_ARG), not a silent other kernel."""
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import lib, PPYoloHipError
+    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    for C, K, R in ((128, 256, 1), (64, 96, 1), (64, 64, 3)):
+        x = torch.randn(1, 8, 8, C).cuda()
+        wk = torch.randn(K, R, R, C).cuda()
+        one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+        y = torch.zeros(1, 8, 8, K).cuda()
+        with pytest.raises(PPYoloHipError):
+            ops.conv2d_bn_act(ops.View(x), wk, one, zero, ops.View(y), 1, (R - 1) // 2, None, cfg=first, splitk=1,
+                              w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
