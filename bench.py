@@ -485,6 +485,8 @@ def main():
     ap.add_argument('--freeze-at', type=int, default=None, help='--train: backbone stages 1..N frozen (default: the configuration\'s 5 = the '
                     'head trains; 1..4 add stages, incl. the DCNv2 backward of stage 5)')
     ap.add_argument('--tune-kinds', default='conv,dcn', help='with --autotune: plan op kinds to re-measure (conv,dcn)')
+    ap.add_argument('--tune-match', default=None, help='with --autotune: only the layers whose table key contains all of these '
+                    'comma-separated pieces (e.g. ":C64:,:R1:")')
     ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
                     'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
     ap.add_argument('--verbose-tune', action='store_true')
@@ -544,7 +546,8 @@ def main():
         e.run()
     torch.cuda.synchronize()
     if a.autotune:
-        ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')))
+        ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')),
+                    match=a.tune_match.split(',') if a.tune_match else None)
         if a.co_tune and depth > 1:
             lanes[1][0].use_graph = True
             changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)

@@ -302,6 +302,7 @@ class HipExecutor(object):
                             if self.math == 'f16x2':
                                 op['wf16'] = K.split_weights_f16x2(op['w'], op['scale'])
         self._assign_amax()
+        self._want_streams = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' if multi_stream is None else bool(multi_stream)
         self._link_pools()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
@@ -321,7 +322,7 @@ class HipExecutor(object):
         # batches lose on the fork/join), but keeping two batches in flight on two single-branch graphs (runtime.InFlight)
         # gains 24 % where two forked ones gain 3 %, and a forked hipGraph replayed under another stream than its first
         # has crashed the ROCm 7.2 runtime -- so the default is one branch, and a forked graph refuses a stream change.
-        want = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' if multi_stream is None else bool(multi_stream)
+        want = self._want_streams
         self.multi_stream = want and any(op.get('stream', 0) for op in p.ops)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.multi_stream else None
         self._build_sync_plan()
@@ -379,7 +380,8 @@ class HipExecutor(object):
             Kout, R, S, C = c['w'].shape
             y = c['y']
             if (R, S, c['stride'], C) != (1, 1, 1, 64) or Kout % 64 or c['ups'] or c['posb'] is not None \
-                    or c.get('wf16') is None or c.get('amax_in_id') is None or c.get('stream', 0) != op.get('stream', 0) \
+                    or c.get('wf16') is None or c.get('amax_in_id') is None \
+                    or (self._want_streams and c.get('stream', 0) != op.get('stream', 0)) \
                     or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.H % 2 or x.W % 2 or x.H * x.W < 32:
                 continue
             c['pool'] = op['y']
@@ -576,7 +578,7 @@ class HipExecutor(object):
         self._graph_stream = None
 
     # ---- autotune --------------------------------------------------------------------------
-    def autotune(self, iters=3, verbose=False, kinds=('conv', 'dcn')):
+    def autotune(self, iters=3, verbose=False, kinds=('conv', 'dcn'), match=None):
         """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
         guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
         from ._lib import lib
@@ -595,7 +597,7 @@ class HipExecutor(object):
             if self.ws.numel() * 4 < big:
                 self.ws = torch.empty(((big + 3) // 4,), dtype=torch.float32, device=self.device)
             for op in self.plan.ops:
-                if op['op'] not in kinds:
+                if op['op'] not in kinds or (match and not all(m in tune_key(op) for m in match)):
                     continue
                 Kout = op['w'].shape[0]
                 Kred = op['w'].shape[1] * op['w'].shape[2] * op['w'].shape[3]

@@ -517,3 +517,38 @@ def test_fresh_process_build_then_smoke():
     r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert r.returncode == 0 and 'smoke ok' in r.stdout, r.stdout[-2000:]
+
+
+def test_vd_shortcut_pool_is_written_by_its_producer(monkeypatch):
+    """HipExecutor._link_pools: the AvgPool2d(2, 2) in front of the stage-3 projection shortcut of ResNet50-vd belongs to the
+    launch of the stage-2 convolution that produces its input; on the streaming kernel (csrc/conv_stream.hip) that launch
+    writes the average from its epilogue, on any other tile the pooling kernel follows it.  The detections are EQUAL to
+    those of the plan with the separate pooling op (PPYOLO_HIP_POOL_FOLD=0) either way -- same sums in the same order."""
+    from ppyolo_hip._lib import lib
+    from ppyolo_hip import ops
+    cfg = PPYOLO_2x_Config()
+    x, ims = synth.synth_images(3, 224, seed=11).cuda(), synth.synth_im_size(3).cuda()
+    monkeypatch.setenv('PPYOLO_HIP_POOL_FOLD', '0')
+    base_model, _ = build_model(cfg, 0, 'cuda')
+    bex = base_model._plans.executor(x)
+    assert not any(op.get('owner') is not None for op in bex.plan.ops)
+    pool0 = [op for op in bex.plan.ops if op['op'] == 'avgpool'][0]
+    prod0 = [op for op in bex.plan.ops if op['op'] == 'conv' and op['y'].buf == pool0['x'].buf]
+    assert len(prod0) == 1
+    prod0[0]['cfg'], prod0[0]['splitk'] = 41, 1             # an f16x2 tile (the shape is not in the table: the heuristic's is exact fp32)
+    base = [p.clone() for p in base_model(x, ims)]
+    monkeypatch.setenv('PPYOLO_HIP_POOL_FOLD', '1')
+    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    for force in (first, first + 1, 41):
+        model, _ = build_model(cfg, 0, 'cuda')
+        ex = model._plans.executor(x)
+        owned = [op for op in ex.plan.ops if op['op'] == 'avgpool' and op.get('owner') is not None]
+        free = [op for op in ex.plan.ops if op['op'] == 'avgpool' and op.get('owner') is None]
+        assert len(owned) == 1 and len(free) == 2          # (stage 3 and 4 outputs have C = 128 / 256: not the streaming kernel's)
+        prod = owned[0]['owner']
+        assert prod['pool'] is owned[0]['y'] and tuple(prod['w'].shape[1:]) == (1, 1, 64)
+        prod['cfg'], prod['splitk'] = force, 1
+        ex.invalidate_graph()
+        got = model(x, ims)
+        for a, b in zip(got, base):
+            assert torch.equal(a, b), force
