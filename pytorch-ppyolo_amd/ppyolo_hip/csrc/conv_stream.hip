@@ -28,7 +28,14 @@ struct StreamArgs {
     int tiles;        // 32-row tiles
 };
 
-template <int KS, bool RES, bool POOL>
+// ALDS = false, TN = 2: the C = 64 form above (activations straight into fragment registers, waves independent, two workgroups
+// per CU).  ALDS = true, TN = 1 (C = 128, e.g. the stage-3 expand layers C128 -> K512 at 76x76): a wave owns 32 channels (64
+// VGPRs of weights again), a workgroup 128, and since many slices re-reading the activations through the L1 would saturate
+// its address path, the tile's [32][C] activations are staged ONCE per workgroup through two alternating LDS buffers
+// (coalesced loads one tile ahead -> ds_write -> ONE workgroup barrier per tile -> swizzled fragment reads); the K / 128
+// workgroups of a pixel stream sit on one XCD (block ids 8 apart), so the tile comes from HBM once.  (Three workgroups per CU
+// would need <= 168 VGPRs: 20-25 spilled, and scratch reloads queue behind the prefetches in the in-order vmcnt.)
+template <int KS, int TN, bool RES, bool POOL, bool ALDS>
 __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
@@ -36,10 +43,17 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *sE = reinterpret_cast<float *>(smem_st) + wave * (32 * LDS_LD);
-    const int nsl = p.K >> 6;                                   // 64-channel slices
-    const int gw = (int)blockIdx.x * 4 + wave;
-    const int slice = gw % nsl, stream = gw / nsl, nstreams = ((int)gridDim.x * 4) / nsl;
-    const int n0 = slice * 64;
+    constexpr int NW = 4, SW = 32 * TN;                         // waves per workgroup, channels per wave
+    constexpr int C = KS * 16, ROW_BYTES = C * 4;
+    char *abuf = smem_st + NW * 32 * LDS_LD * 4;                // ALDS: two [32][C] fp32 tiles
+    const int nsl = p.K / SW;                                   // channel slices
+    const int gw = (int)blockIdx.x * NW + wave;
+    const int groups = ALDS ? nsl / NW : 1;                     // ALDS: workgroups that share the pixels of a stream
+    const int bi = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int slice = ALDS ? (bi % groups) * NW + wave : gw % nsl;
+    const int stream = ALDS ? (bi / groups) * 8 + xcd : gw / nsl;
+    const int nstreams = ALDS ? (int)gridDim.x / groups : ((int)gridDim.x * 4) / nsl;
+    const int n0 = slice * SW;
     const int hw = p.H * p.W;
     // a tile counts 32 pixels, or (POOL) 8 blocks of 2x2 pixels
     const int unit_hw = POOL ? hw >> 2 : hw, units = POOL ? p.M >> 2 : p.M, per_tile = POOL ? 8 : 32;
@@ -57,14 +71,14 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 
     // ---- this wave's weights: B fragments of v_mfma_f32_32x32x16_f16 (column lane&31, k = 16s + 8(lane>>5) + [0,8)) from the
     // [plane][chunk][K][32] planes of ppy_conv2d_split_weights_f16x2
-    uintx4 wf[2][2][KS];
+    uintx4 wf[2][TN][KS];
     {
         const char *wb = reinterpret_cast<const char *>(p.wf16);
         const long long plane_bytes = (long long)p.K * p.C * 2;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const int k = n0 + j * 32 + (lane & 31);
@@ -73,16 +87,31 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
                 }
     }
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-    floatx4 sc[2], sh[2];
+    floatx4 sc[TN], sh[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
         sc[j] = *reinterpret_cast<const floatx4 *>(p.scale + n0 + j * 32 + ec4);
         sh[j] = *reinterpret_cast<const floatx4 *>(p.shift + n0 + j * 32 + ec4);
     }
 
     // ---- requests of a tile: activations in the A-fragment layout, shortcut rows in the epilogue layout
-    uintx4 raw[2 * KS];
+    // ALDS: this wave's share of the tile, 16 bytes per lane, LPR lanes per pixel row
+    constexpr int LPR = C / 4, RPI = 64 / LPR, NI = ALDS ? (32 / NW) / RPI : 1;
+    uintx4 stg[NI];
+    auto stage_row = [&](int i) { return wave * (32 / NW) + i * RPI + lane / LPR; };
+    uintx4 raw[ALDS ? 1 : 2 * KS];
     auto request_a = [&](int t) {
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = stage_row(i);
+                const int idx = POOL ? t * 8 + (row & 7) : t * 32 + row;
+                const bool ok = t >= 0 && t < q.tiles && idx < units;
+                const unsigned off = ok ? (unsigned)pixel_of(idx, row >> 3) * (unsigned)(p.x_ld * 4) + (unsigned)(lane % LPR) * 16u : ST_OOB;
+                stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+            }
+            return;
+        }
         const int fr = lane & 31;
         const int idx = POOL ? t * 8 + (fr & 7) : t * 32 + fr;
         const bool ok = t >= 0 && t < q.tiles && idx < units;
@@ -107,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
             for (int u = 0; u < 4; ++u) pix[u] = (t >= 0 && t < q.tiles && idx0 + 8 * u < units) ? idx0 + 8 * u : -1;
         }
     };
-    uintx4 rv[2][4];
+    uintx4 rv[TN][4];
     auto request_res = [&](int j, const int (&pix)[4]) {
         if constexpr (RES) {
 #pragma unroll
@@ -145,9 +174,11 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
     // stores nothing (all rows invalid) and only requests -- with a separate prologue the compiler's counted waits are the
     // minimum over both paths into the loop head, and the steady state then drains the queue of stores at every tile.
 #pragma unroll
-    for (int i = 0; i < 2 * KS; ++i) raw[i] = uintx4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < (ALDS ? 1 : 2 * KS); ++i) raw[i] = uintx4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < NI; ++i) stg[i] = uintx4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int u = 0; u < 4; ++u) rv[j][u] = uintx4{0u, 0u, 0u, 0u};
     // (and nothing may be pending at the loop head on the entry edge either: a use of the weight / scale registers here
@@ -155,14 +186,27 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[pl][j][s]));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
     int pix_n[4] = {-1, -1, -1, -1}, idx_n = 0;
     const float slope = p.act == PPY_ACT_RELU ? 0.f : (p.act == PPY_ACT_LEAKY ? 0.1f : 1.f);
+    int par = 0;
     for (int t = stream - nstreams; t < q.tiles; t += nstreams) {
+        if constexpr (ALDS) {
+            // the tile requested one iteration ago goes to the buffer last read two iterations ago: one barrier per tile
+            par ^= 1;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = stage_row(i);
+                *reinterpret_cast<uintx4 *>(abuf + par * (32 * ROW_BYTES) + row * ROW_BYTES + (((lane % LPR) ^ (row & 15)) << 4)) = stg[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            request_a(t + nstreams);
+        }
         int pix[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) pix[u] = pix_n[u];
@@ -185,42 +229,51 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
         const int fidx = POOL ? first + (lane & 7) : first + (lane & 31);
         const float sa = fidx < bnd ? sa0 : sa1;
 
-        floatx16 acc[2];
+        floatx16 acc[TN];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uintx4 a0, a1;
+            uintx4 a0, a1, r2[2];
+            if constexpr (ALDS) {       // 16-byte slot c of row r sits at c ^ (r & 15): the 16 rows of a quarter-wave hit 16 bank groups
+                const int fr = lane & 31, c0 = 4 * s + 2 * (lane >> 5);
+                const char *ab = abuf + par * (32 * ROW_BYTES) + fr * ROW_BYTES;
+                r2[0] = *reinterpret_cast<const uintx4 *>(ab + ((c0 ^ (fr & 15)) << 4));
+                r2[1] = *reinterpret_cast<const uintx4 *>(ab + (((c0 + 1) ^ (fr & 15)) << 4));
+            } else {
+                r2[0] = raw[ALDS ? 0 : 2 * s];
+                r2[1] = raw[ALDS ? 0 : 2 * s + 1];
+            }
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const float xa = __uint_as_float(raw[2 * s + (q4 >> 1)][(q4 & 1) * 2]);
-                const float xb = __uint_as_float(raw[2 * s + (q4 >> 1)][(q4 & 1) * 2 + 1]);
+                const float xa = __uint_as_float(r2[q4 >> 1][(q4 & 1) * 2]);
+                const float xb = __uint_as_float(r2[q4 >> 1][(q4 & 1) * 2 + 1]);
                 const unsigned P0 = cvt_pk_f16(xa * sa, xb * sa);
                 a0[q4] = P0;
                 a1[q4] = cvt_pk_f16(fmaf(xa, sa, -f16_lo(P0)), fmaf(xb, sa, -f16_hi(P0)));
             }
             // the three leading products, smallest first, as conv_x3.hip orders them: a1*b0, a0*b1, a0*b0
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, wf[0][j][s]), acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, wf[1][j][s]), acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, wf[0][j][s]), acc[j], 0, 0, 0);
         }
         // the activations of the next tile of this wave
-        request_a(t + nstreams);
+        if constexpr (!ALDS) request_a(t + nstreams);
         epi_pixels(t + nstreams, pix_n, idx_n);
 
         float rowscale[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) rowscale[u] = (POOL ? idx0 : idx0 + 8 * u) < bnd ? inv0 : inv1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             const int col = n0 + j * 32 + ec4;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -229,12 +282,13 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
             }
             __builtin_amdgcn_wave_barrier();
             floatx4 v[4];
+            const floatx4 scj = sc[j], shj = sh[j];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * u) * LDS_LD + ec4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float o = fmaf(v[u][c] * rowscale[u], sc[j][c], sh[j][c]);
+                    float o = fmaf(v[u][c] * rowscale[u], scj[c], shj[c]);
                     if (RES) o += __uint_as_float(rv[j][u][c]);
                     v[u][c] = o > 0.f ? o : o * slope + 0.0f;       // (+0: ReLU gives +0 for negative inputs, as max(o, 0) does)
                 }
@@ -265,25 +319,35 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 #endif
 }
 
-template <int KS, bool RES, bool POOL>
+template <int KS, int TN, bool RES, bool POOL, bool ALDS>
 int launch_stream_one(const StreamArgs &q, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((conv1x1_stream_kernel<KS, RES, POOL>), dim3(grid), dim3(256), 4 * 32 * LDS_LD * sizeof(float), stream, q);
+    auto k = conv1x1_stream_kernel<KS, TN, RES, POOL, ALDS>;
+    const size_t lds = (size_t)4 * 32 * LDS_LD * sizeof(float) + (ALDS ? 2 * 32 * KS * 16 * sizeof(float) : 0);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream, q);
     return ppy_launch_status();
+}
+
+template <int KS, int TN, bool ALDS>
+int launch_stream(const StreamArgs &q, int grid, hipStream_t stream) {
+    if (q.pool) return q.c.res ? launch_stream_one<KS, TN, true, true, ALDS>(q, grid, stream) : launch_stream_one<KS, TN, false, true, ALDS>(q, grid, stream);
+    return q.c.res ? launch_stream_one<KS, TN, true, false, ALDS>(q, grid, stream) : launch_stream_one<KS, TN, false, false, ALDS>(q, grid, stream);
 }
 
 }  // namespace
 
 int ppy_stream_num_configs() { return 2; }
 
-// local 0: 512 workgroups (two per CU), local 1: 256.  `pool` / `pool_ld`: optional 2x2 average of y (see the file header).
+// C = 64 (K % 64 == 0): local 0 = 512 workgroups of four waves (two per CU), local 1 = 256.  C = 128 (K % 128 == 0, K / 128 a
+// power of two): the same grids.  `pool` / `pool_ld`: optional 2x2 average of y.
 int ppy_stream_dispatch(const ConvArgs &p, int local, float *pool, int pool_ld, hipStream_t stream) {
     if (local < 0 || local >= ppy_stream_num_configs()) return PPY_ERR_BAD_ARG;
     // BAD_ARG, not UNSUPPORTED: an explicit id that does not apply is the caller's error (no silent other kernel)
-    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad != 0 || p.C != 64 || p.K % 64 != 0 || p.ups || p.posb) return PPY_ERR_BAD_ARG;
+    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad != 0 || p.ups || p.posb) return PPY_ERR_BAD_ARG;
+    if (!((p.C == 64 && p.K % 64 == 0) || (p.C == 128 && p.K % 128 == 0))) return PPY_ERR_BAD_ARG;
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in) return PPY_ERR_BAD_ARG;
     if (!vec_epilogue_ok(p) || ((uintptr_t)p.x & 15) != 0 || p.x_ld % 4 != 0) return PPY_ERR_BAD_ARG;
-    const int nsl = p.K / 64;
-    if (nsl > 16 || (nsl & (nsl - 1)) != 0) return PPY_ERR_BAD_ARG;           // the slices divide the wave count
+    const int nsl = p.C == 64 ? p.K / 64 : p.K / 128;       // C = 64: slices of 64 channels per wave; C = 128: workgroups per pixel stream
+    if (nsl > 16 || (nsl & (nsl - 1)) != 0) return PPY_ERR_BAD_ARG;           // the slices / groups divide the wave / workgroup count
     const int hw = p.H * p.W;
     if (pool) {
         if (p.H % 2 != 0 || p.W % 2 != 0 || hw / 4 < 8 || pool_ld < p.K || pool_ld % 4 != 0 || ((uintptr_t)pool & 15) != 0) return PPY_ERR_BAD_ARG;
@@ -299,7 +363,6 @@ int ppy_stream_dispatch(const ConvArgs &p, int local, float *pool, int pool_ld, 
     q.pool = pool;
     q.pool_ld = pool_ld;
     q.tiles = pool ? ceil_div(p.M / 4, 8) : ceil_div(p.M, 32);
-    const int grid = local == 0 ? 512 : 256;
-    if (pool) return p.res ? launch_stream_one<4, true, true>(q, grid, stream) : launch_stream_one<4, false, true>(q, grid, stream);
-    return p.res ? launch_stream_one<4, true, false>(q, grid, stream) : launch_stream_one<4, false, false>(q, grid, stream);
+    if (p.C == 128) return launch_stream<8, 1, true>(q, local == 0 ? 512 : 256, stream);
+    return launch_stream<4, 2, false>(q, local == 0 ? 512 : 256, stream);
 }

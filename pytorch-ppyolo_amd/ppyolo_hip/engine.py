@@ -372,14 +372,17 @@ class HipExecutor(object):
             if op['op'] != 'avgpool':
                 continue
             x = op['x']
-            prods = [o for o in ops[:i] if o['op'] in ('conv', 'dcn', 'stem', 'maxpool', 'avgpool', 'spp')
-                     and x.buf in self._op_io(o)[1]]
+            # (a route buffer has several writers, each of its own channel slice: the producer is the one that writes x's)
+            prods = [o for o in ops[:i] if x.buf in self._op_io(o)[1] and (o['op'] != 'conv' or (o['y'].coff < x.coff + x.C
+                                                                                                 and x.coff < o['y'].coff + o['y'].C))]
             if len(prods) != 1 or prods[0]['op'] != 'conv':
                 continue
             c = prods[0]
             Kout, R, S, C = c['w'].shape
             y = c['y']
-            if (R, S, c['stride'], C) != (1, 1, 1, 64) or Kout % 64 or c['ups'] or c['posb'] is not None \
+            groups = Kout // 64 if C == 64 else Kout // 128           # (what ppy_conv1x1_expand_f32 accepts)
+            if (R, S, c['stride']) != (1, 1, 1) or C not in (64, 128) or Kout % (64 if C == 64 else 128) or groups & (groups - 1) \
+                    or groups > 16 or c['ups'] or c['posb'] is not None \
                     or c.get('wf16') is None or c.get('amax_in_id') is None \
                     or (self._want_streams and c.get('stream', 0) != op.get('stream', 0)) \
                     or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.H % 2 or x.W % 2 or x.H * x.W < 32:

@@ -685,9 +685,11 @@ def test_stream_1x1_is_bit_identical_to_the_f16x2_tiles(variant):
     from ppyolo_hip._lib import lib
     first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
     g = torch.Generator().manual_seed(4100 + variant)
-    for N, H, W, K, res, act, y_extra in ((2, 24, 20, 256, True, 'relu', 0), (3, 9, 7, 256, True, 'relu', 0), (1, 6, 6, 64, False, None, 0),
-                                          (5, 8, 5, 128, True, 'leaky', 64), (2, 40, 40, 512, False, 'relu', 0), (8, 7, 5, 256, True, None, 32)):
-        C = 64
+    for C, N, H, W, K, res, act, y_extra in ((64, 2, 24, 20, 256, True, 'relu', 0), (64, 3, 9, 7, 256, True, 'relu', 0), (64, 1, 6, 6, 64, False, None, 0),
+                                             (64, 5, 8, 5, 128, True, 'leaky', 64), (64, 2, 40, 40, 512, False, 'relu', 0), (64, 8, 7, 5, 256, True, None, 32),
+                                             # C = 128: the tile's activations staged through the LDS, K / 128 workgroups per pixel stream
+                                             (128, 2, 24, 20, 512, True, 'relu', 0), (128, 3, 9, 7, 128, False, 'leaky', 0), (128, 5, 8, 5, 256, True, None, 64),
+                                             (128, 2, 40, 40, 1024, True, 'relu', 0), (128, 8, 7, 5, 512, True, 'relu', 32)):
         x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
         w = torch.randn(K, C, 1, 1, generator=g) * 0.125
         sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
@@ -704,7 +706,7 @@ def test_stream_1x1_is_bit_identical_to_the_f16x2_tiles(variant):
             torch.cuda.synchronize()
             outs.append(y)
             maxima.append(_amax_per_image(am, N))
-        what = 'N%d %dx%d K%d res %s act %s' % (N, H, W, K, res, act)
+        what = 'C%d N%d %dx%d K%d res %s act %s' % (C, N, H, W, K, res, act)
         ref = F.conv2d(x, w) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
         if res:
             ref = ref + nchw(r.cpu())
@@ -722,8 +724,8 @@ def test_stream_1x1_writes_the_2x2_average_of_its_output():
     a last tile with fewer than eight blocks), pooled as a slice of a wider buffer."""
     from ppyolo_hip import ops
     g = torch.Generator().manual_seed(4200)
-    for N, H, W, K, res, variant in ((2, 6, 6, 256, True, 0), (3, 6, 10, 128, True, 1), (2, 40, 40, 256, True, 0), (5, 8, 6, 64, False, 0)):
-        C = 64
+    for C, N, H, W, K, res, variant in ((64, 2, 6, 6, 256, True, 0), (64, 3, 6, 10, 128, True, 1), (64, 2, 40, 40, 256, True, 0), (64, 5, 8, 6, 64, False, 0),
+                                        (128, 2, 6, 6, 512, True, 0), (128, 3, 6, 10, 128, True, 1), (128, 2, 40, 40, 512, True, 0), (128, 5, 8, 6, 256, False, 1)):
         x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
         w = torch.randn(K, C, 1, 1, generator=g) * 0.125
         sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
@@ -743,7 +745,7 @@ def test_stream_1x1_writes_the_2x2_average_of_its_output():
         ops.conv1x1_expand(ops.View(xd), wf, sh, ops.View(y1), 'relu', None if r is None else ops.View(r), ops.View(p1, 0, K), variant,
                            ops.amax_slots(xd), am1)
         torch.cuda.synchronize()
-        what = 'N%d %dx%d K%d' % (N, H, W, K)
+        what = 'C%d N%d %dx%d K%d' % (C, N, H, W, K)
         assert torch.equal(y0, y1), what
         assert torch.equal(p0, p1[..., :K]), what
         assert bool((p1[..., K:] == 5.0).all()), what
@@ -755,7 +757,7 @@ def test_stream_1x1_refuses_what_it_cannot_run():
     from ppyolo_hip import ops
     from ppyolo_hip._lib import lib, PPYoloHipError
     first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
-    for C, K, R in ((128, 256, 1), (64, 96, 1), (64, 64, 3)):
+    for C, K, R in ((256, 256, 1), (64, 96, 1), (64, 64, 3), (128, 192, 1), (128, 384, 1)):
         x = torch.randn(1, 8, 8, C).cuda()
         wk = torch.randn(K, R, R, C).cuda()
         one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()

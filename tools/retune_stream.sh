@@ -1,11 +1,12 @@
 #!/bin/bash
-# Re-measure the tile choice of the 1x1 layers with C = 64 (f16x2 mode), where the streaming kernel of csrc/conv_stream.hip is a
+# Re-measure the tile choice of the 1x1 layers with C = $1 (64 or 128; f16x2 mode), where the streaming kernel of csrc/conv_stream.hip is a
 # candidate (the last two conv cfg ids), for the bench workloads.  -> gpurun_out/stream_tune/tuned_<workload>_b<batch>.json
 # (merge: tools/merge_tuned.py f16x2 --match ":C64:,:R1:" gpurun_out/stream_tune/*.json)
+CC=${1:-64}
 mkdir -p gpurun_out/stream_tune
 for W in "r50vd_608 8" "r50vd_608 1" "r50vd_320 1" "r18vd_416 8" "r18vd_416 1" "r18vd_320 8" "r18vd_320 1" "r18vd_608 1"; do
   set -- $W
-  python bench.py --workload $1 --batch $2 --autotune --tune-kinds conv --tune-match ":C64:,:R1:" --verbose-tune \
-    --save-tuning gpurun_out/stream_tune/tuned_$1_b$2.json --no-cpu-baseline --no-alt-math --no-host-input --steps 20 \
+  python bench.py --workload $1 --batch $2 --autotune --tune-kinds conv --tune-match ":C$CC:,:R1:" --verbose-tune \
+    --save-tuning gpurun_out/stream_tune/tuned_c${CC}_$1_b$2.json --no-cpu-baseline --no-alt-math --no-host-input --steps 20 \
     2>&1 | grep "^autotune\|\"value\"" | cut -c1-400 | sed "s/^/$1 b$2: /"
 done
