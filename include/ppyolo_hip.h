@@ -104,15 +104,21 @@ int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const v
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int cfg, int splitk);
 int ppy_conv2d_num_configs(void);
+/* First cfg id of the streaming 1x1 kernel (csrc/conv_stream.hip; two ids) and of the patch kernel for the 3x3 stem layers
+ * with C = 32, K = 32 / 64, stride 1 (csrc/conv_patch.hip; one id) -- both f16x2 only; an explicit id on a geometry the kernel
+ * does not cover is PPY_ERR_BAD_ARG. */
+int ppy_conv2d_stream_first_config(void);
+int ppy_conv2d_patch_first_config(void);
 /* Writes the tile configuration / split the heuristic would pick. */
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);
 
 /* The HBM-bound 1x1 "expand" convolutions (ResNet-vd BottleNeck conv3 + shortcut + ReLU, reference
  * model/resnet_vd.py:55-91; C64 -> K256 at 152x152 moves 425 MB for 6 GFLOP) as a persistent streaming kernel
- * (csrc/conv_stream.hip): 1x1, stride 1, C == 64, K % 64 == 0, f16x2 operands (w_f16x2 / scale_f16x2 / amax_in as above),
- * results bit-identical to the f16x2 tiles of ppy_conv2d_bn_act_f32.  The same kernel is selectable there as the LAST
- * ppy_conv2d_num_configs() - 2 .. - 1 cfg ids (variant 0: two workgroups per CU, 1: one); this entry point adds the second
+ * (csrc/conv_stream.hip): 1x1, stride 1, C == 64 with K % 64 == 0 or C == 128 with K % 128 == 0 (K / 64 resp. K / 128 a power of
+ * two <= 16), f16x2 operands (w_f16x2 / scale_f16x2 / amax_in as above),
+ * results bit-identical to the f16x2 tiles of ppy_conv2d_bn_act_f32.  The same kernel is selectable there as the cfg ids
+ * ppy_conv2d_stream_first_config() + variant (variant 0: two workgroups per CU, 1: one); this entry point adds the second
  * output: pooled (or NULL) = [N][H/2][W/2] rows of ld pooled_ld holding the 2x2 / stride-2 average of y -- the AvgPool2d(2, 2)
  * in front of the vd projection shortcut (reference model/resnet_vd.py:29-33) written from the same epilogue, evaluated
  * (((a + b) + c) + d) * 0.25 exactly as ppy_avgpool2x2_f32 does (H, W even).  PPY_ERR_BAD_ARG for any other geometry:

@@ -30,6 +30,9 @@ int ppy_x3_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t st
 // conv_stream.hip: persistent streaming kernel for 1x1 convolutions with C = 64 (f16x2 operands), optional 2x2 average output
 int ppy_stream_num_configs();
 int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_ld, hipStream_t stream);
+// conv_patch.hip: 3x3 / stride 1 / pad 1 with C = 32 (the stem layers), input patch staged once per output tile (f16x2 operands)
+int ppy_patch_num_configs();
+int ppy_patch_dispatch(const ConvArgs &p, int local_cfg, hipStream_t stream);
 
 namespace {
 

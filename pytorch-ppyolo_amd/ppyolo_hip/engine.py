@@ -471,14 +471,13 @@ class HipExecutor(object):
 
     @staticmethod
     def _stream_first():
-        """First tile-configuration id of the streaming 1x1 kernel (the last ops.NUM_STREAM_CFGS ids)."""
-        from ._lib import lib
-        return lib().ppy_conv2d_num_configs() - K.NUM_STREAM_CFGS
+        """First tile-configuration id of the streaming 1x1 kernel."""
+        return K.stream_first_cfg()
 
     def _run_op(self, op, ws=None):
         t = op['op']
         ws = self.ws if ws is None else ws
-        if t == 'conv' and op.get('pool') is not None and op['cfg'] >= self._stream_first():
+        if t == 'conv' and op.get('pool') is not None and self._stream_first() <= op['cfg'] < self._stream_first() + 2:
             K.conv1x1_expand(self.view(op['x']), op['wf16'], op['shift'], self.view(op['y']), op['act'],
                              None if op['res'] is None else self.view(op['res']), self.view(op['pool']),
                              op['cfg'] - self._stream_first(), self._amax(op.get('amax_in_id')), self._amax(op.get('amax_out_id')))

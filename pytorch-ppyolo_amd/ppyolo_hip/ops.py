@@ -135,7 +135,14 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
-NUM_STREAM_CFGS = 2          # the last ids of ppy_conv2d_num_configs(): csrc/conv_stream.hip, variants 0 / 1
+def stream_first_cfg():
+    """First conv cfg id of the streaming 1x1 kernel (csrc/conv_stream.hip; + variant 0 / 1)."""
+    return lib().ppy_conv2d_stream_first_config()
+
+
+def patch_first_cfg():
+    """Conv cfg id of the patch kernel for the 3x3 stem layers (csrc/conv_patch.hip)."""
+    return lib().ppy_conv2d_patch_first_config()
 
 
 def conv1x1_expand(x, w_f16, shift, y, act=None, residual=None, pooled=None, variant=0, amax_in=None, amax_out=None):

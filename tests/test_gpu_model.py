@@ -538,7 +538,7 @@ def test_vd_shortcut_pool_is_written_by_its_producer(monkeypatch):
         prod0[0]['cfg'], prod0[0]['splitk'] = 41, 1         # an f16x2 tile (the shape is not in the table: the heuristic's may be exact fp32)
     base = [p.clone() for p in base_model(x, ims)]
     monkeypatch.setenv('PPYOLO_HIP_POOL_FOLD', '1')
-    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    first = ops.stream_first_cfg()
     for force in (first, first + 1, 41):
         model, _ = build_model(cfg, 0, 'cuda')
         ex = model._plans.executor(x)

@@ -683,7 +683,7 @@ def test_stream_1x1_is_bit_identical_to_the_f16x2_tiles(variant):
     shortcut, all activations, outputs that are slices of a wider buffer."""
     from ppyolo_hip import ops
     from ppyolo_hip._lib import lib
-    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    first = ops.stream_first_cfg()
     g = torch.Generator().manual_seed(4100 + variant)
     for C, N, H, W, K, res, act, y_extra in ((64, 2, 24, 20, 256, True, 'relu', 0), (64, 3, 9, 7, 256, True, 'relu', 0), (64, 1, 6, 6, 64, False, None, 0),
                                              (64, 5, 8, 5, 128, True, 'leaky', 64), (64, 2, 40, 40, 512, False, 'relu', 0), (64, 8, 7, 5, 256, True, None, 32),
@@ -756,7 +756,7 @@ def test_stream_1x1_refuses_what_it_cannot_run():
     """An explicit streaming id on another geometry is an error (PPY_ERR_BAD_ARG), not a silent other kernel."""
     from ppyolo_hip import ops
     from ppyolo_hip._lib import lib, PPYoloHipError
-    first = lib().ppy_conv2d_num_configs() - ops.NUM_STREAM_CFGS
+    first = ops.stream_first_cfg()
     for C, K, R in ((256, 256, 1), (64, 96, 1), (64, 64, 3), (128, 192, 1), (128, 384, 1)):
         x = torch.randn(1, 8, 8, C).cuda()
         wk = torch.randn(K, R, R, C).cuda()
@@ -764,4 +764,52 @@ def test_stream_1x1_refuses_what_it_cannot_run():
         y = torch.zeros(1, 8, 8, K).cuda()
         with pytest.raises(PPYoloHipError):
             ops.conv2d_bn_act(ops.View(x), wk, one, zero, ops.View(y), 1, (R - 1) // 2, None, cfg=first, splitk=1,
+                              w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
+
+
+def test_patch_3x3_is_bit_identical_to_the_f16x2_tiles():
+    """csrc/conv_patch.hip (3x3 / stride 1 / pad 1, C = 32, K = 32 / 64: input patch staged once per 8 x 32-pixel output tile,
+    split into its fp16 terms once) against the 128x64 f16x2 tile of conv_x3.hip -- same products in the same order, so y must be
+    EQUAL; maps narrower / lower than a tile, widths and heights that are no multiples of 32 / 8, one pixel, many images (more
+    tiles than workgroups), all activations, the output as a slice of a wider buffer, per-image scales far apart."""
+    from ppyolo_hip import ops
+    cfg = ops.patch_first_cfg()
+    g = torch.Generator().manual_seed(4300)
+    for N, H, W, K, act, y_extra in ((2, 24, 40, 32, 'relu', 0), (3, 9, 7, 64, 'relu', 0), (1, 1, 1, 32, None, 0), (5, 8, 33, 64, 'leaky', 64),
+                                     (2, 50, 70, 32, 'relu', 32), (40, 17, 65, 64, 'relu', 0), (1, 304, 304, 32, 'relu', 0)):
+        C = 32
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(2 * torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)
+        sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc)
+        outs, maxima = [], []
+        for c in (cfg, 44):
+            y = torch.full((N, H, W, K + y_extra), 9.0).cuda()
+            am = ops.amax_slots(N=N, device=y.device)
+            ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y, 0, K), 1, 1, act, cfg=c, splitk=1, w_f16=wf,
+                              amax_in=ops.amax_slots(xd), amax_out=am)
+            torch.cuda.synchronize()
+            outs.append(y)
+            maxima.append(_amax_per_image(am, N))
+        what = 'N%d %dx%d K%d act %s' % (N, H, W, K, act)
+        ref = F.conv2d(x, w, None, 1, 1) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+        ref = {'relu': F.relu, 'leaky': lambda t: F.leaky_relu(t, 0.1), None: lambda t: t}[act](ref)
+        close(nchw(outs[0][..., :K]), ref, what=what)
+        assert torch.equal(outs[0], outs[1]), what
+        assert torch.equal(maxima[0], outs[0][..., :K].reshape(N, -1).abs().amax(dim=1)), what
+
+
+def test_patch_3x3_refuses_what_it_cannot_run():
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import PPYoloHipError
+    for C, K, R, stride in ((64, 64, 3, 1), (32, 96, 3, 1), (32, 32, 1, 1), (32, 32, 3, 2)):
+        x = torch.randn(1, 8, 8, C).cuda()
+        wk = torch.randn(K, R, R, C).cuda()
+        one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+        Ho, Wo = ops.conv_out_hw(8, 8, R, R, stride, (R - 1) // 2)
+        y = torch.zeros(1, Ho, Wo, K).cuda()
+        with pytest.raises(PPYoloHipError):
+            ops.conv2d_bn_act(ops.View(x), wk, one, zero, ops.View(y), stride, (R - 1) // 2, None, cfg=ops.patch_first_cfg(), splitk=1,
                               w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
