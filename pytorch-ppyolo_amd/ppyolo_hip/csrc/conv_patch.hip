@@ -17,6 +17,11 @@
 #include "conv_shared.h"
 #pragma clang fp contract(off)
 
+#ifndef PPY_PATCH_ABL
+#define PPY_PATCH_ABL 0   // ablation switch (tools/patch_ablate.sh; results are garbage, only the timing means something): 1 = no MFMA
+                          // phase, 2 = no split / plane writes, 3 = no epilogue, 4 = no patch requests, 5 = MFMAs without LDS reads
+#endif
+
 namespace {
 
 constexpr unsigned PT_OOB = 0x80000000u;      // beyond any tensor this kernel accepts (< 2 GB): loads give 0, stores are dropped
@@ -72,9 +77,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
         s_py[i] = pp / PT_PW;
         s_px[i] = pp - s_py[i] * PT_PW;
     }
-    uintx4 stg[PT_NST];
+    uintx4 stg_a[PT_NST], stg_b[PT_NST];      // two sets: a patch is requested TWO tiles ahead (one tile period is ~2.5 us: not
+                                              // enough for a round trip to HBM under load with one workgroup per CU)
 #pragma unroll
-    for (int i = 0; i < PT_NST; ++i) stg[i] = uintx4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < PT_NST; ++i) stg_a[i] = stg_b[i] = uintx4{0u, 0u, 0u, 0u};
     const int tiles_img = q.tiles_x * q.tiles_y;
     auto tile_of = [&](int t, int &n, int &y0, int &x0) {
         n = t / tiles_img;
@@ -82,7 +88,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
         y0 = by * PT_TH;
         x0 = (r - by * q.tiles_x) * PT_TW;
     };
-    auto request = [&](int t) {
+    auto request = [&](int t, uintx4 (&stg)[PT_NST]) {
         int n, y0, x0;
         tile_of(max(t, 0), n, y0, x0);
         const bool live = t >= 0 && t < q.ntiles;
@@ -91,7 +97,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
             const int y = y0 - 1 + s_py[i], x = x0 - 1 + s_px[i];
             const bool ok = live && tid + 512 * i < PT_UNITS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             const unsigned off = ok ? (unsigned)((n * p.H + y) * p.W + x) * (unsigned)(p.x_ld * 4) + (unsigned)((tid + 512 * i) & 7) * 16u : PT_OOB;
-            stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+            if (PPY_PATCH_ABL != 4) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
         }
     };
 
@@ -108,12 +114,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
     };
     const float slope = p.act == PPY_ACT_RELU ? 0.f : (p.act == PPY_ACT_LEAKY ? 0.1f : 1.f);
     __syncthreads();      // the weights are in place
-
-    // ONE code path for requests and waits (conv_stream.hip): the first iteration is a tile in front of the first (stores nothing)
+    // ONE code path for requests and waits (conv_stream.hip): the loop starts two strides in front of the workgroup's first
+    // tile with iterations that only request; the barriers are executed by every wave in every iteration
     const int stride = (int)gridDim.x;
-    for (int t = (int)blockIdx.x - stride; t < q.ntiles; t += stride) {
+    auto do_tile = [&](int t, uintx4 (&stg)[PT_NST]) {
+        const bool live = t >= 0 && t < q.ntiles;
         int n, y0, x0;
-        tile_of(max(t, 0), n, y0, x0);
+        tile_of(live ? t : 0, n, y0, x0);
+        if (live) {
         if (n != sc_n) {      // per-image activation scale (conv_x3.hip): the power of two that puts the tracked maximum into [2^13, 2^14)
             const float mx = amax_read(p.amax_in, n);
             const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 #pragma unroll
         for (int i = 0; i < PT_NST; ++i) {
             const int u = tid + 512 * i;
-            if (u < PT_UNITS) {
+            if (u < PT_UNITS && PPY_PATCH_ABL != 2) {
                 const int pp = u >> 3, g = u & 7;
                 const float x0f = __uint_as_float(stg[i][0]), x1f = __uint_as_float(stg[i][1]);
                 const float x2f = __uint_as_float(stg[i][2]), x3f = __uint_as_float(stg[i][3]);
@@ -146,9 +154,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
                 *reinterpret_cast<uintx2 *>(pl_lo + o) = uintx2{l0, l1};
             }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        request(t + stride);
+        request(t + 2 * stride, stg);
 
         // ---- nine taps x two 16-deep steps: A fragments = the planes at the tap's shift, B fragments from the resident weights
         floatx16 acc[TN];
@@ -157,40 +166,55 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const int tx = lane & 31, kh = lane >> 5;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int pp = (wave + tap / 3) * PT_PW + tx + tap % 3;
-            const int ao = pp * 64, asw = (pp >> 2) & 3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const uintx4 a0 = *reinterpret_cast<const uintx4 *>(pl_hi + ao + (((2 * s + kh) ^ asw) << 4));
-                const uintx4 a1 = *reinterpret_cast<const uintx4 *>(pl_lo + ao + (((2 * s + kh) ^ asw) << 4));
-                uintx4 b0[TN], b1[TN];
+        if (live && PPY_PATCH_ABL != 1) {
+            // 18 steps (tap, 16-deep half), software-pipelined by hand: the LDS reads of step g+1 are issued in front of the
+            // MFMAs of step g and the order is fenced -- left alone, hipcc puts every step's reads directly in front of its
+            // MFMAs behind an lgkmcnt(0), and the (dependent: one accumulator per column tile) MFMAs wait out the LDS latency
+            // 18 times per tile (measured: 65 us for C32 -> K32 at 304x304 either way it fetched its operands).
+            struct Frag {
+                uintx4 a0, a1, b0[TN], b1[TN];
+            };
+            Frag f[2];
+            auto fetch = [&](Frag &fr, int g) {
+                const int tap = g >> 1, s2 = g & 1;
+                const int pp = (wave + tap / 3) * PT_PW + tx + tap % 3;
+                const int ao = pp * 64 + (((2 * s2 + kh) ^ ((pp >> 2) & 3)) << 4);
+                fr.a0 = *reinterpret_cast<const uintx4 *>(pl_hi + ao);
+                fr.a1 = *reinterpret_cast<const uintx4 *>(pl_lo + ao);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int k = j * 32 + tx;
-                    const int bo = (((2 * s + kh) ^ ((k >> 2) & 3)) << 4);
-                    b0[j] = *reinterpret_cast<const uintx4 *>(wl + ((tap * 2 + 0) * K + k) * 64 + bo);
-                    b1[j] = *reinterpret_cast<const uintx4 *>(wl + ((tap * 2 + 1) * K + k) * 64 + bo);
+                    const int bo = (((2 * s2 + kh) ^ ((k >> 2) & 3)) << 4);
+                    fr.b0[j] = *reinterpret_cast<const uintx4 *>(wl + ((tap * 2 + 0) * K + k) * 64 + bo);
+                    fr.b1[j] = *reinterpret_cast<const uintx4 *>(wl + ((tap * 2 + 1) * K + k) * 64 + bo);
                 }
+            };
+            fetch(f[0], 0);
+#pragma unroll
+            for (int g = 0; g < 18; ++g) {
+                if (g + 1 < 18 && PPY_PATCH_ABL != 5) fetch(f[(g + 1) & 1], g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const Frag &c = f[PPY_PATCH_ABL == 5 ? 0 : g & 1];
                 // the three leading products, smallest first, as conv_x3.hip orders them: a1*b0, a0*b1, a0*b0
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0[j]), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c.a1), __builtin_bit_cast(f16x8, c.b0[j]), acc[j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1[j]), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c.a0), __builtin_bit_cast(f16x8, c.b1[j]), acc[j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0[j]), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, c.a0), __builtin_bit_cast(f16x8, c.b0[j]), acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // every wave is done with the planes before anyone overwrites them (next iteration); the epilogue is wave-private
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (!live || PPY_PATCH_ABL == 3) return;
 
         const int y = y0 + wave;
-        const bool row_ok = t >= 0 && y < p.H;
+        const bool row_ok = y < p.H;
         const unsigned rowbase = (unsigned)((n * p.H + y) * p.W + x0) * (unsigned)(p.y_ld * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -216,6 +240,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
             }
             __builtin_amdgcn_wave_barrier();
         }
+    };
+    for (int t = (int)blockIdx.x - 2 * stride; t < q.ntiles; t += 2 * stride) {
+        do_tile(t, stg_a);
+        do_tile(t + stride, stg_b);
     }
     flush(run_mx, run_n);
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the streaming 1x1 kernel + pooled epilogue against the tiles it replaced (tools/probes/old_c64_table.json = the table
-# entries of the C = 64 1x1 layers and of the C = 128 ones, before csrc/conv_stream.hip), alternating on one box.  -> gpurun_out/stream_ab.log
+# A/B of the streaming 1x1 kernel + pooled epilogue and of the patch kernel for the 3x3 stem layers against the tiles they replaced (tools/probes/old_c64_table.json = the table
+# entries of the C = 64 / C = 128 1x1 layers and of the C = 32 3x3 layers before csrc/conv_stream.hip), alternating on one box.  -> gpurun_out/stream_ab.log
 mkdir -p gpurun_out
 OUT=gpurun_out/stream_ab.log
 : > $OUT
