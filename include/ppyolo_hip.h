@@ -109,6 +109,9 @@ int ppy_conv2d_num_configs(void);
  * does not cover is PPY_ERR_BAD_ARG. */
 int ppy_conv2d_stream_first_config(void);
 int ppy_conv2d_patch_first_config(void);
+/* First cfg id of the f16x2 tiles with specialised waves (csrc/conv_ws.hip: four waves deliver operands, four multiply; any
+ * geometry the f16x2 tiles take, split-K included; bit-identical results). */
+int ppy_conv2d_ws_first_config(void);
 /* Writes the tile configuration / split the heuristic would pick. */
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);

@@ -521,10 +521,13 @@ void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
 
 // configuration ids [kNumCfgs, kNumCfgs + ppy_x3_num_configs()) select the split-bf16 kernels of conv_x3.hip, the ids after
 // them the streaming kernel of conv_stream.hip (1x1, C = 64 / 128, f16x2 operands: ppy_conv2d_stream_first_config() + {0, 1}),
-// then the patch kernel of conv_patch.hip (3x3 / stride 1, C = 32, K = 32 / 64, f16x2 operands)
+// then the patch kernel of conv_patch.hip (3x3 / stride 1, C = 32, K = 32 / 64, f16x2 operands), then the f16x2 tiles with
+// specialised waves of conv_ws.hip
 static int stream_first() { return kNumCfgs + ppy_x3_num_configs(); }
 static int patch_first() { return stream_first() + ppy_stream_num_configs(); }
-extern "C" int ppy_conv2d_num_configs(void) { return patch_first() + ppy_patch_num_configs(); }
+static int ws_first() { return patch_first() + ppy_patch_num_configs(); }
+extern "C" int ppy_conv2d_num_configs(void) { return ws_first() + ppy_ws_num_configs(); }
+extern "C" int ppy_conv2d_ws_first_config(void) { return ws_first(); }
 extern "C" int ppy_conv2d_stream_first_config(void) { return stream_first(); }
 extern "C" int ppy_conv2d_patch_first_config(void) { return patch_first(); }
 
@@ -616,6 +619,7 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (c >= ws_first()) return ppy_ws_dispatch(p, c - ws_first(), s, st);
     if (c >= patch_first()) return s == 1 ? ppy_patch_dispatch(p, c - patch_first(), st) : PPY_ERR_BAD_ARG;
     if (c >= stream_first()) return s == 1 ? ppy_stream_dispatch(p, c - stream_first(), nullptr, 0, st) : PPY_ERR_BAD_ARG;
     if (c >= kNumCfgs) return ppy_x3_dispatch(p, c - kNumCfgs, s, st);

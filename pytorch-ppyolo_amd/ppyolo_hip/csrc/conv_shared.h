@@ -33,6 +33,9 @@ int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_
 // conv_patch.hip: 3x3 / stride 1 / pad 1 with C = 32 (the stem layers), input patch staged once per output tile (f16x2 operands)
 int ppy_patch_num_configs();
 int ppy_patch_dispatch(const ConvArgs &p, int local_cfg, hipStream_t stream);
+// conv_ws.hip: the f16x2 tiles with specialised waves (four deliver operands, four multiply)
+int ppy_ws_num_configs();
+int ppy_ws_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
 
 namespace {
 

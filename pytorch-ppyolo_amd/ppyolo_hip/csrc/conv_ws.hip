@@ -1,0 +1,352 @@
+// f16x2 implicit-GEMM convolution with SPECIALISED waves: four waves only deliver operands, four only multiply.
+//
+// Same operator, same operand layouts in the LDS, same products in the same order and the same epilogue as the f16x2 tiles of
+// conv_x3.hip (results are bit-identical).  What changes is who issues what.  In conv_x3.hip every wave drops its share of a
+// chunk's LDS-DMA pieces into its own MFMA stream; measured there: operand delivery alone takes 699
+// cycles per 32-deep chunk, the MFMAs 768, and together they take 1399 -- the times ADD, because a wave that issues a DMA piece
+// into a backed-up memory pipeline stalls in order, its MFMAs included; and ONE extra producer wave could not issue fast enough
+// (a piece every ~50 cycles).  Here a workgroup has eight waves: waves 4..7 issue ALL pieces (a quarter each) and wait on their
+// own vmcnt, waves 0..3 (2 x 2 over the tile) never execute a vector-memory instruction inside the main loop -- LDS reads, the
+// operand split and MFMAs only.  One workgroup barrier per chunk couples the two groups exactly as conv_x3.hip's does: at the
+// barrier of chunk k the consumers have read all of chunk k and the producers have seen chunk k+1 land; behind it the
+// producers refill chunk k's stage with chunk k+NS.
+#include "conv_shared.h"
+
+#include <type_traits>
+
+namespace {
+
+template <int BM, int BN, int NS, bool SPLIT, bool VEC>
+__global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
+    static_assert(BM % (8 * NWP) == 0 && B_ROWS % (16 * NWP) == 0, "whole DMA instructions per producer wave");
+    constexpr int A_PASS = BM / (8 * NWP), B_PASS = B_ROWS / (16 * NWP), G = A_PASS + B_PASS;
+    constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64, STAGE = A_BYTES + B_BYTES;
+    static_assert((NS - 1) * G <= 63, "6-bit vmcnt");
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem_ws[];
+    char *smem = smem_ws;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.K + BN - 1) / BN;
+    int tile_id;
+    {   // XCD-contiguous tile order (conv_x3.hip)
+        const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7;
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        tile_id = xcd * q + min(xcd, r) + idx;
+    }
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kc_begin = split * p.chunks_per_split;
+    const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
+    const int nchunks = kc_end - kc_begin;
+    const int hw = p.Ho * p.Wo;
+
+    if (wave >= 4) {
+        // ================= producers: every LDS-DMA piece of the tile, a quarter per wave =================
+        const int pw = wave - 4;
+        const unsigned OOB = 0xFFFFFFF0u;
+        const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
+        unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
+        {
+            const int drow = lane >> 3, dslot = lane & 7;
+            const int step_rows = 8 * NWP;
+            const int step_ho = step_rows / p.Wo, step_wo = step_rows - step_ho * p.Wo;
+            int m_first = min(m0 + pw * 8 + drow, p.M - 1);
+            int n = m_first / hw, rem = m_first - n * hw;
+            int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+#pragma unroll
+            for (int j = 0; j < A_PASS; ++j) {
+                const int row = (j * NWP + pw) * 8 + drow;
+                const int scol = dslot ^ ((row >> 1) & 7);
+                const int mr = m0 + row;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                a_off[j] = (unsigned)((((long long)n * p.H + hi0) * p.W + wi0) * p.x_ld * 4 + bias + scol * 16);
+                unsigned colmask = 0, okb = 0;
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(wi0 + s2) < (unsigned)p.W) colmask |= 1u << s2;
+                for (int r = 0; r < p.R; ++r)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H) okb |= colmask << (r * p.S);
+                a_ok[j] = mr < p.M ? okb : 0u;
+                wo += step_wo;
+                ho += step_ho;
+                if (wo >= p.Wo) { wo -= p.Wo; ++ho; }
+                while (ho >= p.Ho) { ho -= p.Ho; ++n; }
+            }
+        }
+        {
+            const int drow = lane >> 2, dslot = lane & 3;
+            const long long plane_bytes = (long long)p.K * p.Kred * 2;
+#pragma unroll
+            for (int j = 0; j < B_PASS; ++j) {
+                const int rb = (j * NWP + pw) * 16 + drow;          // row of the [2*BN] B tile
+                const int plane = rb / BN, nrow = rb - plane * BN;
+                const int scol = dslot ^ ((rb >> 2) & 3);
+                const int k = min(n0 + nrow, p.K - 1);              // rows >= K are masked at store
+                b_off[j] = (unsigned)(plane * plane_bytes + (long long)k * 64 + scol * 16);      // [chunk][K][32] planes
+            }
+        }
+        const int RS = p.R * p.S;
+        int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
+        int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
+        const char *xb = reinterpret_cast<const char *>(p.x) - bias;
+        const char *wb = reinterpret_cast<const char *>(p.wf16);
+        auto issue = [&](int stage, bool have) {
+            const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
+            const long long b_uni = ((long long)l_tap * (p.C / 32) + l_cc) * p.K * 64;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? b_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
+            const unsigned tapbit = have ? (1u << l_tap) : 0u;
+            const unsigned lds = (unsigned)(stage * STAGE + pw * 1024);
+#pragma unroll
+            for (int d = 0; d < A_PASS; ++d) {
+                const unsigned off = (a_ok[d] & tapbit) ? a_off[d] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PASS; ++j) {
+                const unsigned off = have ? b_off[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + lds + A_BYTES + j * NWP * 1024), 16, off, 0, 0, 0);
+            }
+            ++l_tap;
+            ++l_s;
+            if (l_s == p.S) { l_s = 0; ++l_r; }
+            if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
+        };
+        if (nchunks > 0) {
+            // NS stage slots are requested up front, slots past the end of the reduction as out-of-range dummies, so that the
+            // number of outstanding pieces is the same at every wait below
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) issue(sidx, sidx < nchunks);
+            wait_vmcnt<(NS - 1) * G>();                  // chunk 0 has landed
+            __builtin_amdgcn_s_barrier();
+            int st = 0;
+            for (int k = 0; k < nchunks; ++k) {
+                wait_vmcnt<(NS - 2) * G>();              // chunk k+1 has landed (this wave's pieces; the barrier makes it all of them)
+                __builtin_amdgcn_s_barrier();            // ... and the consumers have read all of chunk k
+                issue(st, k + NS < nchunks);
+                st = st + 1 == NS ? 0 : st + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================= consumers: 2 x 2 waves over the tile; LDS reads, operand split, MFMAs =================
+    const int wm = wave >> 1, wn = wave & 1;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragment read offsets (bytes).  MFMA k-step s (16 deep), lane-half h: k = 16s + 8h + [0,8)
+    //   A: two 16-byte slots 4s+2h, 4s+2h+1 of row (lane&31);  B: one slot 2s+h of row (lane&31) per plane
+    const int frow = lane & 31, fkh = lane >> 5;
+    const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 2) & 3;
+    int a_foff[2][2], b_foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
+        a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
+    }
+    float sa[TM], inv_sa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {        // per-image activation scale (conv_x3.hip)
+        const int mrow = min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1);
+        const float mx = amax_read(p.amax_in, mrow / hw);
+        const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        int f = 267 - e;
+        f = f < 103 ? 103 : (f > 167 ? 167 : f);
+        sa[i] = __uint_as_float((unsigned)f << 23);
+        inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
+    }
+
+    struct Frag {        // operands of one k-step
+        uintx4 a[TM][NP];
+        uintx4 b[NP][TN];
+    };
+    constexpr int NM = 3 * TM * TN;            // MFMAs per k-step
+    constexpr int NRA = 2 * TM, NRB = NP * TN, NR = NRA + NRB;
+    constexpr int NSL = 3 * 4 * TM;            // split stages per k-step (3 dependent stages x 4 pairs x TM)
+    constexpr int RPS = (NR + NM - 1) / NM;
+    constexpr int LEAD0 = (NRA + RPS - 1) / RPS + 1;
+    constexpr int LEAD = LEAD0 < NM ? LEAD0 : NM - 1;
+    constexpr int PER = (NSL + (NM - LEAD) - 1) / (NM - LEAD);
+    // One k-step: NM slots { one MFMA of step g ; at most RPS LDS reads for step g+1 ; PER stages of the split of step g+1's A
+    // fragments }, fenced so that hipcc keeps that order (conv_x3.hip's step() without the DMA pieces)
+    auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;      // k-step (0/1) of the chunk the NEXT operands come from
+        constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0};      // a1*b0, a0*b1, a0*b0: smallest first
+        const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
+        const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
+        floatx4 raw[TM][2];
+        float ra[TM][4], rb[TM][4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            {
+                const int t = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][ta[t]]),
+                                                                  __builtin_bit_cast(f16x8, cur.b[tb[t]][j]), acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < RPS; ++u) {
+                const int r = m * RPS + u;
+                if (r >= NR) {
+                } else if (r < NRA) {
+                    raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                } else {
+                    const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
+                    nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
+                }
+            }
+            if (m >= LEAD) {
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int sl = (m - LEAD) * PER + u;
+                    if (sl < NSL) {
+                        const int st = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q = pr % 4;
+                        const float xa = raw[i][q >> 1][(q & 1) * 2], xb = raw[i][q >> 1][(q & 1) * 2 + 1];
+                        if (st == 0) {
+                            nxt.a[i][0][q] = cvt_pk_f16(xa * sa[i], xb * sa[i]);
+                        } else if (st == 1) {     // residual of the SCALED value: fma(x, sa, -a0) is exact
+                            const unsigned P = nxt.a[i][0][q];
+                            ra[i][q] = fmaf(xa, sa[i], -f16_lo(P));
+                            rb[i][q] = fmaf(xb, sa[i], -f16_hi(P));
+                        } else {
+                            nxt.a[i][1][q] = cvt_pk_f16(ra[i][q], rb[i][q]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+
+    if (nchunks > 0) {
+        Frag f0, f1;
+        __builtin_amdgcn_s_barrier();            // chunk 0 is in the LDS
+        {   // operands of (chunk 0, k-step 0): not overlapped with anything
+            const char *a_ptr = smem + wm * WM * 128;
+            const char *b_ptr = smem + A_BYTES + wn * WN * 64;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
+                const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xa = q < 2 ? lo[2 * q] : hi[2 * q - 4], xb = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+                    const unsigned P0 = cvt_pk_f16(xa * sa[i], xb * sa[i]);
+                    f0.a[i][0][q] = P0;
+                    f0.a[i][1][q] = cvt_pk_f16(fmaf(xa, sa[i], -f16_lo(P0)), fmaf(xb, sa[i], -f16_hi(P0)));
+                }
+            }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
+        }
+        int st = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            step(f0, f1, st, S1());                              // k-step 0 of chunk k  ||  fetch + split k-step 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of chunk k has returned
+            __builtin_amdgcn_s_barrier();
+            st = st + 1 == NS ? 0 : st + 1;
+            step(f1, f0, st, S0());                              // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float rowscale[TM][4];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) rowscale[i][t] = __shfl(inv_sa[i], (lane >> 3) + 8 * t);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float inv = __shfl(inv_sa[i], (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][e] *= inv;
+            }
+    }
+    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
+                                              VEC ? rowscale : nullptr);
+#endif
+}
+
+template <int BM, int BN, int NS, bool SPLIT, bool VEC>
+int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC>;
+    static PpyLdsAttr attr;
+    if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), lds, stream, p);
+    return PPY_OK;
+}
+
+template <int BM, int BN, int NS>
+int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
+    const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
+    const long long wbytes = (long long)p.K * p.Kred * 2 * 2;
+    if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
+    constexpr int STAGE_BYTES = BM * 128 + 2 * BN * 64;
+    static_assert(NS * STAGE_BYTES <= 160 * 1024, "LDS");
+    size_t lds = (size_t)NS * STAGE_BYTES;
+    const size_t epi = (size_t)4 * 32 * LDS_LD * sizeof(float);
+    if (lds < epi) lds = epi;
+    p.nstages = NS;
+    p.chunks_total = p.R * p.S * (p.C / 32);
+    p.chunks_per_split = ceil_div(p.chunks_total, splits);
+    splits = ceil_div(p.chunks_total, p.chunks_per_split);
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
+    const bool vec = vec_epilogue_ok(p);
+    int rc;
+    if (splits > 1) {
+        rc = vec ? launch_ws_one<BM, BN, NS, true, true>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, true, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+        launch_splitk_reduce(p, splits, vec, stream);
+    } else {
+        rc = vec ? launch_ws_one<BM, BN, NS, false, true>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, false, false>(p, splits, lds, tiles, stream);
+        if (rc != PPY_OK) return rc;
+    }
+    return ppy_launch_status();
+}
+
+}  // namespace
+
+// local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6
+// (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
+int ppy_ws_num_configs() { return 4; }
+
+int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
+    if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
+    ConvArgs q = p;
+    q.scale = p.scale_f16;
+    q.posb = p.posb ? p.posb_f16 : nullptr;
+    switch (c) {
+        case 0: return launch_ws<128, 128, 3>(q, s, st);
+        case 1: return launch_ws<128, 128, 4>(q, s, st);
+        case 2: return launch_ws<64, 128, 4>(q, s, st);
+        case 3: return launch_ws<64, 128, 6>(q, s, st);
+    }
+    return PPY_ERR_BAD_ARG;
+}

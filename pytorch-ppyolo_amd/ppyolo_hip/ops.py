@@ -140,6 +140,11 @@ def stream_first_cfg():
     return lib().ppy_conv2d_stream_first_config()
 
 
+def ws_first_cfg():
+    """First conv cfg id of the f16x2 tiles with specialised waves (csrc/conv_ws.hip)."""
+    return lib().ppy_conv2d_ws_first_config()
+
+
 def patch_first_cfg():
     """Conv cfg id of the patch kernel for the 3x3 stem layers (csrc/conv_patch.hip)."""
     return lib().ppy_conv2d_patch_first_config()

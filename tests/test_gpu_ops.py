@@ -818,3 +818,43 @@ def test_patch_3x3_refuses_what_it_cannot_run():
         with pytest.raises(PPYoloHipError):
             ops.conv2d_bn_act(ops.View(x), wk, one, zero, ops.View(y), stride, (R - 1) // 2, None, cfg=ops.patch_first_cfg(), splitk=1,
                               w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
+
+
+def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
+    """csrc/conv_ws.hip (four waves deliver operands, four multiply) against the f16x2 tiles of conv_x3.hip: same operand
+    layouts, same products in the same order, same epilogue -- EQUAL outputs over 3x3 / 1x1, strides, tiny maps, tiles that
+    straddle images, K not a multiple of 4 (scalar epilogue) or of the tile, shortcuts, split-K that does not divide the chunks,
+    reductions shorter than the stage count."""
+    from ppyolo_hip import ops
+    first = ops.ws_first_cfg()
+    from ppyolo_hip._lib import lib
+    nws = lib().ppy_conv2d_num_configs() - first
+    g = torch.Generator().manual_seed(4400)
+    ws = torch.empty(16 << 20).cuda()
+    for N, H, W, C, K, R, stride, res, splitk in ((2, 19, 19, 64, 136, 3, 1, True, 1), (1, 1, 1, 32, 40, 3, 1, False, 1), (3, 1, 7, 64, 72, 1, 1, True, 2),
+                                                  (5, 2, 2, 96, 64, 3, 1, False, 4), (1, 33, 31, 32, 258, 3, 2, False, 2), (4, 6, 5, 160, 27, 3, 1, False, 5),
+                                                  (2, 38, 38, 256, 256, 1, 1, True, 1), (2, 24, 24, 128, 256, 3, 1, False, 1), (2, 13, 11, 1024, 100, 1, 1, True, 3)):
+        pad = (R - 1) // 2
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, R, R, generator=g) * (1.0 / (R * R * C) ** 0.5)
+        sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        ref = F.conv2d(x, w, None, stride, pad) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+        r = torch.randn(ref.shape, generator=g) if res else None
+        ref = F.leaky_relu(ref + r if res else ref, 0.1)
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        rd = nhwc(r).cuda() if res else None
+        wf = ops.split_weights_f16x2(wk, sc)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        outs = []
+        for c in [41] + [first + i for i in range(nws)]:
+            y = torch.full((N, Ho, Wo, K), 9.0).cuda()
+            am = ops.amax_slots(N=N, device=y.device)
+            ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y), stride, pad, 'leaky', residual=None if rd is None else ops.View(rd),
+                              cfg=c, splitk=splitk, ws=ws, w_f16=wf, amax_in=ops.amax_slots(xd), amax_out=am)
+            torch.cuda.synchronize()
+            outs.append(y)
+        what = 'N%d %dx%d C%d K%d R%d s%d res %s split %d' % (N, H, W, C, K, R, stride, res, splitk)
+        close(nchw(outs[0]), ref, what=what)
+        for i, y in enumerate(outs[1:]):
+            assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
