@@ -145,6 +145,10 @@ def ws_first_cfg():
     return lib().ppy_conv2d_ws_first_config()
 
 
+def ws_num_cfgs():
+    return lib().ppy_conv2d_num_configs() - lib().ppy_conv2d_ws_first_config()
+
+
 def patch_first_cfg():
     """Conv cfg id of the patch kernel for the 3x3 stem layers (csrc/conv_patch.hip)."""
     return lib().ppy_conv2d_patch_first_config()

@@ -274,10 +274,13 @@ class TrainStep(object):
         tab = self._tuned_f if f16 else self._tuned
         tkey = key + ':f' if f16 else key
         ent = tab.get(tkey)
-        if ent is None and self.tune:
+        # PPYOLO_HIP_TRAIN_RETUNE=1: measure the f16x2 geometries again even where the table has an entry (new candidate kernels)
+        again = f16 and os.environ.get('PPYOLO_HIP_TRAIN_RETUNE', '0') == '1' and tkey not in self._measured
+        if (ent is None or again) and self.tune:
             ids = list(range(NUM_FP32_CFGS, NUM_FP32_CFGS + 9))                 # the nine bf16x3 tiles
             if f16:
                 ids = list(range(NUM_X3_F16_FIRST, NUM_X3_F16_LAST + 1))        # the nine f16x2 tiles x {2, 3, 4} LDS stages
+                ids += list(range(K.ws_first_cfg(), K.ws_first_cfg() + K.ws_num_cfgs()))      # ... and with specialised waves (csrc/conv_ws.hip)
             best = None
             for cfg_id in ids:
                 for splitk in (1, 2, 3, 4, 6, 8):
