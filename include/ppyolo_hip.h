@@ -149,6 +149,20 @@ int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f16x2, const 
  *     Pixel slices are combined in a fixed order, so results are run-to-run identical.
  * ws: ppy_conv2d_{dgrad,wgrad}_workspace_bytes() bytes, 256-byte aligned.
  */
+/* Training-mode forward of the convolution in front of a BatchNorm2d on batch statistics (reference
+ * model/custom_layers.py:243-253): y = conv(x, w) + bias on an f16x2 tile (cfg >= 0: an f16x2 id of csrc/conv_x3.hip or
+ * csrc/conv_ws.hip; one split) and, from the same epilogue, the first pass of the BatchNorm: per wave row-tile ("slice") and
+ * channel the triple (n, mean, M2) of y in bn_partials[*bn_slices][K][3].  ppy_conv2d_bn_partials_bytes(M, K) bytes always hold
+ * the triples AND the scratch ppy_bn_train_stats_merge_f32 needs behind them; that call turns them into mean / invstd / running
+ * statistics exactly as ppy_bn_train_stats_f32 does from a pass over y (same Chan merge, slices in order) -- without reading y
+ * again.  w_f16x2 / scale_f16x2: ppy_conv2d_split_weights_f16x2 with scale = 1.  PPY_ERR_UNSUPPORTED: cfg names another kernel
+ * family (the caller then runs ppy_conv2d_bn_act_f32 + ppy_bn_train_stats_f32). */
+size_t ppy_conv2d_bn_partials_bytes(long long M, int K);
+int ppy_conv2d_train_fwd_f32(const float *x, int x_ld, const float *w_krsc, const void *w_f16x2, const float *scale_f16x2,
+                             const float *bias, float *y, int y_ld, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                             int cfg, const float *amax_in, float *bn_partials, size_t bn_partials_bytes, int *bn_slices, void *stream);
+int ppy_bn_train_stats_merge_f32(float *partials, size_t partials_bytes, int slices, int C, float eps, float momentum, float *mean,
+                                 float *invstd, float *running_mean, float *running_var, void *stream);
 int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float *dx, int dx_ld, int N, int H, int W,
                          int C, int K, int R, int S, int stride, int pad, int cfg, int splitk, const float *amax_dy, void *ws,
                          size_t ws_bytes, void *stream);

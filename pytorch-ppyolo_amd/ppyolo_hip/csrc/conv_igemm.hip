@@ -619,6 +619,8 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
+    // (statistics from the epilogue exist in the f16x2 kernels only: conv_x3.hip's tiles, conv_stream.hip, conv_patch.hip, conv_ws.hip)
+    if (p.bn_part && c < kNumCfgs + ppy_x3_f16_base()) return PPY_ERR_UNSUPPORTED;
     if (c >= ws_first()) return ppy_ws_dispatch(p, c - ws_first(), s, st);
     if (c >= patch_first()) return s == 1 ? ppy_patch_dispatch(p, c - patch_first(), st) : PPY_ERR_BAD_ARG;
     if (c >= stream_first()) return s == 1 ? ppy_stream_dispatch(p, c - stream_first(), nullptr, 0, st) : PPY_ERR_BAD_ARG;
@@ -683,4 +685,45 @@ extern "C" int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f1
     p.nstages = 2;
     p.trace = nullptr;
     return ppy_stream_dispatch(p, variant, pooled, pooled_ld, (hipStream_t)stream);
+}
+
+
+// Training-mode forward of Conv2dUnit's convolution (reference model/custom_layers.py:243-253: conv (+ bias) in front of a
+// BatchNorm2d on batch statistics): y = conv(x, w) + bias on an f16x2 kernel (cfg: any f16x2 id -- tiles, streaming 1x1, stem
+// patch, specialised waves; one split), AND the first pass of the BatchNorm from the same epilogue -- (n, mean, M2) of every channel per wave row-tile in
+// bn_partials [*bn_slices][K][3] (ppy_conv2d_bn_partials_bytes(M, K) bytes are always enough), to be merged by
+// ppy_bn_train_stats_merge_f32.  The separate statistics pass over y (ppy_bn_train_stats_f32) re-reads the whole tensor.
+// scale_f16x2: from ppy_conv2d_split_weights_f16x2 with scale = 1.  PPY_ERR_UNSUPPORTED for any other kernel family.
+// slices of 32 rows, plus what row-tiles (<= 256 rows) and the stem patch kernel's 8 x 32-pixel tiles over-cover at the borders
+static long long bn_slice_capacity(long long M) { return 4 * ((M + 31) / 32) + 64; }
+extern "C" size_t ppy_conv2d_bn_partials_bytes(long long M, int K) {
+    return (size_t)(bn_slice_capacity(M) + (bn_slice_capacity(M) + 63) / 64) * K * 3 * sizeof(float);      // + the first merge level's output
+}
+
+extern "C" int ppy_conv2d_train_fwd_f32(const float *x, int x_ld, const float *w_krsc, const void *w_f16x2, const float *scale_f16x2,
+                                        const float *bias, float *y, int y_ld, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                        int pad, int cfg, const float *amax_in, float *bn_partials, size_t bn_partials_bytes,
+                                        int *bn_slices, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && w_krsc && w_f16x2 && scale_f16x2 && bias && y && amax_in && bn_partials && bn_slices && cfg >= 0);
+    Geometry g;
+    if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return PPY_ERR_BAD_ARG;
+    PPY_CHECK_ARG(x_ld >= C && x_ld % 4 == 0 && y_ld >= K && ((uintptr_t)x & 15) == 0);
+    PPY_CHECK_ARG(cfg < ppy_conv2d_num_configs());
+    if (bn_partials_bytes < ppy_conv2d_bn_partials_bytes(g.M, K)) return PPY_ERR_WORKSPACE;
+    ConvArgs p;
+    p.x = x; p.w = w_krsc; p.w3 = nullptr; p.wf16 = (const unsigned short *)w_f16x2;
+    p.scale_f16 = scale_f16x2; p.posb_f16 = nullptr; p.amax_in = amax_in; p.amax_out = nullptr; p.scale = scale_f16x2; p.shift = bias;
+    p.res = nullptr; p.posb = nullptr; p.y = y; p.part = nullptr;
+    p.x_ld = x_ld; p.res_ld = 0; p.y_ld = y_ld;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;
+    p.stride = stride; p.pad = pad; p.act = PPY_ACT_NONE; p.ups = 0;
+    p.M = g.M; p.Kred = g.Kred; p.cchunks = C / BK; p.chunks_total = g.chunks; p.chunks_per_split = g.chunks;
+    p.nstages = 2;
+    p.trace = nullptr;
+    p.bn_part = bn_partials;
+    p.bn_slices_host = bn_slices;
+    p.bn_capacity = (int)bn_slice_capacity(g.M);
+    *bn_slices = 0;
+    return dispatch_cfg(p, cfg, 1, (hipStream_t)stream);
 }

@@ -34,7 +34,7 @@ struct PatchArgs {
     int tiles_x, tiles_y, ntiles;
 };
 
-template <int TN>
+template <int TN, bool BNS = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
 __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
@@ -215,6 +215,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 
         const int y = y0 + wave;
         const bool row_ok = y < p.H;
+        if constexpr (BNS) {      // training forward: the BatchNorm's first pass from here (conv_shared.h), one slice per (tile, output row)
+            const int nv = row_ok ? min(max(p.W - x0, 0), 32) : 0;
+            const float inv_f[1] = {inv_sa};
+            tile_bn_stats<1, TN, 32, 32 * TN>(p, reinterpret_cast<const floatx16(&)[1][TN]>(acc), inv_f, p.M - nv, 0, 0, 0, lane, t * PT_TH + wave);
+        }
         const unsigned rowbase = (unsigned)((n * p.H + y) * p.W + x0) * (unsigned)(p.y_ld * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -249,9 +254,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 #endif
 }
 
-template <int TN>
+template <int TN, bool BNS = false>
 int launch_patch(const PatchArgs &q, hipStream_t stream) {
-    auto k = conv3x3_patch_kernel<TN>;
+    if constexpr (!BNS) {
+        if (q.c.bn_part) return launch_patch<TN, true>(q, stream);
+    }
+    auto k = conv3x3_patch_kernel<TN, BNS>;
     const size_t lds = (size_t)2 * PT_PLANE + (size_t)9 * 2 * 32 * TN * 64 + (size_t)8 * 32 * LDS_LD * sizeof(float);
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
@@ -273,6 +281,11 @@ int ppy_patch_dispatch(const ConvArgs &p, int local, hipStream_t stream) {
     if (!vec_epilogue_ok(p) || ((uintptr_t)p.x & 15) != 0 || p.x_ld % 4 != 0) return PPY_ERR_BAD_ARG;
     const long long lim = 0x7FFFF000LL;
     if ((long long)p.M * p.x_ld * 4 >= lim || (long long)p.M * p.y_ld * 4 >= lim) return PPY_ERR_UNSUPPORTED;
+    if (p.bn_part) {
+        if (p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
+        if (p.N * ceil_div(p.W, PT_TW) * ceil_div(p.H, PT_TH) * PT_TH > p.bn_capacity) return PPY_ERR_WORKSPACE;
+        if (p.bn_slices_host) *p.bn_slices_host = p.N * ceil_div(p.W, PT_TW) * ceil_div(p.H, PT_TH) * PT_TH;
+    }
     PatchArgs q;
     q.c = p;
     q.c.scale = p.scale_f16;

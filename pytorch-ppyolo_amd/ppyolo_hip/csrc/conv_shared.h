@@ -17,6 +17,12 @@ struct ConvArgs {
     int M, Kred, cchunks, chunks_total, chunks_per_split;
     int nstages;                 // conv_x3 kernels: LDS stages (2..4 chunks resident; 2 in every other kernel)
     unsigned long long *trace;   // debug: per-workgroup timeline (ppy_debug_set_trace), NULL in production
+    // training forward (ppy_conv2d_train_fwd_f32): per-channel BatchNorm statistics of y from the epilogue, as (n, mean, M2)
+    // triples [slice][K][3] with one slice per wave row-tile (tile_bn_stats below); the launcher reports the slice count to
+    // *bn_slices_host (a HOST pointer: never dereferenced on the device)
+    float *bn_part = nullptr;
+    int *bn_slices_host = nullptr;
+    int bn_capacity = 0;         // slices bn_part has room for (a launcher that needs more returns PPY_ERR_WORKSPACE)
 };
 
 struct Geometry {
@@ -208,6 +214,58 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
         }
     }
     if (!SPLIT && p.amax_out) amax_track2(amx, amx_hi, n_lo, n_hi, p.amax_out, blockIdx.x * 8 + wave);
+}
+
+// Per-channel (n, mean, M2) of the values tile_epilogue is about to store for this wave's WM x WN sub-tile -- the first pass of a
+// training-mode BatchNorm (reference model/custom_layers.py:243-253, torch.nn.BatchNorm2d on batch statistics) without reading
+// y back: in the accumulator layout a lane holds 16 rows of ONE column per 32x32 tile, so a column's sum over the sub-tile is a
+// sum over registers and one exchange with lane ^ 32.  Two passes over the registers (mean, then centred squares): as accurate
+// as the two-pass slice kernel of train.hip; csrc/train.hip merges the slices with Chan's formula.  inv_sa: the f16x2 kernels'
+// inverse activation scale of row (lane & 31) of tile i (the accumulators are still scaled).  Plain conv + bias only
+// (no shortcut, no position bias, no activation, no upsampling): v = fma(acc * inv, scale, shift) as the epilogue computes it.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void tile_bn_stats(const ConvArgs &p, const floatx16 (&acc)[TM][TN], const float (&inv_sa)[TM], int m0, int n0,
+                                              int wm, int wn, int lane, int slice) {
+    const int row0 = m0 + wm * WM;
+    const int nvalid = min(max(p.M - row0, 0), WM);
+    float inv[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) inv[i][e] = __shfl(inv_sa[i], (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool colok = col < p.K;
+        const float sc = colok ? p.scale[col] : 1.f, sh = colok ? p.shift[col] : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const float v = fmaf(acc[i][j][e] * inv[i][e], sc, sh);
+                sum += r < nvalid ? v : 0.f;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = nvalid > 0 ? sum / (float)nvalid : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const float d = fmaf(acc[i][j][e] * inv[i][e], sc, sh) - mean;
+                m2 += r < nvalid ? d * d : 0.f;
+            }
+        m2 += __shfl_xor(m2, 32);
+        if (colok && lane < 32) {
+            float *o = p.bn_part + ((long long)slice * p.K + col) * 3;
+            o[0] = (float)nvalid;
+            o[1] = mean;
+            o[2] = m2;
+        }
+    }
 }
 
 // ---- exact operand splits for the 16-bit MFMA (conv_x3.hip header: bf16x3 = 3 bf16 terms, f16x2 = 2 fp16 terms) ----

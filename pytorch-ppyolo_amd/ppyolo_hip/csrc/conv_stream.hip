@@ -35,7 +35,7 @@ struct StreamArgs {
 // (coalesced loads one tile ahead -> ds_write -> ONE workgroup barrier per tile -> swizzled fragment reads); the K / 128
 // workgroups of a pixel stream sit on one XCD (block ids 8 apart), so the tile comes from HBM once.  (Three workgroups per CU
 // would need <= 168 VGPRs: 20-25 spilled, and scratch reloads queue behind the prefetches in the in-order vmcnt.)
-template <int KS, int TN, bool RES, bool POOL, bool ALDS>
+template <int KS, int TN, bool RES, bool POOL, bool ALDS, bool BNS = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
 __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
@@ -265,6 +265,12 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
             for (int j = 0; j < TN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, wf[0][j][s]), acc[j], 0, 0, 0);
         }
+        if constexpr (BNS) {       // training forward: the BatchNorm's first pass from here (conv_shared.h), one slice per 32-pixel tile
+            if (t >= 0) {
+                const float inv_f[1] = {fidx < bnd ? inv0 : inv1};
+                tile_bn_stats<1, TN, 32, SW>(p, reinterpret_cast<const floatx16(&)[1][TN]>(acc), inv_f, t * 32, n0, 0, 0, lane, t);
+            }
+        }
         // the activations of the next tile of this wave
         if constexpr (!ALDS) request_a(t + nstreams);
         epi_pixels(t + nstreams, pix_n, idx_n);
@@ -329,6 +335,12 @@ int launch_stream_one(const StreamArgs &q, int grid, hipStream_t stream) {
 
 template <int KS, int TN, bool ALDS>
 int launch_stream(const StreamArgs &q, int grid, hipStream_t stream) {
+    if (q.c.bn_part) {       // (the dispatcher has checked: no pooled output, no shortcut)
+        auto k = conv1x1_stream_kernel<KS, TN, false, false, ALDS, true>;
+        const size_t lds = (size_t)4 * 32 * LDS_LD * sizeof(float) + (ALDS ? 2 * 32 * KS * 16 * sizeof(float) : 0);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream, q);
+        return ppy_launch_status();
+    }
     if (q.pool) return q.c.res ? launch_stream_one<KS, TN, true, true, ALDS>(q, grid, stream) : launch_stream_one<KS, TN, false, true, ALDS>(q, grid, stream);
     return q.c.res ? launch_stream_one<KS, TN, true, false, ALDS>(q, grid, stream) : launch_stream_one<KS, TN, false, false, ALDS>(q, grid, stream);
 }
@@ -357,6 +369,11 @@ int ppy_stream_dispatch(const ConvArgs &p, int local, float *pool, int pool_ld, 
     const long long lim = 0x7FFFF000LL;
     if ((long long)p.M * p.x_ld * 4 >= lim || (long long)p.M * p.y_ld * 4 >= lim || (p.res && (long long)p.M * p.res_ld * 4 >= lim))
         return PPY_ERR_UNSUPPORTED;
+    if (p.bn_part) {         // BatchNorm statistics from the epilogue: plain conv + bias, one slice per 32-pixel tile
+        if (pool || p.res || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
+        if (ceil_div(p.M, 32) > p.bn_capacity) return PPY_ERR_WORKSPACE;
+        if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, 32);
+    }
     StreamArgs q;
     q.c = p;
     q.c.scale = p.scale_f16;

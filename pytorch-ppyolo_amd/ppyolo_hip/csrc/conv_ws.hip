@@ -16,7 +16,7 @@
 
 namespace {
 
-template <int BM, int BN, int NS, bool SPLIT, bool VEC>
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * 2 + wm);
     float rowscale[TM][4];
     if constexpr (VEC) {
 #pragma unroll
@@ -292,9 +293,12 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #endif
 }
 
-template <int BM, int BN, int NS, bool SPLIT, bool VEC>
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false>
 int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC>;
+    if constexpr (!SPLIT && !BNS) {
+        if (p.bn_part) return launch_ws_one<BM, BN, NS, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
+    }
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), lds, stream, p);
@@ -317,6 +321,11 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
     const bool vec = vec_epilogue_ok(p);
+    if (p.bn_part) {         // BatchNorm statistics from the epilogue: one split, plain conv + bias
+        if (splits > 1 || p.res || p.posb || p.ups || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
+        if (ceil_div(p.M, BM) * 2 > p.bn_capacity) return PPY_ERR_WORKSPACE;
+        if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * 2;
+    }
     int rc;
     if (splits > 1) {
         rc = vec ? launch_ws_one<BM, BN, NS, true, true>(p, splits, lds, tiles, stream)

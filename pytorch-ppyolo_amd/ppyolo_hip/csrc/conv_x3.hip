@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long
 // selecting 0 instead of the activation scale in the operand split of that lane.  Two slabs alternate; the pieces of the
 // next slab ride in the DMA groups of the first two chunks of a super-chunk (the third carries out-of-range dummies so
 // that every group has the same G pieces and the counted vmcnt waits stay what they are).
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false>
+// BNS = true (training forward, ppy_conv2d_train_fwd_f32): the epilogue also emits the BatchNorm statistics of what it stores
+// (tile_bn_stats, conv_shared.h).  A separate instantiation: as a run-time branch it cost the inference kernels 12-20 VGPRs.
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -556,6 +558,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     // back to the unscaled sum (the weight scale is folded into p.scale by the caller): the inverse scale of tile row r
     // sits in lane r.  Vector epilogue: applied after the transposition to the 4 rows per tile a lane finishes;
     // scalar epilogue (K % 4 != 0, rare): applied to the accumulators, element e = row (e&3) + 8(e>>2) + 4(lane>>5).
+    if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * (BM / WM) + wm);
     float rowscale[TM][4];
     if constexpr (F16) {
         if constexpr (VEC) {
@@ -608,9 +611,12 @@ constexpr X3Cfg kX3[] = {     // the same nine tiles for both schemes (LDS sizes
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false>
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false>
 int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB>;
+    if constexpr (F16 && !SPLIT && !BNS) {
+        if (p.bn_part) return launch_x3_one<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, true>(p, splits, lds, tiles, stream);
+    }
+    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, BNS>;
     static PpyLdsAttr attr;      // (the stage count is a launch parameter: allow the whole LDS)
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
@@ -648,6 +654,11 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
     const bool vec = vec_epilogue_ok(p);
+    if (p.bn_part) {         // BatchNorm statistics from the epilogue: f16x2, one split, plain conv + bias
+        if (!F16 || splits > 1 || p.res || p.posb || p.ups || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
+        if (ceil_div(p.M, BM) * (BM / WM) > p.bn_capacity) return PPY_ERR_WORKSPACE;
+        if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * (BM / WM);
+    }
     int rc;
     if (splits > 1) {
         rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream)

@@ -119,6 +119,33 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, 
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
 }
 
+// First level of a long list of slices (the convolution epilogues write one per wave row-tile: thousands for the 152x152 maps):
+// workgroup (channel group, g) merges the slices [g * per_group, (g + 1) * per_group) into one triple, same order as the final kernel
+__global__ void __launch_bounds__(256) bn_stats_merge_kernel(const float *part, int C, int slices, int per_group, float *out) {
+    __shared__ float s_n[16][FIN_CH], s_m[16][FIN_CH], s_q[16][FIN_CH];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * FIN_CH + cl;
+    const int s0 = blockIdx.y * per_group, s1 = min(s0 + per_group, slices);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C)
+        for (int s = s0 + l; s < s1; s += 16) {
+            const float *o = part + ((long long)s * C + c) * 3;
+            chan_merge(n, mean, m2, o[0], o[1], o[2]);
+        }
+    s_n[l][cl] = n; s_m[l][cl] = mean; s_q[l][cl] = m2;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (l < w) {
+            chan_merge(n, mean, m2, s_n[l + w][cl], s_m[l + w][cl], s_q[l + w][cl]);
+            s_n[l][cl] = n; s_m[l][cl] = mean; s_q[l][cl] = m2;
+        }
+        __syncthreads();
+    }
+    if (l != 0 || c >= C) return;
+    float *o = out + ((long long)blockIdx.y * C + c) * 3;
+    o[0] = n; o[1] = mean; o[2] = m2;
+}
+
 // ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per element of work, the per-channel
 // parameters as 16-byte loads (L1 / L2 resident).  A workgroup owns a run of pixels (at most two images), so that the optional
 // per-image max|y| (the operand scale of a following f16x2 convolution, amax_track2 in common.h) costs one or two atomics per wave.
@@ -573,6 +600,32 @@ extern "C" int ppy_bn_train_stats_f32(const float *x, int x_ld, int P, int C, fl
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, eps, momentum, mean,
                        invstd, running_mean, running_var);
+    return ppy_launch_status();
+}
+
+// The second half of ppy_bn_train_stats_f32 for statistics that come out of a convolution's epilogue
+// (ppy_conv2d_train_fwd_f32): partials [slices][C][3] = (n, mean, M2) per slice and channel -> mean, 1 / sqrt(biased var + eps),
+// running statistics.  `partials` is used as scratch behind its first slices * C * 3 floats when there are many slices
+// (needs (slices + ceil(slices / 64)) * C * 3 floats in all).
+extern "C" int ppy_bn_train_stats_merge_f32(float *partials, size_t partials_bytes, int slices, int C, float eps, float momentum, float *mean,
+                                            float *invstd, float *running_mean, float *running_var, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(partials && mean && invstd && slices > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float *src = partials;
+    if (slices > 256) {
+        const int per_group = 64, groups = ceil_div(slices, per_group);
+        float *lvl = partials + (size_t)slices * C * 3;
+        if (partials_bytes < ((size_t)slices + groups) * C * 3 * sizeof(float)) return PPY_ERR_WORKSPACE;
+        hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(ceil_div(C, FIN_CH), groups), dim3(256), 0, st, (const float *)partials, C, slices,
+                           per_group, lvl);
+        src = lvl;
+        slices = groups;
+    } else if (partials_bytes < (size_t)slices * C * 3 * sizeof(float)) {
+        return PPY_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, src, C, slices, eps, momentum, mean, invstd,
+                       running_mean, running_var);
     return ppy_launch_status();
 }
 

@@ -167,6 +167,33 @@ def conv1x1_expand(x, w_f16, shift, y, act=None, residual=None, pooled=None, var
     check(rc, 'ppy_conv1x1_expand_f32')
 
 
+def conv2d_train_fwd(x, w_krsc, w_f16, bias, y, stride, pad, cfg, amax_in, partials):
+    """Training-mode convolution + the first pass of its BatchNorm from the epilogue: y = conv(x, w) + bias on the f16x2 tile `cfg`
+    (conv_x3.hip / conv_ws.hip ids), (n, mean, M2) triples into `partials` (a float32 tensor of at least
+    conv2d_bn_partials_bytes(M, K) bytes).  Returns the slice count for bn_train_stats_merge.  See ppy_conv2d_train_fwd_f32."""
+    _dev(x.t, w_krsc, w_f16[0], w_f16[1], bias, y.t, partials)
+    K, R, S, C = w_krsc.shape
+    assert C == x.C and K == y.C and w_krsc.is_contiguous()
+    n = ctypes.c_int(0)
+    check(lib().ppy_conv2d_train_fwd_f32(x.ptr, x.ld, w_krsc.data_ptr(), w_f16[0].data_ptr(), w_f16[1].data_ptr(), bias.data_ptr(), y.ptr, y.ld,
+                                         x.N, x.H, x.W, C, K, R, S, stride, pad, cfg, amax_in.data_ptr(), partials.data_ptr(),
+                                         partials.numel() * partials.element_size(), ctypes.byref(n), _stream()), 'ppy_conv2d_train_fwd_f32')
+    return n.value
+
+
+def conv2d_bn_partials_bytes(M, K):
+    return int(lib().ppy_conv2d_bn_partials_bytes(M, K))
+
+
+def bn_train_stats_merge(partials, slices, eps, momentum, mean, invstd, running_mean=None, running_var=None):
+    """(n, mean, M2) triples [slices][C][3] of conv2d_train_fwd -> mean / invstd [C], running statistics updated in place.
+    See ppy_bn_train_stats_merge_f32."""
+    _dev(partials, mean, invstd, running_mean, running_var)
+    check(lib().ppy_bn_train_stats_merge_f32(partials.data_ptr(), partials.numel() * partials.element_size(), slices, mean.numel(), eps, momentum,
+                                             mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var), _stream()),
+          'ppy_bn_train_stats_merge_f32')
+
+
 def _bwd_ws(nbytes, device):
     return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device)
 

@@ -154,6 +154,8 @@ class TrainStep(object):
         self.overlap = os.environ.get('PPYOLO_HIP_TRAIN_OVERLAP', '1') != '0' and not self.external
         self._buckets, self._pending, self._works, self._reduced = None, {}, [], []
         self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
+        self.fuse_stats = os.environ.get('PPYOLO_HIP_TRAIN_FUSE_STATS', '1') == '1'      # BatchNorm statistics from the conv epilogue
+        self._bn_part = None
         self._measured = {}
         self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
 
@@ -349,7 +351,17 @@ class TrainStep(object):
             K.conv2d_bn_act(xin.view(), krsc, one, b0, raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
                             w_x3=ent['planes'], w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
         key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
-        run(*self._choose(key, run, R * S * Cp // 32, use_f16))
+        cfg_id, splitk = self._choose(key, run, R * S * Cp // 32, use_f16)
+        # BatchNorm statistics from the convolution's epilogue (the f16x2 kernels, one split): saves the
+        # statistics kernel's pass over the raw output
+        slices = 0
+        if has_bn and use_f16 and self.fuse_stats and splitk == 1 and cfg_id >= NUM_X3_F16_FIRST:      # (every f16x2 kernel family)
+            need = K.conv2d_bn_partials_bytes(xin.N * Ho * Wo, Kout) // 4
+            if self._bn_part is None or self._bn_part.numel() < need:
+                self._bn_part = torch.empty(need, dtype=torch.float32, device=self.dev)
+            slices = K.conv2d_train_fwd(xin.view(), krsc, ent['f16'], b0, raw.view(), stride, pad, cfg_id, xin.amax, self._bn_part)
+        else:
+            run(cfg_id, splitk)
         self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
         if not has_bn:
             y = raw
@@ -357,7 +369,10 @@ class TrainStep(object):
         else:
             mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
             invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
-            K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
+            if slices:
+                K.bn_train_stats_merge(self._bn_part, slices, 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'])
+            else:
+                K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
             self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
             y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
             y.req = trainable

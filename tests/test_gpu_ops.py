@@ -468,9 +468,9 @@ def test_conv_random_shapes_all_kernels():
                               cfg=cfg, splitk=splitk, ws=ws, w_x3=ops.split_weights_bf16x3(wk),
                               w_f16=ops.split_weights_f16x2(wk, sc.cuda()), amax_in=ops.amax_slots(xd))
         special_ok = True
-        if cfg >= ops.patch_first_cfg():                                   # patch kernel: 3x3 / stride 1, C = 32, K = 32 / 64, no shortcut
+        if ops.patch_first_cfg() <= cfg < ops.ws_first_cfg():                # patch kernel: 3x3 / stride 1, C = 32, K = 32 / 64, no shortcut
             special_ok = R == 3 and stride == 1 and C == 32 and K in (32, 64) and not use_res and splitk == 1
-        elif cfg >= ops.stream_first_cfg():                                # streaming kernel: 1x1 / stride 1, C = 64 / 128, whole channel slices
+        elif ops.stream_first_cfg() <= cfg < ops.patch_first_cfg():          # streaming kernel: 1x1 / stride 1, C = 64 / 128, whole channel slices
             special_ok = R == 1 and stride == 1 and splitk == 1 and H * W >= 32 and ((C == 64 and K in (32 * 2, 128, 256)) or (C == 128 and K in (128, 256)))
         if (SLAB0 <= cfg < SLAB1 and not (R == 3 and stride == 1)) or not special_ok:        # refused loudly, no silent other kernel
             from ppyolo_hip._lib import PPYoloHipError

@@ -233,3 +233,57 @@ def test_pool_backward_and_strided_data_gradient():
         ops.conv2d_dgrad(ops.View(up, 0, K), w.permute(0, 2, 3, 1).contiguous().cuda(), ops.View(dx), 1, pad)
         err = float((dx.cpu() - nhwc(want)).abs().max() / want.abs().max())
         assert err <= 2e-6, ((N, C, K, H, W, R, s), err)
+
+
+def test_batchnorm_statistics_from_the_convolution_epilogue():
+    """ppy_conv2d_train_fwd_f32 + ppy_bn_train_stats_merge_f32 against the two-kernel form (ppy_conv2d_bn_act_f32, then
+    ppy_bn_train_stats_f32 reading y back): y is EQUAL (same tile, same epilogue), mean / invstd / running statistics agree to
+    rounding (both are two-pass per slice + Chan merges; the slices differ) and with torch's batch statistics of y -- every
+    f16x2 kernel family (tiles incl. slab / 96-row variants, streaming 1x1, stem patch, specialised waves), rows that do not fill the last tile, K = 258 (scalar epilogue, a partial column tile), a
+    bias, per-image scales far apart, and a map large enough for the two-level merge (> 256 slices)."""
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import PPYoloHipError
+    g = torch.Generator().manual_seed(5100)
+    wsf = ops.ws_first_cfg()
+    for N, H, W, C, K, R, stride, cfgs in ((2, 19, 19, 64, 128, 3, 1, (41, 44, 47, 48, 51, 66, 70, wsf, wsf + 2)), (3, 13, 11, 96, 258, 1, 1, (41, 44, wsf + 1)),
+                                           (8, 76, 76, 32, 64, 3, 1, (44, wsf + 3, ops.patch_first_cfg())), (5, 9, 7, 160, 40, 3, 2, (48, wsf)),
+                                           (1, 4, 4, 32, 32, 1, 1, (41,)), (3, 21, 37, 32, 32, 3, 1, (ops.patch_first_cfg(), 85)),
+                                           (3, 24, 20, 64, 256, 1, 1, (ops.stream_first_cfg(), ops.stream_first_cfg() + 1, 88)),
+                                           (2, 9, 7, 128, 128, 1, 1, (ops.stream_first_cfg(),))):
+        pad = (R - 1) // 2
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(N, 1, 1, 1, generator=g)) + 0.3
+        w = torch.randn(K, C, R, R, generator=g) * (1.0 / (R * R * C) ** 0.5)
+        bias = torch.randn(K, generator=g).cuda()
+        one = torch.ones(K).cuda()
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, one)
+        Ho, Wo = ops.conv_out_hw(H, W, R, R, stride, pad)
+        M = N * Ho * Wo
+        for cfg in cfgs:
+            y0 = torch.full((N, Ho, Wo, K), 9.0).cuda()
+            ops.conv2d_bn_act(ops.View(xd), wk, one, bias, ops.View(y0), stride, pad, None, cfg=cfg, splitk=1, w_f16=wf, amax_in=ops.amax_slots(xd))
+            m0, i0 = torch.empty(K).cuda(), torch.empty(K).cuda()
+            rm0, rv0 = torch.full((K,), 0.25).cuda(), torch.full((K,), 2.0).cuda()
+            ops.bn_train_stats(ops.View(y0), 1e-5, 0.1, m0, i0, rm0, rv0)
+            y1 = torch.full((N, Ho, Wo, K), 9.0).cuda()
+            part = torch.full((ops.conv2d_bn_partials_bytes(M, K) // 4,), float('nan')).cuda()
+            slices = ops.conv2d_train_fwd(ops.View(xd), wk, wf, bias, ops.View(y1), stride, pad, cfg, ops.amax_slots(xd), part)
+            m1, i1 = torch.empty(K).cuda(), torch.empty(K).cuda()
+            rm1, rv1 = torch.full((K,), 0.25).cuda(), torch.full((K,), 2.0).cuda()
+            ops.bn_train_stats_merge(part, slices, 1e-5, 0.1, m1, i1, rm1, rv1)
+            torch.cuda.synchronize()
+            what = 'N%d %dx%d C%d K%d R%d s%d cfg %d (%d slices)' % (N, H, W, C, K, R, stride, cfg, slices)
+            assert slices > 0 and torch.equal(y0, y1), what
+            yy = y1.reshape(-1, K).double()
+            assert rel(m1.double(), yy.mean(0)) < 2e-6, what
+            assert rel(i1.double(), 1.0 / torch.sqrt(yy.var(0, unbiased=False) + 1e-5)) < 2e-6, what
+            assert rel(m1, m0) < 2e-6 and rel(i1, i0) < 2e-6 and rel(rm1, rm0) < 2e-6 and rel(rv1, rv0) < 2e-6, what
+    # another kernel family refuses (the caller then uses the two-kernel form)
+    x = torch.randn(1, 8, 8, 64).cuda()
+    wk = torch.randn(64, 1, 1, 64).cuda()
+    one = torch.ones(64).cuda()
+    for cfg in (19, 33):          # exact-fp32 MFMA, bf16x3
+        with pytest.raises(PPYoloHipError):
+            ops.conv2d_train_fwd(ops.View(x), wk, ops.split_weights_f16x2(wk, one), one, ops.View(torch.empty(1, 8, 8, 64).cuda()), 1, 0,
+                                 cfg, ops.amax_slots(x), torch.empty(ops.conv2d_bn_partials_bytes(64, 64) // 4).cuda())
