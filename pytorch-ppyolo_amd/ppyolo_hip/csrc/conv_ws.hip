@@ -16,14 +16,21 @@
 
 namespace {
 
-template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false>      // (BNS: conv_x3.hip)
+// PRE = true: the producer waves also SPLIT the activations.  A producer wave that has seen its own pieces of a chunk land
+// (its counted vmcnt: no other wave involved) reads exactly those rows back from the landing area, scales and splits them into
+// the two fp16 terms ONCE and writes them to two plane tiles of the stage; the consumers read finished A fragments (two
+// 16-byte LDS reads per 32 rows and k-step, as before) and execute no VALU instruction per operand at all.  In the plain form
+// every consumer wave splits the rows of its sub-tile itself -- twice per workgroup (the two waves of a row of the 2 x 2
+// layout), in the issue slots of the waves that feed the MFMA pipe.  Same values, same products: bit-identical results.
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
     static_assert(BM % (8 * NWP) == 0 && B_ROWS % (16 * NWP) == 0, "whole DMA instructions per producer wave");
     constexpr int A_PASS = BM / (8 * NWP), B_PASS = B_ROWS / (16 * NWP), G = A_PASS + B_PASS;
-    constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * 128, AP_BYTES = PRE ? 2 * BM * 64 : 0, B_BYTES = B_ROWS * 64;      // fp32 landing area, A planes, B planes
+    constexpr int STAGE = A_BYTES + AP_BYTES + B_BYTES;
     static_assert((NS - 1) * G <= 63, "6-bit vmcnt");
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) char smem_ws[];
@@ -110,12 +117,46 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < B_PASS; ++j) {
                 const unsigned off = have ? b_off[j] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + lds + A_BYTES + j * NWP * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + lds + A_BYTES + AP_BYTES + j * NWP * 1024), 16, off, 0, 0, 0);
             }
             ++l_tap;
             ++l_s;
             if (l_s == p.S) { l_s = 0; ++l_r; }
             if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
+        };
+        // PRE: the scale of the image of each of this lane's piece rows, and the split of this wave's pieces of a stage
+        float sa_p[A_PASS];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < A_PASS; ++j) {
+                const int mrow = min(m0 + (j * NWP + pw) * 8 + (lane >> 3), p.M - 1);
+                const float mx = amax_read(p.amax_in, mrow / hw);
+                const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+                int f = 267 - e;
+                f = f < 103 ? 103 : (f > 167 ? 167 : f);
+                sa_p[j] = __uint_as_float((unsigned)f << 23);
+            }
+        }
+        auto split_stage = [&](int stage) {
+            if constexpr (PRE) {
+                typedef __attribute__((ext_vector_type(2))) unsigned uintx2;
+                char *sb = smem + stage * STAGE;
+#pragma unroll
+                for (int d = 0; d < A_PASS; ++d) {
+                    const int row = (d * NWP + pw) * 8 + (lane >> 3);
+                    const int g4 = (lane & 7) ^ ((row >> 1) & 7);          // the 4-channel group this lane's 16 bytes hold (source-side swizzle)
+                    const floatx4 v = *reinterpret_cast<const floatx4 *>(sb + pw * 1024 + d * NWP * 1024 + lane * 16);
+                    const float sc_r = sa_p[d];
+                    const unsigned h0 = cvt_pk_f16(v[0] * sc_r, v[1] * sc_r), h1 = cvt_pk_f16(v[2] * sc_r, v[3] * sc_r);
+                    const unsigned l0 = cvt_pk_f16(fmaf(v[0], sc_r, -f16_lo(h0)), fmaf(v[1], sc_r, -f16_hi(h0)));
+                    const unsigned l1 = cvt_pk_f16(fmaf(v[2], sc_r, -f16_lo(h1)), fmaf(v[3], sc_r, -f16_hi(h1)));
+                    // plane row = 32 fp16 = 64 B, 16-byte slot c (channels 8c .. 8c+7) stored at c ^ ((row>>2)&3)
+                    const int o = row * 64 + (((g4 >> 1) ^ ((row >> 2) & 3)) << 4) + (g4 & 1) * 8;
+                    *reinterpret_cast<uintx2 *>(sb + A_BYTES + o) = uintx2{h0, h1};
+                    *reinterpret_cast<uintx2 *>(sb + A_BYTES + BM * 64 + o) = uintx2{l0, l1};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         };
         if (nchunks > 0) {
             // NS stage slots are requested up front, slots past the end of the reduction as out-of-range dummies, so that the
@@ -123,10 +164,12 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #pragma unroll
             for (int sidx = 0; sidx < NS; ++sidx) issue(sidx, sidx < nchunks);
             wait_vmcnt<(NS - 1) * G>();                  // chunk 0 has landed
+            split_stage(0);
             __builtin_amdgcn_s_barrier();
             int st = 0;
             for (int k = 0; k < nchunks; ++k) {
                 wait_vmcnt<(NS - 2) * G>();              // chunk k+1 has landed (this wave's pieces; the barrier makes it all of them)
+                split_stage(st + 1 == NS ? 0 : st + 1);
                 __builtin_amdgcn_s_barrier();            // ... and the consumers have read all of chunk k
                 issue(st, k + NS < nchunks);
                 st = st + 1 == NS ? 0 : st + 1;
@@ -157,6 +200,9 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
         a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
+    int ap_foff[2];                       // PRE: A planes, row (lane&31), slot 2s+h at (2s+h) ^ ((row>>2)&3)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ap_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     float sa[TM], inv_sa[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {        // per-image activation scale (conv_x3.hip)
@@ -175,7 +221,7 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
     };
     constexpr int NM = 3 * TM * TN;            // MFMAs per k-step
     constexpr int NRA = 2 * TM, NRB = NP * TN, NR = NRA + NRB;
-    constexpr int NSL = 3 * 4 * TM;            // split stages per k-step (3 dependent stages x 4 pairs x TM)
+    constexpr int NSL = PRE ? 0 : 3 * 4 * TM;  // split stages per k-step (3 dependent stages x 4 pairs x TM)
     constexpr int RPS = (NR + NM - 1) / NM;
     constexpr int LEAD0 = (NRA + RPS - 1) / RPS + 1;
     constexpr int LEAD = LEAD0 < NM ? LEAD0 : NM - 1;
@@ -185,8 +231,8 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
     auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag) {
         constexpr int s = decltype(s_tag)::value;      // k-step (0/1) of the chunk the NEXT operands come from
         constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0};      // a1*b0, a0*b1, a0*b0: smallest first
-        const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
-        const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
+        const char *a_ptr = PRE ? smem + stage * STAGE + A_BYTES + wm * WM * 64 : smem + stage * STAGE + wm * WM * 128;
+        const char *b_ptr = smem + stage * STAGE + A_BYTES + AP_BYTES + wn * WN * 64;
         floatx4 raw[TM][2];
         float ra[TM][4], rb[TM][4];
 #pragma unroll
@@ -201,7 +247,10 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
                 const int r = m * RPS + u;
                 if (r >= NR) {
                 } else if (r < NRA) {
-                    raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                    if constexpr (PRE)      // (tile r>>1, plane r&1)
+                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r & 1) * BM * 64 + (r >> 1) * 32 * 64 + ap_foff[s]);
+                    else
+                        raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
                 } else {
                     const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
                     nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
@@ -241,9 +290,15 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_barrier();            // chunk 0 is in the LDS
         {   // operands of (chunk 0, k-step 0): not overlapped with anything
             const char *a_ptr = smem + wm * WM * 128;
-            const char *b_ptr = smem + A_BYTES + wn * WN * 64;
+            const char *b_ptr = smem + A_BYTES + AP_BYTES + wn * WN * 64;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        f0.a[i][pl] = *reinterpret_cast<const uintx4 *>(smem + A_BYTES + pl * BM * 64 + (wm * WM + i * 32) * 64 + ap_foff[0]);
+                    continue;
+                }
                 const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
                 const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
 #pragma unroll
@@ -293,24 +348,24 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
 #endif
 }
 
-template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false>
+template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false>
 int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
     if constexpr (!SPLIT && !BNS) {
-        if (p.bn_part) return launch_ws_one<BM, BN, NS, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
+        if (p.bn_part) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
     }
-    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS>;
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), lds, stream, p);
     return PPY_OK;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool PRE = false>
 int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
     const long long wbytes = (long long)p.K * p.Kred * 2 * 2;
     if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
-    constexpr int STAGE_BYTES = BM * 128 + 2 * BN * 64;
+    constexpr int STAGE_BYTES = BM * 128 * (PRE ? 2 : 1) + 2 * BN * 64;
     static_assert(NS * STAGE_BYTES <= 160 * 1024, "LDS");
     size_t lds = (size_t)NS * STAGE_BYTES;
     const size_t epi = (size_t)4 * 32 * LDS_LD * sizeof(float);
@@ -328,13 +383,13 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     }
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_ws_one<BM, BN, NS, true, true>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, true, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, true, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_ws_one<BM, BN, NS, false, true>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, false, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, false, true>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, false, false>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
@@ -342,9 +397,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 
 }  // namespace
 
-// local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6
+// local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6; with the activations
+// split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 4; }
+int ppy_ws_num_configs() { return 7; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -356,6 +412,9 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 1: return launch_ws<128, 128, 4>(q, s, st);
         case 2: return launch_ws<64, 128, 4>(q, s, st);
         case 3: return launch_ws<64, 128, 6>(q, s, st);
+        case 4: return launch_ws<128, 128, 3, true>(q, s, st);
+        case 5: return launch_ws<64, 128, 4, true>(q, s, st);
+        case 6: return launch_ws<128, 64, 4, true>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }
