@@ -200,11 +200,20 @@ class TrainStep(object):
             krsc[..., :Cin] = w.permute(0, 2, 3, 1)
             ent = dict(krsc=krsc, planes=None, f16=None, Cin=Cin, trainable=key in self.train_keys)
             self._wcache[key] = ent
-        if ent['planes'] is None or ent['trainable']:
-            ent['planes'] = K.split_weights_bf16x3(ent['krsc'])
+        if ent['trainable'] or (ent['planes'] is None and ent['f16'] is None):
+            ent['planes'] = None       # bf16x3 planes: split on demand (_planes) -- a layer on the f16x2 kernels never needs them
             if self.f16:      # (planes, per-channel epilogue scale with the weight scale folded in) for a unit scale
                 ent['f16'] = K.split_weights_f16x2(ent['krsc'], self._vec('one', ent['krsc'].shape[0], 1.0))
+            else:
+                self._planes(ent)
         return ent
+
+    @staticmethod
+    def _planes(ent):
+        """The three bf16 planes of a weight entry (bf16x3 kernels), split when first asked for after an update."""
+        if ent['planes'] is None:
+            ent['planes'] = K.split_weights_bf16x3(ent['krsc'])
+        return ent['planes']
 
     def _alloc_flat(self):
         """Parameters, gradients, velocities and EMA shadows of ALL trainable tensors in flat buffers, in kernel layout:
@@ -349,7 +358,7 @@ class TrainStep(object):
 
         def run(cfg_id, splitk):
             K.conv2d_bn_act(xin.view(), krsc, one, b0, raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
-                            w_x3=ent['planes'], w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
+                            w_x3=None if use_f16 else self._planes(ent), w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
         key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
         cfg_id, splitk = self._choose(key, run, R * S * Cp // 32, use_f16)
         # BatchNorm statistics from the convolution's epilogue (the f16x2 kernels, one split): saves the
@@ -453,7 +462,7 @@ class TrainStep(object):
         Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
         om = self.new(x.N, Ho, Wo, 27, ld=32, zero=True)
         K.conv2d_bn_act(x.view(), co['krsc'], self._vec('one', 27, 1.0), self.param(prefix + '.conv.conv_offset.bias'), om.view(), stride, 1,
-                        None, ws=self.ws, w_x3=co['planes'])
+                        None, ws=self.ws, w_x3=self._planes(co))
         w = self.weight(prefix + '.conv.dcn_weight')
         Kout = w['krsc'].shape[0]
         raw = self.new(x.N, Ho, Wo, Kout)
@@ -461,7 +470,7 @@ class TrainStep(object):
         ent = (self._tuned_f if use_f16 else self._tuned).get('dcnf:N%d:H%d:W%d:C%d:K%d:R3:s%d%s' % (x.N, x.H, x.W, x.C, Kout, stride,
                                                                                                 ':f' if use_f16 else ''))
         K.dcnv2(x.view(), w['krsc'], self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), om.view(), raw.view(), stride, 1, None,
-                self.ws, cfg=ent[0] if ent else -1, splitk=ent[1] if ent else 0, w_x3=w['planes'], w_f16=w['f16'] if use_f16 else None,
+                self.ws, cfg=ent[0] if ent else -1, splitk=ent[1] if ent else 0, w_x3=None if use_f16 else self._planes(w), w_f16=w['f16'] if use_f16 else None,
                 amax_in=x.amax if use_f16 else None)
         self.flops += 2 * x.N * Ho * Wo * (Kout * 9 * x.C + 27 * 9 * x.C)
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
