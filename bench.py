@@ -185,6 +185,39 @@ def decode_nms_leg(ex, reps=5):
                                 kernels='nms_select / nms_colmax / nms_decay / nms_finish'))
 
 
+def hbm_conv_leg(ex, reps=5):
+    """Secondary roofline of the HBM-bound convolution launches: the streaming 1x1 kernel's slowest launch of the
+    plan against HBM bandwidth -- algorithmic bytes = activations + shortcut read once, output (+ its 2x2 average) written once."""
+    from ppyolo_hip import ops as K
+    first = K.stream_first_cfg()
+    cands = [op for op in ex.plan.ops if op['op'] == 'conv' and first <= op['cfg'] < first + 2]
+    best = None
+    for op in cands:
+        x, y = op['x'], op['y']
+        M = y.N * y.H * y.W
+        byt = 4 * (M * x.C + M * y.C * (2 if op['res'] is not None else 1) + (M // 4 * y.C if op.get('pool') is not None else 0))
+        t = None
+        for _ in range(reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ex._run_op(op)
+            e.record()
+            e.synchronize()
+            ms = s.elapsed_time(e)
+            t = ms if t is None else min(t, ms)
+        if best is None or byt > best[0]:
+            best = (byt, t, x, y, op)
+    if best is None:
+        return None
+    byt, t, x, y, op = best
+    gbs = byt / (t * 1e-3) / 1e9
+    return dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s', frac=round(gbs / 8000.0, 4), bytes_per_launch=byt,
+                us_per_launch=round(t * 1e3, 1),
+                kernel='conv1x1_stream_kernel: C%d -> K%d at %dx%d%s%s (largest launch of %d on this kernel)' % (
+                    x.C, y.C, y.H, y.W, ' + shortcut' if op['res'] is not None else '', ' + pooled output' if op.get('pool') is not None else '',
+                    len(cands)))
+
+
 def alt_math_leg(wl, dev, x, ims, steps, current, depth=1):
     """Not `value`: the same step with the other convolution math modes, measured in the same process right after the
     headline run (hipGraph replay, inputs resident): 'fp32' = every convolution on the exact-fp32 MFMA."""
@@ -718,6 +751,9 @@ def main():
             out['one_batch_at_a_time'] = dict(value=one_at_a_time, unit='images/s',
                                               note='the graph of lane 0 replayed alone (= --in-flight 1)')
         out['roofline_other'] = decode_nms_leg(ex)
+        hbm_conv = hbm_conv_leg(ex)
+        if hbm_conv is not None:
+            out['roofline_other']['expand_1x1'] = hbm_conv
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:
