@@ -23,9 +23,10 @@ namespace {
 // every consumer wave splits the rows of its sub-tile itself -- twice per workgroup (the two waves of a row of the 2 x 2
 // layout), in the issue slots of the waves that feed the MFMA pipe.  Same values, same products: bit-identical results.
 template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false>      // (BNS: conv_x3.hip)
-__global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2;              // consumer waves: CM x 2 over the tile (256-row tiles: eight)
+    constexpr int WM = BM / CM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
     static_assert(BM % (8 * NWP) == 0 && B_ROWS % (16 * NWP) == 0, "whole DMA instructions per producer wave");
     constexpr int A_PASS = BM / (8 * NWP), B_PASS = B_ROWS / (16 * NWP), G = A_PASS + B_PASS;
@@ -53,9 +54,9 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
     const int nchunks = kc_end - kc_begin;
     const int hw = p.Ho * p.Wo;
 
-    if (wave >= 4) {
+    if (wave >= NC) {
         // ================= producers: every LDS-DMA piece of the tile, a quarter per wave =================
-        const int pw = wave - 4;
+        const int pw = wave - NC;
         const unsigned OOB = 0xFFFFFFF0u;
         const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
         unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(512) conv_igemm_ws_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * 2 + wm);
+    if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * CM + wm);
     float rowscale[TM][4];
     if constexpr (VEC) {
 #pragma unroll
@@ -356,7 +357,7 @@ int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStrea
     auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
-    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(BM == 256 ? 768 : 512), lds, stream, p);
     return PPY_OK;
 }
 
@@ -368,7 +369,7 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     constexpr int STAGE_BYTES = BM * 128 * (PRE ? 2 : 1) + 2 * BN * 64;
     static_assert(NS * STAGE_BYTES <= 160 * 1024, "LDS");
     size_t lds = (size_t)NS * STAGE_BYTES;
-    const size_t epi = (size_t)4 * 32 * LDS_LD * sizeof(float);
+    const size_t epi = (size_t)(BM == 256 ? 8 : 4) * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
     p.nstages = NS;
     p.chunks_total = p.R * p.S * (p.C / 32);
@@ -378,8 +379,8 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     const bool vec = vec_epilogue_ok(p);
     if (p.bn_part) {         // BatchNorm statistics from the epilogue: one split, plain conv + bias
         if (splits > 1 || p.res || p.posb || p.ups || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
-        if (ceil_div(p.M, BM) * 2 > p.bn_capacity) return PPY_ERR_WORKSPACE;
-        if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * 2;
+        if (ceil_div(p.M, BM) * (BM == 256 ? 4 : 2) > p.bn_capacity) return PPY_ERR_WORKSPACE;
+        if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * (BM == 256 ? 4 : 2);
     }
     int rc;
     if (splits > 1) {
@@ -398,9 +399,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 }  // namespace
 
 // local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6; with the activations
-// split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4
+// split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4; eight consumer waves (4 x 2)
+// + four producers on a 256x128 tile: 7 = two stages, 8 = three
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 7; }
+int ppy_ws_num_configs() { return 9; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -415,6 +417,8 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 4: return launch_ws<128, 128, 3, true>(q, s, st);
         case 5: return launch_ws<64, 128, 4, true>(q, s, st);
         case 6: return launch_ws<128, 64, 4, true>(q, s, st);
+        case 7: return launch_ws<256, 128, 2>(q, s, st);
+        case 8: return launch_ws<256, 128, 3>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }
