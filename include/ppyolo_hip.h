@@ -104,6 +104,14 @@ int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const v
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int cfg, int splitk);
 int ppy_conv2d_num_configs(void);
+/* Map of the cfg ids (all families compute the same operator; the f16x2 families are bit-identical to each other):
+ *   0-30   exact-fp32 MFMA tiles (csrc/conv_igemm.hip)            31-39  bf16x3 tiles (csrc/conv_x3.hip; need w_x3)
+ *   40-66  f16x2 tiles, 9 shapes x {2, 3, 4} LDS stages           67-84  the same with slab reuse (3x3 / stride 1 / pad 1 only)
+ *   85-93  f16x2 tiles of 96 / 192 rows x {2, 3, 4} stages        then, from the functions below:
+ *   stream_first + {0, 1}   streaming 1x1 kernel (C = 64 / 128)   patch_first   patch kernel of the 3x3 stem layers (C = 32)
+ *   ws_first + {0..8}       f16x2 tiles with specialised waves: 128x128 (3 / 4 stages), 64x128 (4 / 6), the three PRE variants,
+ *                           256x128 with eight consumer waves (2 / 3 stages)
+ * An explicit id on a geometry its kernel does not cover returns PPY_ERR_BAD_ARG (never a silent other kernel). */
 /* First cfg id of the streaming 1x1 kernel (csrc/conv_stream.hip; two ids) and of the patch kernel for the 3x3 stem layers
  * with C = 32, K = 32 / 64, stride 1 (csrc/conv_patch.hip; one id) -- both f16x2 only; an explicit id on a geometry the kernel
  * does not cover is PPY_ERR_BAD_ARG. */
