@@ -242,6 +242,37 @@ class Builder(object):
         return y
 
 
+def link_pools(ops, op_io, has_f16, two_streams=False):
+    """Host logic of HipExecutor._link_pools, device-free (tests/test_plan_host_logic.py): gives every 'avgpool' op whose input
+    slice is written by exactly one 1x1 / stride-1 convolution that ppy_conv1x1_expand_f32 accepts (C = 64 with K % 64 == 0, or
+    C = 128 with K % 128 == 0; K / 64 resp. K / 128 a power of two <= 16; no upsampling, no position bias; has_f16(op): f16x2
+    operands at hand) to that convolution: conv['pool'] = the pooled slice, avgpool['owner'] = the convolution.  op_io(op) ->
+    (input buffer ids, output buffer ids).  Returns the number of links."""
+    n = 0
+    for i, op in enumerate(ops):
+        if op['op'] != 'avgpool':
+            continue
+        x = op['x']
+        # (a route buffer has several writers, each of its own channel slice: the producer is the one that writes x's)
+        prods = [o for o in ops[:i] if x.buf in op_io(o)[1] and (o['op'] != 'conv' or (o['y'].coff < x.coff + x.C
+                                                                                      and x.coff < o['y'].coff + o['y'].C))]
+        if len(prods) != 1 or prods[0]['op'] != 'conv':
+            continue
+        c = prods[0]
+        Kout, R, S, C = c['w'].shape
+        y = c['y']
+        groups = Kout // 64 if C == 64 else Kout // 128           # (what ppy_conv1x1_expand_f32 accepts)
+        if (R, S, c['stride']) != (1, 1, 1) or C not in (64, 128) or Kout % (64 if C == 64 else 128) or groups & (groups - 1) \
+                or groups > 16 or c['ups'] or c['posb'] is not None or not has_f16(c) \
+                or (two_streams and c.get('stream', 0) != op.get('stream', 0)) \
+                or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.H % 2 or x.W % 2 or x.H * x.W < 32:
+            continue
+        c['pool'] = op['y']
+        op['owner'] = c
+        n += 1
+    return n
+
+
 # =========================================================================================
 class HipExecutor(object):
     """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
@@ -367,28 +398,8 @@ class HipExecutor(object):
         follows it immediately; the 'avgpool' op of the plan is skipped either way."""
         if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_POOL_FOLD', '1') != '1':
             return
-        ops = self.plan.ops
-        for i, op in enumerate(ops):
-            if op['op'] != 'avgpool':
-                continue
-            x = op['x']
-            # (a route buffer has several writers, each of its own channel slice: the producer is the one that writes x's)
-            prods = [o for o in ops[:i] if x.buf in self._op_io(o)[1] and (o['op'] != 'conv' or (o['y'].coff < x.coff + x.C
-                                                                                                 and x.coff < o['y'].coff + o['y'].C))]
-            if len(prods) != 1 or prods[0]['op'] != 'conv':
-                continue
-            c = prods[0]
-            Kout, R, S, C = c['w'].shape
-            y = c['y']
-            groups = Kout // 64 if C == 64 else Kout // 128           # (what ppy_conv1x1_expand_f32 accepts)
-            if (R, S, c['stride']) != (1, 1, 1) or C not in (64, 128) or Kout % (64 if C == 64 else 128) or groups & (groups - 1) \
-                    or groups > 16 or c['ups'] or c['posb'] is not None \
-                    or c.get('wf16') is None or c.get('amax_in_id') is None \
-                    or (self._want_streams and c.get('stream', 0) != op.get('stream', 0)) \
-                    or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.H % 2 or x.W % 2 or x.H * x.W < 32:
-                continue
-            c['pool'] = op['y']
-            op['owner'] = c
+        link_pools(self.plan.ops, self._op_io, lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None,
+                   self._want_streams)
 
     def _amax(self, idx):
         return None if idx is None else self.amax[idx * self._amax_block:(idx + 1) * self._amax_block]

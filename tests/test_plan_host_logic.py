@@ -73,3 +73,28 @@ def test_cpu_input_raises():
     model, _ = build_model(PPYOLO_r18vd_Config())
     with pytest.raises(PPYoloHipError):
         model(torch.zeros(1, 3, 64, 64), torch.tensor([[64., 64.]]))
+
+
+def test_pool_links_of_the_r50_plan():
+    """engine.link_pools (device-free part of HipExecutor._link_pools): the average pools in front of the stage-3 and stage-4
+    projection shortcuts go to the 1x1 convolutions that produce their inputs (C64 -> K256 and C128 -> K512, the latter into a
+    slice of the stage-3 / route buffer that has a second writer), the one in front of stage 5 (input from a C = 256 layer) stays
+    a launch of its own; nothing is linked without f16x2 operands; the linked plan still interprets to the same features."""
+    from ppyolo_hip.engine import HipExecutor, link_pools
+    cfg = PPYOLO_2x_Config()
+    model, _ = build_model(cfg)
+    plan = build_plan(model, 2, 160, 160, 'cpu')
+    x = synth.synth_images(2, 160, seed=3)
+    base_feats, base_outs, _ = CpuPlanRunner(plan).run(x)
+    assert link_pools(plan.ops, HipExecutor._op_io, lambda c: False) == 0
+    assert link_pools(plan.ops, HipExecutor._op_io, lambda c: True) == 2
+    pools = [o for o in plan.ops if o['op'] == 'avgpool']
+    assert [o.get('owner') is not None for o in pools] == [True, True, False]
+    for o, (C, Kout) in zip(pools[:2], ((64, 256), (128, 512))):
+        c = o['owner']
+        assert tuple(c['w'].shape) == (Kout, 1, 1, C) and c['pool'] is o['y']
+        assert (c['y'].buf, c['y'].coff, c['y'].C) == (o['x'].buf, o['x'].coff, o['x'].C) and c['res'] is not None
+    assert HipExecutor._op_io(pools[0]) == ([], []) and pools[0]['y'].buf in HipExecutor._op_io(pools[0]['owner'])[1]
+    feats, outs, _ = CpuPlanRunner(plan).run(x)             # (the interpreter pools where the plan says; same tensors)
+    for a, b in zip(feats + outs, base_feats + base_outs):
+        assert torch.equal(a, b)
