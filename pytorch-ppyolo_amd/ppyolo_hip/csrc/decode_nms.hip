@@ -114,6 +114,32 @@ __device__ __forceinline__ void yolo_decode_body(const DecodeArgs &p, const int 
         }
         for (int i = (n4 << 2) - pre + tid; i < ncl * nch; i += 256)
             if (i >= 0) vals[i] = src[i];
+    } else if ((p.head_ld & 3) == 0 && (((uintptr_t)p.head) & 15) == 0) {
+        // rows with a padded pixel stride (the plan rounds K up to 4: 258 channels in rows of 260): 16-byte loads per row,
+        // ceil(nch / 4) groups each, all of a batch issued before the first LDS write
+        const int gpr = (nch + 3) >> 2, n4 = ncl * gpr;
+        constexpr int U = 8;
+        for (int i0 = 0; i0 < n4; i0 += 256 * U) {
+            floatx4 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < n4) {
+                    const int c = i / gpr, g = i - c * gpr;
+                    r[u] = *reinterpret_cast<const floatx4 *>(p.head + (cell0 + c) * p.head_ld + 4 * g);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < n4) {
+                    const int c = i / gpr, g = i - c * gpr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * g + e < nch) vals[c * nch + 4 * g + e] = r[u][e];
+                }
+            }
+        }
     } else {
         for (int c = 0; c < ncl; ++c)
             for (int i = tid; i < nch; i += 256) vals[c * nch + i] = p.head[(cell0 + c) * p.head_ld + i];

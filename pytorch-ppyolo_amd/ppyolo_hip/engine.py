@@ -175,12 +175,28 @@ class Builder(object):
             assert Cin == x.C, (Cin, x.C)
         w_krsc = _meta(Kout, R, S, x.C) if self.skeleton else w.permute(0, 2, 3, 1).contiguous()
         Ho, Wo = K.conv_out_hw(x.H, x.W, R, S, stride, pad)
+        y = None
+        if out is None and Kout % 4 and Kout >= 64 and res is None and posb is None and not ups \
+                and os.environ.get('PPYOLO_HIP_PAD_K', '1') == '1':
+            # K that is no multiple of 4 (the 258-channel head outputs) would run the 4-byte scalar epilogue: the launch computes
+            # K rounded up to 4 with all-zero extra filters (scale 1, shift 0) into a buffer whose pixel stride has the room;
+            # consumers see the first K channels (the decode kernel reads such rows with 16-byte loads).  Not for the narrow
+            # 27-channel offset / mask convolutions of DCNv2: measured neutral.
+            Kp = (Kout + 3) // 4 * 4
+            buf = self.new_buf(x.N, Ho, Wo, Kp)
+            out, y = A(buf, 0, Kout, x.N, Ho, Wo), A(buf, 0, Kp, x.N, Ho, Wo)
+            if self.skeleton:
+                w_krsc = _meta(Kp, R, S, x.C)
+            else:
+                w_krsc = torch.cat([w_krsc, torch.zeros((Kp - Kout, R, S, x.C), dtype=w_krsc.dtype, device=w_krsc.device)])
+                scale = torch.cat([scale, torch.ones(Kp - Kout, dtype=scale.dtype, device=scale.device)])
+                shift = torch.cat([shift, torch.zeros(Kp - Kout, dtype=shift.dtype, device=shift.device)])
         if out is None:
             out = self.new_act(x.N, Ho * (2 if ups else 1), Wo * (2 if ups else 1), Kout)
         assert out.C == Kout and out.H == Ho * (2 if ups else 1) and out.W == Wo * (2 if ups else 1)
         if res is not None:
             assert (res.C, res.H, res.W) == (Kout, Ho, Wo)
-        self._emit(dict(op='conv', x=x, y=out, w=w_krsc, scale=scale, shift=shift, stride=stride, pad=pad, act=act,
+        self._emit(dict(op='conv', x=x, y=out if y is None else y, w=w_krsc, scale=scale, shift=shift, stride=stride, pad=pad, act=act,
                         res=res, posb=posb, ups=ups, cfg=-1, splitk=0), setup)
         return out
 
