@@ -447,7 +447,7 @@ def train_bench(a, wl, dev, rank, world):
     bb, cc, ss = synth_ground_truth(a.batch, 50 + rank + a.seed_offset)
     targets = [torch.from_numpy(t).to(dev) for t in gt2yolo_target(bb, cc, ss, hc['anchors'], hc['anchor_masks'], hc['downsample'], 80, S)]
     gt = torch.from_numpy(bb).to(dev)
-    ts = TrainStep(model, cfg, world)
+    ts = TrainStep(model, cfg, world, seed_rank=rank + a.seed_offset)      # (DropBlock draws: rank r == a single run with --seed-offset r)
     lr = lr_at(4000, cfg)
     losses = []
     if a.autotune:          # measure the convolution geometries the tables do not know (-> ppyolo_hip/tuned_gfx950_train.json)

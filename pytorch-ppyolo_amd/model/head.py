@@ -59,8 +59,9 @@ class DetectionBlock(torch.nn.Module):
                 coord = ly.coord_conv
             elif isinstance(ly, DropBlock):
                 if not ly.is_test:
-                    raise NotImplementedError('DropBlock training mode is outside the inference path; call '
-                                              'head.set_dropblock(is_test=True)')
+                    raise NotImplementedError('this is the inference plan: call head.set_dropblock(is_test=True) (reference '
+                                              'demo.py:93); DropBlock in training mode runs in the training step -- '
+                                              'model(x, None, False, ...) / ppyolo_hip.train.TrainStep')
             elif isinstance(ly, SPP):
                 x = b.spp(x)            # x is slot 0 of the 4C buffer (arranged below)
             else:

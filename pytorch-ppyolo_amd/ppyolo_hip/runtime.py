@@ -30,13 +30,44 @@ class PlanCache(object):
         self._ex = {}
         self.blob = None               # weight owner loaded from a native blob (ppyolo_hip/blob.py), if any
         self.generation = 0
+        self._sig = None               # parameter signature the executors' folded weights were derived from
+        self._tensors = None
+        # the check costs ~0.14 ms of host time per forward (468 tensors): a server whose weights are final may switch it off
+        self.pinned = os.environ.get('PPYOLO_HIP_PIN_WEIGHTS', '0') == '1'
         self.use_graph = os.environ.get('PPYOLO_HIP_GRAPH', '1') != '0'
         self.autotune = os.environ.get('PPYOLO_HIP_AUTOTUNE', '0') == '1'
 
     def clear(self):
         self._ex = {}
         self.blob = None
+        self._sig = None
+        self._tensors = None
         self.generation += 1          # InFlight lanes built from older executors (older weights) are stale
+
+    def _signature(self):
+        """Changes whenever a parameter or buffer is written in place (optimizer.step(), EMA.apply() / restore() through
+        `p.copy_`, BatchNorm statistics of a training forward) or rebound (`p.data = ...`, as the reference's EMA does,
+        model/EMA.py:46-58): the tensors' autograd version counters and storage addresses."""
+        ts = self._tensors
+        if ts is None:          # (walking the module tree costs ~1 ms: once per clear(); rebinding `.data` keeps the Parameter objects)
+            m = self._model
+            ts = self._tensors = [t for t in list(m.parameters()) + list(m.buffers()) if t.device.type != 'meta']
+        a = 0
+        for t in ts:
+            a ^= t.data_ptr()
+        return (sum([t._version for t in ts]), a)
+
+    def check_current(self):
+        """The executors hold COPIES of the folded / re-laid / split weights: drop them when the parameters they were derived
+        from have been modified since (the reference's loop trains, then evaluates with `ema.apply(); eval; ema.restore()`
+        every eval_iter iterations, train.py:481-499 -- each evaluation must see the weights of ITS iteration).  A loaded
+        native blob is such a copy too."""
+        if self.pinned:
+            return
+        sig = self._signature()
+        if self._sig is not None and sig != self._sig and (self._ex or self.blob is not None):
+            self.clear()
+        self._sig = sig
 
     def executor(self, x, lane=0, multi_stream=None):
         """Lane 0 belongs to `PPYOLO.forward` / `forward_padded`; lanes > 0 are further executors of the same shape (own
@@ -52,6 +83,7 @@ class PlanCache(object):
         N, C, H, W = x.shape
         if C != 3:
             raise PPYoloHipError('expected NCHW input with 3 channels')
+        self.check_current()
         key = (N, H, W, str(x.device), lane)
         ex = self._ex.get(key)
         if ex is None:
@@ -136,6 +168,7 @@ class InFlight(object):
         self._next = 0
 
     def _lane(self, x, k):
+        self._model._plans.check_current()                           # parameters modified in place since the lanes were built
         if self._generation != self._model._plans.generation:      # load_state_dict / .to(): weights changed
             if any(lane.ticket is not None for lane in self._lanes.values()):
                 raise PPYoloHipError('the model changed while batches were in flight: collect their tickets first')

@@ -76,12 +76,11 @@ class ModelSettings(object):
             raise PPYoloHipError('the head holds no loss settings: build it with yolo_loss=YOLOv3Loss(...) (reference train.py:241-249)')
         self.backbone_type = type(bb).__name__
         self.backbone = dict(freeze_at=bb.freeze_at, feature_maps=list(bb.feature_maps))
-        dropping = [m for blk in hd.detection_blocks for m in blk.layers if type(m).__name__ == 'DropBlock']
         self.head = dict(anchors=hd.anchors, anchor_masks=hd.anchor_masks, num_classes=hd.num_classes, downsample=hd.downsample,
                          conv_block_num=hd.conv_block_num, coord_conv=hd.coord_conv, spp=hd.use_spp, keep_prob=hd.keep_prob,
                          drop_block=bool(hd.drop_block), iou_aware=hd.iou_aware,
                          # head.set_dropblock(is_test=True): the DropBlock modules stay in the layer lists, as identities
-                         drop_active=bool(dropping) and not all(m.is_test for m in dropping))
+                         drop_active=self.drop_active(hd))
         if hd.block_size != 3:
             raise PPYoloHipError('DropBlock block_size %r: the mask kernel implements the configurations\' 3' % (hd.block_size,))
         if bool(hd.iou_aware) != (yl._iou_aware_loss is not None):
@@ -93,8 +92,14 @@ class ModelSettings(object):
         self.use_ema = False
 
 
+    @staticmethod
+    def drop_active(hd):
+        dropping = [m for blk in hd.detection_blocks for m in blk.layers if type(m).__name__ == 'DropBlock']
+        return bool(dropping) and not all(m.is_test for m in dropping)
+
+
 class TrainStep(object):
-    def __init__(self, model, cfg=None, world_size=1, external_optimizer=False):
+    def __init__(self, model, cfg=None, world_size=1, external_optimizer=False, seed_rank=None):
         """cfg: a configuration object (config/ppyolo_2x.py), or None = read the settings from the model's own objects.
         external_optimizer: the parameters live in the MODULE and something else (torch.optim, the reference's loop) updates
         them: they are re-read at every forward, step() / sgd() / the fused EMA are off -- see loss_dict()."""
@@ -132,6 +137,11 @@ class TrainStep(object):
         self.ema_steps = 0
         self.masks = None
         self.seed = 0
+        # DropBlock draws differ between data-parallel ranks (the reference's processes each own a torch.rand stream) and
+        # between runs with another PPYOLO_HIP_SEED
+        rank = seed_rank if seed_rank is not None else (
+            torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0)
+        self.seed_base = (int(os.environ.get('PPYOLO_HIP_SEED', '0')) * 0x2545F491 + rank * 0x5851F42D) & 0xFFFFFFFFFFFF
         self.acts = None
         self.flops = 0                      # algorithmic convolution FLOPs (2 * MAC) of the last forward + backward
         # tile configurations: the measured bf16x3 table of the inference path knows the backbone's shapes; the head's own
@@ -151,7 +161,16 @@ class TrainStep(object):
             with open(TRAIN_TABLE_F16) as fh:
                 self._tuned_f.update(json.load(fh))
         self._amax_arena, self._amax_next = None, 0
-        self.overlap = os.environ.get('PPYOLO_HIP_TRAIN_OVERLAP', '1') != '0' and not self.external
+        # Gradient buckets go out as asynchronous all-reduces DURING the backward.  With backend nccl (= RCCL) that puts RCCL's fp32
+        # sum kernels beside this library's 16-bit-MFMA kernels on the same CUs -- the co-residence under which a packed-fp32
+        # instruction form misreads.  librccl's gfx950 code holds 945 v_pk_*_f32, none in that form
+        # (tools/rccl_pk_scan.py -> profiles/r03_rccl_pk_scan.txt), but the pair has never executed on hardware (no multi-GPU
+        # box): under nccl the overlap is therefore OPT-IN (PPYOLO_HIP_TRAIN_OVERLAP=1) and the default is one collective after
+        # the backward, when no MFMA kernel of this rank is in flight; other backends (gloo: host reductions) overlap by default.
+        ov = os.environ.get('PPYOLO_HIP_TRAIN_OVERLAP')
+        nccl = world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_backend() == 'nccl'
+        self.overlap = ((ov == '1') if nccl else (ov != '0')) and not self.external
         self._buckets, self._pending, self._works, self._reduced = None, {}, [], []
         self.tune = False                   # True: measure shapes the tables do not know while stepping (autotune())
         self.fuse_stats = os.environ.get('PPYOLO_HIP_TRAIN_FUSE_STATS', '1') == '1'      # BatchNorm statistics from the conv epilogue
@@ -617,7 +636,7 @@ class TrainStep(object):
             m = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=self.dev)
             scale = torch.empty(1, dtype=torch.float32, device=self.dev)
             self.seed += 1
-            K.dropblock_mask(m, scale, keep_prob, (self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
+            K.dropblock_mask(m, scale, keep_prob, (self.seed_base + self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
         y = self.new(x.N, x.H, x.W, x.C, req=True)
         y.amax = None if x.amax is None else x.amax * scale     # y = x * mask * scale, mask in {0, 1}
         K.dropblock_apply(x.view(), m, scale, y.view())
@@ -822,6 +841,8 @@ class TrainStep(object):
                 for w in self._works:
                     w.wait()
             else:
+                # not overlapped: the collective is ordered behind the backward's kernels on the current stream, and the SGD
+                # launches behind it -- RCCL's reduction never runs beside this rank's MFMA kernels
                 torch.distributed.all_reduce(self.gflat)
             self._works, self._reduced, self._pending = [], [], {}
             self.gflat.mul_(1.0 / self.world)
@@ -849,14 +870,21 @@ class TrainStep(object):
         return loss6
 
     # ---- views for tests / checkpoints --------------------------------------------------------------------------------------
-    def grads(self):
-        """Gradients in the state_dict's own layouts ([K, C, R, S] convolution weights)."""
+    def grads(self, flat=None):
+        """Gradients in the state_dict's own layouts ([K, C, R, S] convolution weights) -- of the last forward_backward, or
+        read from `flat`, a copy of the flat gradient buffer taken after an earlier one (then the results are views of it
+        wherever no re-layout is needed)."""
         out = {}
+        base = self.gflat.data_ptr()
         for k in self.train_keys:
             g = self.G[k]
+            if flat is not None:
+                o = (g.data_ptr() - base) // 4
+                g = flat[o:o + g.numel()].view(g.shape)
             if k in self._wcache:
-                g = g[..., :self._wcache[k]['Cin']].permute(0, 3, 1, 2).contiguous()
-            out[k] = g.clone()
+                out[k] = g[..., :self._wcache[k]['Cin']].permute(0, 3, 1, 2).contiguous()
+            else:
+                out[k] = g if flat is not None else g.clone()
         return out
 
     def sync_to_model(self, ema=False):
@@ -887,6 +915,10 @@ class _FinishedBackward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ts, loss6, n_terms, *params):
         ctx.ts = ts
+        # the gradients of THIS forward: the step's flat buffer is overwritten by the next training forward (gradient
+        # accumulation `(model(a) + model(b)).backward()`, a validation-loss forward before the backward), so keep a copy --
+        # one device-to-device move of 92.6 MB (R50vd head), ~40 us
+        ctx.gsnap = ts.gflat.clone()
         return tuple(loss6[i].clone() for i in range(n_terms))
 
     @staticmethod
@@ -896,7 +928,8 @@ class _FinishedBackward(torch.autograd.Function):
         if not g or any(v != g[0] for v in g) or len(g) != len(gs):
             raise PPYoloHipError('the HIP training step differentiates the SUM of the loss terms (reference train.py:429-440); '
                                  'got upstream gradients %s' % g)
-        grads = ts.grads()
+        grads = ts.grads(ctx.gsnap)
+        ctx.gsnap = None
         out = tuple(grads[k] if g[0] == 1.0 else grads[k] * g[0] for k in ts.train_keys)
         return (None, None, None) + out
 
@@ -910,9 +943,13 @@ def loss_dict(model, images, gt_box, targets):
     (BatchNorm on batch statistics everywhere, DropBlock), loss and the backward through the head run here, as HIP
     kernels; gt_label / gt_score do not enter the reference's loss either (model/losses.py:113-117)."""
     ts = getattr(model, '_train_bridge', None)
+    if ts is not None and (ts.dev != next(model.parameters()).device or ts.freeze_at != int(model.backbone.freeze_at)):
+        ts = None                     # moved / re-frozen since: the cached kernel-layout weights describe another model
     if ts is None:
         ts = TrainStep(model, None, external_optimizer=True)
         object.__setattr__(model, '_train_bridge', ts)
+    else:                             # head.set_dropblock(is_test=...) may have been called since (eval between iterations)
+        ts.cfg.head['drop_active'] = ModelSettings.drop_active(model.head)
     if isinstance(targets, (list, tuple)):
         targets = [t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets]
     dev = ts.dev

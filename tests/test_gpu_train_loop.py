@@ -170,3 +170,124 @@ def test_ema_class_matches_reference(golden):
         assert d == g['decays'][t] and 'frozen' not in ema._shadow
         assert np.array_equal(ema._shadow['a'].cpu().numpy(), g['a_shadow%d' % t])
         assert np.array_equal(ema._shadow['b'].cpu().numpy(), g['b_shadow%d' % t])
+
+
+def _r18_loop_pieces(S=128, N=2, seed=7):
+    from ppyolo_hip.targets import gt2yolo_target, synth_ground_truth
+    cfg = PPYOLO_r18vd_Config()
+    m = build_train_model(cfg, 0, 'cuda')
+    m.head.set_dropblock(is_test=True)          # (no random masks: the runs below are compared with each other)
+    bb, cc, ss = synth_ground_truth(N, seed)
+    hc = cfg.head
+    targets = [torch.from_numpy(t).cuda() for t in gt2yolo_target(bb, cc, ss, hc['anchors'], hc['anchor_masks'], hc['downsample'], 80, S)]
+    return cfg, m, torch.from_numpy(bb).cuda(), targets
+
+
+def test_eval_between_training_iterations_sees_the_current_weights():
+    """The reference's loop (train.py:481-499): every eval_iter iterations `ema.apply(); model.eval(); eval; model.train();
+    ema.restore()`.  The inference plans hold COPIES of the folded weights; each evaluation must run the parameters of its own
+    iteration -- checked against a freshly built model that loads the same state_dict."""
+    from model.EMA import ExponentialMovingAverage
+    from conftest import build_model
+    S, N = 128, 2
+    cfg, m, gt, targets = _r18_loop_pieces(S, N)
+    groups = []
+    m.add_param_group(groups, 0.002, 0.0005)
+    opt = torch.optim.SGD(groups, lr=0.002, momentum=0.9, weight_decay=0.0005)
+    ema = ExponentialMovingAverage(m, 0.9)
+    ema.register()
+    xe = synth.synth_images(N, S, seed=99).cuda()
+    ims = synth.synth_im_size(N).cuda()
+
+    def head_outputs(mod):
+        ex = mod._plans.executor(xe)
+        return [ex.view(a).dense().clone() for a in ex.plan.head_outs]
+
+    def evaluate(with_ema):
+        if with_ema:
+            ema.apply()
+        m.eval()
+        preds = [p.clone() for p in m(xe, ims)] + head_outputs(m)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.train()
+        if with_ema:
+            ema.restore()
+        fresh, _ = build_model(cfg, 0, 'cuda')
+        fresh.load_state_dict(sd)
+        want = [p for p in fresh(xe, ims)] + head_outputs(fresh)
+        assert len(preds) == len(want)
+        for a, b in zip(preds, want):
+            assert torch.equal(a, b), 'the evaluation ran stale weights'
+        return preds[N:]          # (the raw head outputs: detections may be empty on both sides)
+
+    seen = []
+    for it in range(4):
+        x = synth.synth_images(N, S, seed=300 + it).cuda()
+        losses = m(x, None, False, gt, None, None, targets)
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        opt.step()
+        ema.update()
+        if it in (1, 3):
+            seen.append(evaluate(with_ema=True))
+            seen.append(evaluate(with_ema=False))          # restore() changed the parameters again
+    # the four evaluations did run four different sets of weights
+    flat = [torch.cat([p.reshape(-1) for p in ps]) for ps in seen]
+    for i in range(len(flat)):
+        for j in range(i + 1, len(flat)):
+            assert flat[i].shape != flat[j].shape or not torch.equal(flat[i], flat[j])
+    # InFlight lanes notice as well
+    pipe = m.eval().in_flight(2)
+    t = pipe.submit(xe, ims)
+    first = t.result()
+    with torch.no_grad():
+        m.head.yolo_output_convs[0].conv.bias.add_(0.5)
+    def lane_outputs(k):
+        ex = pipe.lanes(xe)[k][0]
+        return [ex.view(a).dense().clone() for a in ex.plan.head_outs]
+    first = first + lane_outputs(0)
+    with torch.no_grad():
+        m.head.yolo_output_convs[0].conv.bias.add_(0.5)
+    second = pipe.submit(xe, ims).result()
+    second = second + lane_outputs(1)           # (round robin: the second submit went to lane 1, rebuilt from the new weights)
+    fresh, _ = build_model(cfg, 0, 'cuda')
+    fresh.load_state_dict(m.state_dict())
+    for a, b in zip(second, [p for p in fresh(xe, ims)] + head_outputs(fresh)):
+        assert torch.equal(a, b)
+    assert any(a.shape != b.shape or not torch.equal(a, b) for a, b in zip(first, second))
+    # pinned: the check is off, the caller vouches for the weights
+    m(xe, ims)                                  # (builds forward's own executor from the current weights)
+    m.pin_weights()
+    with torch.no_grad():
+        m.head.yolo_output_convs[0].conv.bias.add_(0.5)
+    m(xe, ims)
+    for a, b in zip(head_outputs(m), second[N:]):
+        assert torch.equal(a, b)
+
+
+def test_two_training_forwards_before_one_backward_keep_their_own_gradients():
+    """Gradient accumulation through the reference's surface: l1 = model(a); l2 = model(b); (l1 + l2).backward() must deliver
+    grad(a) + grad(b), not twice the last forward's gradients (the step's flat gradient buffer is reused by every forward)."""
+    S, N = 128, 2
+    cfg, m, gt, targets = _r18_loop_pieces(S, N)
+    xa, xb = synth.synth_images(N, S, seed=11).cuda(), synth.synth_images(N, S, seed=12).cuda()
+    names = [k for k, q in m.named_parameters() if q.requires_grad]
+    # BatchNorm running statistics do not enter a training forward's output, so the three passes see the same function
+    single = []
+    for x in (xa, xb):
+        m.zero_grad()
+        sum(m(x, None, False, gt, None, None, targets).values()).backward()
+        single.append({k: q.grad.detach().clone() for k, q in m.named_parameters() if q.grad is not None})
+    assert sorted(single[0]) == sorted(names)
+    m.zero_grad()
+    la = sum(m(xa, None, False, gt, None, None, targets).values())
+    lb = sum(m(xb, None, False, gt, None, None, targets).values())
+    (la + lb).backward()
+    worst = 0.0
+    for k, q in m.named_parameters():
+        if q.grad is None:
+            continue
+        want = single[0][k] + single[1][k]
+        assert torch.equal(q.grad, want), k
+        worst = max(worst, float((single[0][k] - single[1][k]).abs().max()))
+    assert worst > 0          # the two batches do have different gradients

@@ -42,8 +42,10 @@ def relmax(a, b):
     return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize('cfgc,S', [(PPYOLO_r18vd_Config, 256), (PPYOLO_2x_Config, 192)])
+@pytest.mark.parametrize('cfgc,S', [(PPYOLO_r18vd_Config, 256)])
 def test_train_step_matches_the_oracle(cfgc, S):
+    # (R50vd: test_train_step_three_way / test_train_step_full_size below -- its training-mode forward amplifies fp32 rounding
+    # 1000x on the way to the head, in the reference as much as here, so it is held to the reference's own distance from float64)
     from ppyolo_hip.train import TrainStep
     cfg = cfgc()
     N = 4
@@ -89,20 +91,9 @@ def test_train_step_matches_the_oracle(cfgc, S):
     for k, g in grads.items():
         worst[k] = relmax(g, r['grads'][k])
     print('max relative gradient error over %d tensors: %.3e (median %.3e)' % (len(worst), max(worst.values()), float(np.median(list(worst.values())))))
-    if cfgc is PPYOLO_r18vd_Config:
-        # (median 1e-5 .. 3e-4 depending on the rounding of the BatchNorm statistics; a single LeakyReLU slope that flips on an
-        # element within rounding of 0 moves a 256-term sum by 1e-2)
-        assert float(np.median(list(worst.values()))) <= 1e-3 and max(worst.values()) <= 3e-2, {k: v for k, v in worst.items() if v > 2e-3}
-    else:
-        # R50vd at a size the CPU oracle can run: stage 5 (6x6 maps, BatchNorm over 144 samples, channels that ReLU leaves
-        # almost constant) amplifies the 4e-5 agreement of stages 2-4 to 2e-3 at the head input -- in the oracle on another CPU
-        # just as much -- and LeakyReLU / |.| sign flips of a handful of elements then move sums of a few hundred terms by
-        # tens of percent.  Held here: every gradient tensor points the same way; the head's backward is compared STRICTLY
-        # on well-conditioned features in test_r50_head_backward_strict.
-        cos = {k: float(torch.nn.functional.cosine_similarity(g.double().cpu().reshape(1, -1), r['grads'][k].double().reshape(1, -1)))
-               for k, g in grads.items()}
-        print('min cosine similarity %.4f' % min(cos.values()))
-        assert min(cos.values()) >= 0.9, {k: v for k, v in cos.items() if v < 0.9}
+    # (median 1e-5 .. 3e-4 depending on the rounding of the BatchNorm statistics; a single LeakyReLU slope that flips on an
+    # element within rounding of 0 moves a 256-term sum by 1e-2)
+    assert float(np.median(list(worst.values()))) <= 1e-3 and max(worst.values()) <= 3e-2, {k: v for k, v in worst.items() if v > 2e-3}
     # BatchNorm running statistics moved the same way
     for k in ('backbone.stage1_conv1_1.bn.running_mean', 'backbone.stage1_conv1_1.bn.running_var'):
         assert relmax(model.state_dict()[k], r['state'][k]) <= 1e-4
@@ -286,45 +277,79 @@ def test_stage5_blocks_backward_strict():
     assert max(worst.values()) <= 0.12 and float(np.median(list(worst.values()))) <= 1.5e-2, {k: v for k, v in worst.items() if v > 1.5e-2}
 
 
-@pytest.mark.parametrize('cfgc,S,fa', [(PPYOLO_r18vd_Config, 256, 2), (PPYOLO_r18vd_Config, 192, 0), (PPYOLO_2x_Config, 192, 3)])
-def test_train_step_with_backbone_stages(cfgc, S, fa):
+def _assert_three_way(res, capsys=None):
+    """The whole step against the float64 oracle, held to the fp32 oracle's own distance from it (tests/train_parity_util.py).
+    Why not a plain tolerance: the training-mode forward normalises every layer with BATCH statistics, which makes the random-
+    weight network mildly chaotic -- the reference's own fp32 forward drifts 1.2x per layer from a float64 run (3.5x per DCNv2
+    block), to 2.4e-3 rms at the head outputs and 12 % at the gradients, at 608 px as much as at 192 (profiles/r03_train_parity.txt).
+    Two correct fp32 implementations are therefore this far apart; what can be held is that the HIP path is no further from
+    the exact answer than the reference is."""
+    import train_parity_util as tp
+    lines = tp.summarize(res)
+    if capsys is not None:
+        with capsys.disabled():
+            print('\n' + '\n'.join(lines))
+    for d in res['feats']:
+        assert d['hip_rms'] <= 1.5 * d['ref_rms'] + 1e-7 * d['rms'], ('backbone feature map', d)
+    for d in res['heads']:
+        assert d['hip_rms'] <= 1.5 * d['ref_rms'], ('head outputs', d)
+    # a loss term is a sum over P ~ 10^2..10^3 positive cells of quantities that carry the head outputs' error delta ~ 3e-3:
+    # relative error ~ delta / sqrt(P) ~ 1e-3 for either implementation (the reference's own: 3e-7 .. 4e-4, by luck of the draw)
+    for k, (h, a, b) in res['losses'].items():
+        assert abs(h - b) <= 5e-3 * abs(b), (k, h, a, b)
+    gh = np.array([v[0] for v in res['grads'].values()])
+    gr = np.array([v[1] for v in res['grads'].values()])
+    assert np.median(gh) <= 1.5 * np.median(gr) + 1e-6 and gh.max() <= 1.5 * gr.max() + 1e-5, (np.median(gh), np.median(gr), gh.max(), gr.max())
+    bh = np.array([v[0] for v in res['bn'].values()])
+    br = np.array([v[1] for v in res['bn'].values()])
+    assert np.median(bh) <= 1e-5 and bh.max() <= 1.5 * br.max() + 1e-6, (np.median(bh), bh.max(), br.max())
+    ho = res.get('head_only')
+    if ho:
+        # identical inputs to the part that trains: fp32-level tolerances
+        for k, (h, a, b) in ho['losses'].items():
+            assert abs(h - b) <= 1e-5 * abs(b), (k, h, a, b)                   # (asked for: 1e-4; measured <= 7.2e-7)
+        assert all(v[0] <= 1e-5 for v in ho['outs']), ho['outs']               # measured <= 2.6e-6 of the maximum
+        assert all(v[0] <= 2e-5 for v in ho['douts']), ho['douts']             # measured <= 3.4e-6
+        hh = np.array([v[0] for v in ho['grads'].values()])
+        hr = np.array([v[1] for v in ho['grads'].values()])
+        # (the R50vd head's backward carries ~1e-3 of fp32 noise in BOTH implementations -- BatchNorm backward cancellation
+        # over 20 layers: reference fp32 vs float64 median 6e-4, max 1.3e-3 .. 2e-3; r18vd: 1e-6)
+        assert np.median(hh) <= 1.5 * np.median(hr) + 1e-6 and hh.max() <= 3.0 * hr.max() + 1e-5 and hh.max() <= 1e-2, \
+            (np.median(hh), np.median(hr), hh.max(), hr.max())
+
+
+def test_train_step_full_size(capsys):
+    """BASELINE config 5 at ITS OWN workload: R50vd 608x608, 8 images, freeze_at = 5, DropBlock active (the oracle's masks),
+    the f16x2 kernels -- three-way against the fp32 and the float64 training oracle (reference train.py:416-443,
+    model/losses.py:121-241, model/iou_losses.py:39-246); numbers in profiles/r03_train_parity.txt."""
+    import train_parity_util as tp
+    res = tp.three_way(PPYOLO_2x_Config, 608, 8, 5, True)
+    assert len(res['grads']) == 69 and len(res['losses']) == 6 and 'head_only' in res
+    _assert_three_way(res, capsys)
+
+
+@pytest.mark.parametrize('cfgc,S,N', [(PPYOLO_2x_Config, 320, 4), (PPYOLO_r18vd_Config, 416, 8)])
+def test_train_step_three_way(cfgc, S, N, capsys):
+    """The whole step at a size the CPU oracle runs in seconds (golden g16's 320 px for R50vd; config 2's workload for r18vd)."""
+    import train_parity_util as tp
+    _assert_three_way(tp.three_way(cfgc, S, N, 5, True), capsys)
+
+
+@pytest.mark.parametrize('cfgc,S,fa', [(PPYOLO_r18vd_Config, 256, 2), (PPYOLO_r18vd_Config, 192, 0), (PPYOLO_2x_Config, 320, 3)])
+def test_train_step_with_backbone_stages(cfgc, S, fa, capsys):
     """freeze_at < 5: the stages above it train with the head (reference model/resnet_vd.py:174-200) -- strided 3x3 data gradients,
-    avg-pool shortcuts, DCNv2 backward in the loop; against the oracle's autograd on the same inputs, DropBlock off, the loss
-    gradient injected (see test_train_step_matches_the_oracle)."""
-    from ppyolo_hip.train import TrainStep
-    cfg = cfgc()
-    N = 4
-    model, sd = build_model(cfg, 0, 'cuda')
-    cfg.backbone['freeze_at'] = fa
-    cfg.head['drop_active'] = False
-    x = synth.synth_images(N, S, seed=11)
-    gt, targets = synth_targets(cfg, N, S, 5)
-    real = orc.drop_block_train
-    orc.drop_block_train = lambda t, *a, **k: t
-    try:
-        torch.set_num_threads(16)
-        r = trn.train_step(sd, cfg, x, gt, targets)
-    finally:
-        orc.drop_block_train = real
-    ts = TrainStep(model, cfg)
-    loss6 = ts.forward_backward(x.cuda(), gt.cuda(), [t.cuda() for t in targets], inject_douts=[d.clone() for d in r['douts']])
-    torch.cuda.synchronize()
-    grads = ts.grads()
-    assert set(grads) == set(r['grads']) and any(k.startswith('backbone.stage%d' % (fa + 1)) for k in grads)
-    cos = {k: float(torch.nn.functional.cosine_similarity(g.double().cpu().reshape(1, -1), r['grads'][k].double().reshape(1, -1)))
-           for k, g in grads.items()}
-    worst = {k: relmax(g, r['grads'][k]) for k, g in grads.items()}
-    bb = [k for k in grads if k.startswith('backbone.')]
-    print('freeze_at %d: %d tensors (%d in the backbone): min cosine %.4f (%s), median relative max error %.2e'
-          % (fa, len(grads), len(bb), min(cos.values()), min(cos, key=cos.get), float(np.median(list(worst.values())))))
-    # (whole-network comparison: BatchNorm on batch statistics over tiny maps amplifies fp32 noise, see above; the blocks'
-    # backward is held to fp32 tolerance on well-conditioned inputs in test_stage5_blocks_backward_strict and the operator tests)
-    assert min(cos.values()) >= 0.9, {k: v for k, v in cos.items() if v < 0.9}
+    avg-pool shortcuts, DCNv2 backward in the loop; three-way against the oracle's autograd in fp32 and float64, DropBlock off."""
+    import train_parity_util as tp
+    res = tp.three_way(cfgc, S, 4, fa, False, want_model=True)
+    ts, model = res.pop('_ts'), res.pop('_model')
+    bb = [k for k in res['grads'] if k.startswith('backbone.')]
+    assert any(k.startswith('backbone.stage%d' % (fa + 1)) for k in bb)
+    _assert_three_way(res, capsys)
     # and one SGD step runs over the enlarged parameter set (conv_offset biases in the weight-decay group)
+    before = model.state_dict()[bb[0]].clone()
     ts.sgd(1e-3)
     ts.sync_to_model()
-    k0 = bb[0]
-    assert not torch.equal(model.state_dict()[k0].cpu(), sd[k0])
+    assert not torch.equal(model.state_dict()[bb[0]], before)
 
 
 def test_multi_scale_steps():
