@@ -101,6 +101,26 @@ int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const v
                           int H, int W, int C, int K, int R, int S, int stride, int pad, int act,
                           int upsample2x, int cfg, int splitk, const float *amax_in, float *amax_out,
                           void *ws, size_t ws_bytes, void *stream);
+/* The same launch with PRE-SPLIT tensors on one or both sides ("global pre-split"; f16x2 tile kernels of
+ * csrc/conv_x3.hip / conv_ws.hip with an explicit cfg, one split; a pre-split y cannot be combined with upsample2x).  Between a producer convolution and the ONE
+ * convolution that consumes its output the tensor can travel as the consumer's finished MFMA operands instead of fp32: per pixel
+ * and 32-channel group, 32 fp16 first terms followed by 32 fp16 second terms of value * s_image (RNE; the residual is exact) -- the
+ * same 128 bytes, the same pixel stride.  The consumer's main loop then carries no scale / split VALU work.
+ *   y_split_scale != NULL: y is WRITTEN in that form (K and y_ld multiples of 32, y 128-byte aligned) and y_split_scale[n]
+ *     receives the power of two s_n that puts the STATIC bound  y_bound_mul * max|x_n| + y_bound_add  of |y_n| into [2^13, 2^14)
+ *     (caller's duty: y_bound_mul >= max_k |scale_k| * sum_c |w_k,c|, y_bound_add >= max_k |shift_k| (+ |posbias * scale|);
+ *     max|x_n| is taken from amax_in, rounded up to a power of two); amax_out still receives max|y|.
+ *   x_split_scale != NULL: x holds such operands, written by a launch whose y_split_scale it is (C and x_ld multiples of 32).
+ * PPY_ERR_BAD_ARG when the chosen cfg cannot read / write such tensors (never a silent reinterpretation of the bytes).
+ * Reference operator: the same Conv2dUnit.forward (model/custom_layers.py:243-253). */
+int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                                const void *w_f16x2, const float *scale, const float *scale_f16x2,
+                                const float *shift, const float *residual, int res_ld,
+                                const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N,
+                                int H, int W, int C, int K, int R, int S, int stride, int pad, int act,
+                                int upsample2x, int cfg, int splitk, const float *amax_in, float *amax_out,
+                                void *ws, size_t ws_bytes, void *stream, const float *x_split_scale,
+                                float *y_split_scale, float y_bound_mul, float y_bound_add);
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int cfg, int splitk);
 int ppy_conv2d_num_configs(void);

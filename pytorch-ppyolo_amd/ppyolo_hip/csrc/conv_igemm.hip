@@ -571,13 +571,14 @@ static unsigned long long *g_trace = nullptr;
 // (4 x u64 per workgroup); tools/conv_trace.py turns that into a per-CU timeline.
 extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 
-extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
-                                     const void *w_f16x2, const float *scale, const float *scale_f16x2,
-                                     const float *shift, const float *residual, int res_ld,
-                                     const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N, int H,
-                                     int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
-                                     int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
-                                     size_t ws_bytes, void *stream) {
+static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                       const void *w_f16x2, const float *scale, const float *scale_f16x2,
+                       const float *shift, const float *residual, int res_ld,
+                       const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N, int H,
+                       int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
+                       int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
+                       size_t ws_bytes, void *stream, const float *x_split_scale, float *y_split_scale, float y_bound_mul,
+                       float y_bound_add) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && w_krsc && scale && shift && y);
     Geometry g;
@@ -609,18 +610,55 @@ extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_kr
     p.chunks_per_split = ceil_div(g.chunks, s);
     p.nstages = 2;
     p.trace = g_trace;
+    p.xscale = x_split_scale; p.yscale = y_split_scale; p.ysplit_mul = y_bound_mul; p.ysplit_add = y_bound_add;
     hipStream_t st = (hipStream_t)stream;
     rc = dispatch_cfg(p, c, s, st);
-    if (rc == PPY_ERR_UNSUPPORTED && c >= 14) {
+    if (rc == PPY_ERR_UNSUPPORTED && c >= 14 && !x_split_scale && !y_split_scale) {
         // LDS-DMA kernel declined (tensor >= 4 GB: 32-bit DMA offsets): VGPR-staged kernel, 64x64 tiles
         rc = dispatch_cfg(p, 3, s, st);
     }
     return rc;
 }
 
+extern "C" int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                                     const void *w_f16x2, const float *scale, const float *scale_f16x2,
+                                     const float *shift, const float *residual, int res_ld,
+                                     const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
+                                     int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N, H,
+                       W, C, K, R, S, stride, pad, act, upsample2x, cfg, splitk, amax_in, amax_out, ws, ws_bytes, stream, nullptr,
+                       nullptr, 0.f, 0.f);
+}
+
+// The same launch with PRE-SPLIT tensors on one or both sides (f16x2 tile kernels, explicit cfg, one split):
+// x_split_scale != NULL: x holds finished operands -- per pixel and 32-channel group 32 fp16 first terms then 32 fp16 second
+// terms of x * x_split_scale[n] (what a producer launch with y_split_scale wrote);  y_split_scale != NULL: y is WRITTEN in that
+// form for its one consumer, with y_split_scale[n] = the power of two that puts  y_bound_mul * max|x_n| + y_bound_add  (a
+// static bound of |y|: y_bound_mul >= max_k |scale_k| * sum|w_k|, y_bound_add >= max_k |shift_k| (+ the position bias)) into
+// [2^13, 2^14).  PPY_ERR_BAD_ARG when the chosen kernel cannot read / write such tensors -- never a silent reinterpretation.
+extern "C" int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
+                                           const void *w_f16x2, const float *scale, const float *scale_f16x2,
+                                           const float *shift, const float *residual, int res_ld,
+                                           const float *posbias, const float *posbias_f16x2, float *y, int y_ld, int N, int H,
+                                           int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
+                                           int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
+                                           size_t ws_bytes, void *stream, const float *x_split_scale, float *y_split_scale,
+                                           float y_bound_mul, float y_bound_add) {
+    PPY_CHECK_ARG(cfg >= 0 && splitk <= 1 && !(upsample2x && y_split_scale));
+    PPY_CHECK_ARG(!y_split_scale || (y_bound_mul >= 0.f && y_bound_add >= 0.f && K % 32 == 0 && y_ld % 32 == 0 && ((uintptr_t)y & 127) == 0));
+    PPY_CHECK_ARG(!x_split_scale || (C % 32 == 0 && x_ld % 32 == 0 && ((uintptr_t)x & 127) == 0));
+    return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N, H,
+                       W, C, K, R, S, stride, pad, act, upsample2x, cfg, splitk, amax_in, amax_out, ws, ws_bytes, stream, x_split_scale,
+                       y_split_scale, y_bound_mul, y_bound_add);
+}
+
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
     // (statistics from the epilogue exist in the f16x2 kernels only: conv_x3.hip's tiles, conv_stream.hip, conv_patch.hip, conv_ws.hip)
     if (p.bn_part && c < kNumCfgs + ppy_x3_f16_base()) return PPY_ERR_UNSUPPORTED;
+    // pre-split tensors exist on the f16x2 tiles (conv_x3.hip, conv_ws.hip) only: anything else would misread the bytes
+    if ((p.xscale || p.yscale) && (c < kNumCfgs + ppy_x3_f16_base() || (c >= stream_first() && c < ws_first()))) return PPY_ERR_BAD_ARG;
     if (c >= ws_first()) return ppy_ws_dispatch(p, c - ws_first(), s, st);
     if (c >= patch_first()) return s == 1 ? ppy_patch_dispatch(p, c - patch_first(), st) : PPY_ERR_BAD_ARG;
     if (c >= stream_first()) return s == 1 ? ppy_stream_dispatch(p, c - stream_first(), nullptr, 0, st) : PPY_ERR_BAD_ARG;

@@ -23,7 +23,31 @@ struct ConvArgs {
     float *bn_part = nullptr;
     int *bn_slices_host = nullptr;
     int bn_capacity = 0;         // slices bn_part has room for (a launcher that needs more returns PPY_ERR_WORKSPACE)
+    // "global pre-split" (round 3; f16x2 kernels): a producer whose output has ONE consumer, a convolution on
+    // these kernels, stores it as the consumer's MFMA operand -- per 32-channel group of a pixel 32 fp16 first terms then 32 fp16
+    // second terms of y * s (the same 128 bytes the fp32 values would take) -- with s = a power of two per image from a STATIC
+    // bound of |y|: ysplit_mul * (an upper bound of the input's tracked maximum) + ysplit_add.  The consumer then reads finished
+    // operands: no scale / split VALU work per (tap, wave) in its main loop.
+    float *yscale = nullptr;        // producer: [N] per-image scales of the split output it writes (NULL: plain fp32 output)
+    float ysplit_mul = 0.f, ysplit_add = 0.f;
+    const float *xscale = nullptr;  // consumer: [N] per-image scales of its pre-split input (NULL: fp32 input, tracked maximum)
 };
+
+// scale of a pre-split tensor from a bound of its magnitude: the power of two that puts `bound` into [2^13, 2^14), as the
+// activation scales of the f16x2 kernels (conv_x3.hip), clamped to [2^-24, 2^40]
+static __device__ __forceinline__ float split_scale_of(float bound) {
+    const int e = (int)((__float_as_uint(bound) >> 23) & 0xffu);
+    int f = 267 - e;
+    f = f < 103 ? 103 : (f > 167 ? 167 : f);
+    return __uint_as_float((unsigned)f << 23);
+}
+static __device__ __forceinline__ float pow2_above(float mx) {       // the power of two in (mx, 2 mx]  (mx >= 0; 2^-126 for 0)
+    const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;
+    return __uint_as_float((e >= 253u ? 254u : e + 1u) << 23);
+}
+static __device__ __forceinline__ float pow2_inverse(float s) {      // 1 / s for s = 2^k, exactly
+    return __uint_as_float((254u - ((__float_as_uint(s) >> 23) & 0xffu)) << 23);
+}
 
 struct Geometry {
     int Ho, Wo, M, Kred, chunks;
@@ -47,6 +71,28 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
+
+// ---- exact operand splits for the 16-bit MFMA (conv_x3.hip header: bf16x3 = 3 bf16 terms, f16x2 = 2 fp16 terms) ----
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float floatx2;
+typedef __attribute__((ext_vector_type(4))) unsigned uintx4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // RNE, a -> low half
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// halves of a packed pair back to fp32 (scalar bit casts: a vector bit_cast of the packed word was mis-combined
+// across the pairs of a fragment by hipcc -O3 -- every pair subtracted the FIRST pair's value)
+__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // RNE, a -> low half
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 __device__ __forceinline__ float epilogue_store(const ConvArgs &p, int m, int col, float v,
                                                 float sc, float sh) {
@@ -76,7 +122,11 @@ __device__ __forceinline__ float epilogue_store(const ConvArgs &p, int m, int co
 template <int TM, int TN, int WM, int WN, bool SPLIT, bool VEC>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)[TM][TN], float *smem, int m0,
                                               int n0, int wm, int wn, int lane, int wave, int split,
-                                              const float (*rowscale)[4] = nullptr) {
+                                              const float (*rowscale)[4] = nullptr, const float (*rowsplit)[4] = nullptr,
+                                              bool split_out = false) {
+    // split_out (vector path, no split-K, no upsampling): the output is stored PRE-SPLIT for its one consumer (ConvArgs::yscale);
+    // rowsplit = scale of the image of the rows (lane>>3) + 8t of tile i.  (A flag beside an always-valid array: a pointer that is
+    // null at run time put the array into scratch memory.)
     // rowscale (vector path only): factor for the rows (lane>>3) + 8t of tile i that this lane finishes -- the f16x2
     // kernels undo their per-image activation scale here, after the transposition, instead of on the accumulators
     const int hw = p.Ho * p.Wo;
@@ -159,7 +209,18 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                                 amx = fmaxf(amx, m < bnd ? rmx : 0.0f);
                                 amx_hi = fmaxf(amx_hi, m < bnd ? 0.0f : rmx);
                             }
-                            if (!p.ups) {
+                            if (rowsplit != nullptr && split_out) {
+                                // two fp16 terms of v * s (RNE; the residual fma(v, s, -first) is exact), first terms of the
+                                // pixel's 32-channel group in its bytes 0..63, second terms in bytes 64..127
+                                typedef __attribute__((ext_vector_type(2))) unsigned uintx2_;
+                                const float s = rowsplit[i][t];
+                                const unsigned h0 = cvt_pk_f16(v[0] * s, v[1] * s), h1 = cvt_pk_f16(v[2] * s, v[3] * s);
+                                const unsigned l0 = cvt_pk_f16(fmaf(v[0], s, -f16_lo(h0)), fmaf(v[1], s, -f16_hi(h0)));
+                                const unsigned l1 = cvt_pk_f16(fmaf(v[2], s, -f16_lo(h1)), fmaf(v[3], s, -f16_hi(h1)));
+                                char *o = reinterpret_cast<char *>(p.y + (long long)m * p.y_ld) + (col >> 5) * 128 + (col & 31) * 2;
+                                *reinterpret_cast<uintx2_ *>(o) = uintx2_{h0, h1};
+                                *reinterpret_cast<uintx2_ *>(o + 64) = uintx2_{l0, l1};
+                            } else if (!p.ups) {
                                 *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
                             } else {
                                 const int n = m / hw, rem = m - n * hw;
@@ -266,28 +327,6 @@ __device__ __forceinline__ void tile_bn_stats(const ConvArgs &p, const floatx16 
             o[2] = m2;
         }
     }
-}
-
-// ---- exact operand splits for the 16-bit MFMA (conv_x3.hip header: bf16x3 = 3 bf16 terms, f16x2 = 2 fp16 terms) ----
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float floatx2;
-typedef __attribute__((ext_vector_type(4))) unsigned uintx4;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // RNE, a -> low half
-    const floatx2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// halves of a packed pair back to fp32 (scalar bit casts: a vector bit_cast of the packed word was mis-combined
-// across the pairs of a fragment by hipcc -O3 -- every pair subtracted the FIRST pair's value)
-__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
-__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // RNE, a -> low half
-    const floatx2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
 // 8 consecutive-k floats of one row -> three bf16x8 MFMA operands (exact 3-term split)

@@ -22,7 +22,9 @@ namespace {
 // 16-byte LDS reads per 32 rows and k-step, as before) and execute no VALU instruction per operand at all.  In the plain form
 // every consumer wave splits the rows of its sub-tile itself -- twice per workgroup (the two waves of a row of the 2 x 2
 // layout), in the issue slots of the waves that feed the MFMA pipe.  Same values, same products: bit-identical results.
-template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false>      // (BNS: conv_x3.hip)
+// GP = true: the input arrives pre-split from its producer (conv_x3.hip, ConvArgs::xscale): same DMA, the consumers' fragment
+// reads are the operands.
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2;              // consumer waves: CM x 2 over the tile (256-row tiles: eight)
@@ -33,6 +35,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     constexpr int A_BYTES = BM * 128, AP_BYTES = PRE ? 2 * BM * 64 : 0, B_BYTES = B_ROWS * 64;      // fp32 landing area, A planes, B planes
     constexpr int STAGE = A_BYTES + AP_BYTES + B_BYTES;
     static_assert((NS - 1) * G <= 63, "6-bit vmcnt");
+    static_assert(!GP || (!PRE && !SPLIT && VEC && !BNS), "pre-split input: plain consumers, one split, vector epilogue");
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) char smem_ws[];
     char *smem = smem_ws;
@@ -197,23 +200,36 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     int a_foff[2][2], b_foff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
-        a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        if constexpr (GP) {      // first terms in the 16-byte slots 0..3 of the row, second terms in 4..7 (conv_x3.hip)
+            a_foff[s][0] = frow * 128 + (((2 * s + fkh) ^ a_sw) << 4);
+            a_foff[s][1] = frow * 128 + (((4 + 2 * s + fkh) ^ a_sw) << 4);
+        } else {
+            a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
+            a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        }
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
     int ap_foff[2];                       // PRE: A planes, row (lane&31), slot 2s+h at (2s+h) ^ ((row>>2)&3)
 #pragma unroll
     for (int s = 0; s < 2; ++s) ap_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
-    float sa[TM], inv_sa[TM];
+    float sa[TM], inv_sa[TM], xmax_up[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {        // per-image activation scale (conv_x3.hip)
+        xmax_up[i] = 1.0f;
         const int mrow = min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1);
+        if constexpr (GP) {
+            sa[i] = p.xscale[mrow / hw];
+            inv_sa[i] = pow2_inverse(sa[i]);
+            if (p.yscale) xmax_up[i] = pow2_above(amax_read(p.amax_in, mrow / hw));      // (conv_x3.hip: chains bound from the tracked maximum)
+            continue;
+        }
         const float mx = amax_read(p.amax_in, mrow / hw);
         const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
         int f = 267 - e;
         f = f < 103 ? 103 : (f > 167 ? 167 : f);
         sa[i] = __uint_as_float((unsigned)f << 23);
         inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
+        xmax_up[i] = 16384.0f * inv_sa[i];
     }
 
     struct Frag {        // operands of one k-step
@@ -222,7 +238,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     };
     constexpr int NM = 3 * TM * TN;            // MFMAs per k-step
     constexpr int NRA = 2 * TM, NRB = NP * TN, NR = NRA + NRB;
-    constexpr int NSL = PRE ? 0 : 3 * 4 * TM;  // split stages per k-step (3 dependent stages x 4 pairs x TM)
+    constexpr int NSL = (PRE || GP) ? 0 : 3 * 4 * TM;  // split stages per k-step (3 dependent stages x 4 pairs x TM)
     constexpr int RPS = (NR + NM - 1) / NM;
     constexpr int LEAD0 = (NRA + RPS - 1) / RPS + 1;
     constexpr int LEAD = LEAD0 < NM ? LEAD0 : NM - 1;
@@ -250,6 +266,8 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
                 } else if (r < NRA) {
                     if constexpr (PRE)      // (tile r>>1, plane r&1)
                         nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r & 1) * BM * 64 + (r >> 1) * 32 * 64 + ap_foff[s]);
+                    else if constexpr (GP)  // (tile r>>1, term r&1) of the pre-split rows
+                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
                     else
                         raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
                 } else {
@@ -300,6 +318,11 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
                         f0.a[i][pl] = *reinterpret_cast<const uintx4 *>(smem + A_BYTES + pl * BM * 64 + (wm * WM + i * 32) * 64 + ap_foff[0]);
                     continue;
                 }
+                if constexpr (GP) {
+                    f0.a[i][0] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
+                    f0.a[i][1] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+                    continue;
+                }
                 const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
                 const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
 #pragma unroll
@@ -328,7 +351,25 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
         __builtin_amdgcn_s_barrier();
     }
     if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * CM + wm);
-    float rowscale[TM][4];
+    float rowscale[TM][4], rowsplit[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rowsplit[i][t] = 0.f;
+    bool split_out = false;
+    if constexpr (VEC && !SPLIT) {        // the output goes to one consumer as finished operands (conv_x3.hip, ConvArgs::yscale)
+        split_out = p.yscale != nullptr;
+        if (split_out) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float ys = split_scale_of(fmaf(p.ysplit_mul, xmax_up[i], p.ysplit_add));
+                const int mr = m0 + wm * WM + i * 32 + (lane & 31);
+                if (n0 == 0 && wn == 0 && lane < 32 && mr < p.M) p.yscale[mr / hw] = ys;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rowsplit[i][t] = __shfl(ys, (lane >> 3) + 8 * t);
+            }
+        }
+    }
     if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -345,16 +386,19 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
             }
     }
     tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
-                                              VEC ? rowscale : nullptr);
+                                              VEC ? rowscale : nullptr, (VEC && !SPLIT) ? rowsplit : nullptr, split_out);
 #endif
 }
 
-template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false>
+template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false, bool GP = false>
 int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    if constexpr (!SPLIT && !BNS) {
+    if constexpr (!SPLIT && !BNS && !GP) {
         if (p.bn_part) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
     }
-    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE>;
+    if constexpr (!SPLIT && VEC && !BNS && !PRE && !GP) {
+        if (p.xscale) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, false, true>(p, splits, lds, tiles, stream);
+    }
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE, GP>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(BM == 256 ? 768 : 512), lds, stream, p);
@@ -382,6 +426,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
         if (ceil_div(p.M, BM) * (BM == 256 ? 4 : 2) > p.bn_capacity) return PPY_ERR_WORKSPACE;
         if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * (BM == 256 ? 4 : 2);
     }
+    if ((p.xscale || p.yscale) && (splits > 1 || !vec || p.bn_part)) return PPY_ERR_BAD_ARG;      // (conv_x3.hip's rule)
+    if (p.yscale && p.ups) return PPY_ERR_BAD_ARG;
+    if (p.xscale && PRE) return PPY_ERR_BAD_ARG;
+    if (p.yscale && (p.K % 32 != 0 || p.y_ld % 32 != 0)) return PPY_ERR_BAD_ARG;
     int rc;
     if (splits > 1) {
         rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true>(p, splits, lds, tiles, stream)

@@ -80,7 +80,11 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float *w, long
 // that every group has the same G pieces and the counted vmcnt waits stay what they are).
 // BNS = true (training forward, ppy_conv2d_train_fwd_f32): the epilogue also emits the BatchNorm statistics of what it stores
 // (tile_bn_stats, conv_shared.h).  A separate instantiation: as a run-time branch it cost the inference kernels 12-20 VGPRs.
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false>
+// GP = true ("global pre-split", f16x2 only): the input tensor was stored by its producer as finished operands -- per pixel and
+// 32-channel group 32 fp16 first terms, then 32 fp16 second terms of x * s_image (ConvArgs::xscale; conv_shared.h's split
+// store) -- so a chunk's A row is the same 128 bytes, DMA'd and swizzled as before, but the fragment reads ARE the MFMA
+// operands: no scale / split VALU instruction in the main loop.
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false, bool GP = false>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -91,6 +95,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     constexpr int B_ROWS = NP * BN;
     static_assert(BM % (8 * NW) == 0 && B_ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
     static_assert(!SLAB || F16, "the slab variant zeroes padding taps through the f16x2 activation scale");
+    static_assert(!GP || (F16 && !SLAB && !SPLIT && VEC), "pre-split input: f16x2 tiles, one split, vector epilogue");
     constexpr int SLAB_PIECES = BM / 8 + 1;                        // slab rows 0 .. BM+7 (BM + 2 are used)
     constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
     constexpr int SP_W = (SLAB_PIECES + NW - 1) / NW;              // slab pieces per wave per super-chunk
@@ -289,17 +294,22 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     int a_foff[2][2], b_foff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
-        a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        if constexpr (GP) {      // first terms in the 16-byte slots 0..3 of the row, second terms in 4..7: k-step s, half h -> slot 2s+h (+4)
+            a_foff[s][0] = frow * 128 + (((2 * s + fkh) ^ a_sw) << 4);
+            a_foff[s][1] = frow * 128 + (((4 + 2 * s + fkh) ^ a_sw) << 4);
+        } else {
+            a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
+            a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
+        }
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
 
     // f16x2: activation scale PER IMAGE = the power of two that puts the image's maximum (tracked by its producers,
     // amax_track in common.h) into [2^13, 2^14); a lane keeps the scale of the image of each of its TM tile rows.
     // Both scales are exact powers of two.
-    float sa[TM], inv_sa[TM];
+    float sa[TM], inv_sa[TM], xmax_up[TM];      // (xmax_up: a power of two above the image's tracked max|x|)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) sa[i] = inv_sa[i] = 1.0f;
+    for (int i = 0; i < TM; ++i) sa[i] = inv_sa[i] = xmax_up[i] = 1.0f;
     // slab variant, "fetch context" of the chunk whose operands are being read: taps inside the image for each of this
     // lane's fragment rows (bit r*3 + s), the scale with the padding taps zeroed, the slab and the tap's row shift
     unsigned f_ok[TM];
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     constexpr int NST = F16 ? 3 : 5;          // dependent split stages per pair
     constexpr int NM = NPROD * TM * TN;       // MFMAs per k-step
     constexpr int NRA = 2 * TM, NRB = NP * TN; // LDS reads per k-step
-    constexpr int NSL = NST * 4 * TM;         // split stages per k-step
+    constexpr int NSL = GP ? 0 : NST * 4 * TM;         // split stages per k-step (none when the input arrives pre-split)
     // slot plan: LDS reads first (RPS per slot; the raw A rows lead), split stages from slot LEAD on (PER per slot),
     // DMA pieces spread over the step (DPS per hosting slot)
     constexpr int NR = NRA + NRB;
@@ -377,7 +387,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                 const int r = m * RPS + u;
                 if ((PPY_X3_ABL >= 5 && PPY_X3_ABL != 6) || r >= NR) {
                 } else if (r < NRA) {
-                    raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                    if constexpr (GP)       // (tile r>>1, term r&1): the finished operand
+                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                    else
+                        raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
                 } else {
                     const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
                     nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
@@ -467,12 +480,21 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mrow = min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1);
+                if constexpr (GP) {        // the scale its producer chose for this image
+                    sa[i] = p.xscale[mrow / hw];
+                    inv_sa[i] = pow2_inverse(sa[i]);
+                    // (a link in a CHAIN of pre-split tensors bounds its own output from the input's TRACKED maximum, not from the
+                    // input's bound: static bounds multiplied along a chain lose 2^6 per link and underflow the fp16 range)
+                    if (p.yscale) xmax_up[i] = pow2_above(amax_read(p.amax_in, mrow / hw));
+                    continue;
+                }
                 const float mx = amax_read(p.amax_in, mrow / hw);
                 const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
                 int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
                 f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite
                 sa[i] = __uint_as_float((unsigned)f << 23);
                 inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
+                xmax_up[i] = 16384.0f * inv_sa[i];             // max|x| < 2^14 / sa
                 if constexpr (SLAB) {          // taps of this fragment row that lie inside the image
                     const int mr = m0 + wm * WM + i * 32 + (lane & 31);
                     const int n = mrow / hw, rem = mrow - n * hw;
@@ -501,6 +523,11 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
             const char *b_ptr = smem + STAGE_BASE + A_BYTES + wn * WN * 64;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if constexpr (GP) {
+                    f0.a[i][0] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
+                    f0.a[i][1] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+                    continue;
+                }
                 const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
                 const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
                 if constexpr (F16) {
@@ -559,7 +586,27 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     // sits in lane r.  Vector epilogue: applied after the transposition to the 4 rows per tile a lane finishes;
     // scalar epilogue (K % 4 != 0, rare): applied to the accumulators, element e = row (e&3) + 8(e>>2) + 4(lane>>5).
     if constexpr (BNS) tile_bn_stats<TM, TN, WM, WN>(p, acc, inv_sa, m0, n0, wm, wn, lane, tile_m * (BM / WM) + wm);
-    float rowscale[TM][4];
+    float rowscale[TM][4], rowsplit[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rowsplit[i][t] = 0.f;
+    bool split_out = false;
+    if constexpr (F16 && VEC && !SPLIT) {
+        // this launch's output goes to ONE consumer as finished operands (ConvArgs::yscale): per-image scale from the static bound
+        // |y| <= ysplit_mul * max|x| + ysplit_add, with max|x| < 2^14 / sa (the tracked maximum rounded up to a power of two)
+        split_out = p.yscale != nullptr;
+        if (split_out) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float ys = split_scale_of(fmaf(p.ysplit_mul, xmax_up[i], p.ysplit_add));
+                const int mr = m0 + wm * WM + i * 32 + (lane & 31);
+                if (n0 == 0 && wn == 0 && lane < 32 && mr < p.M) p.yscale[mr / hw] = ys;      // (every writer of an image writes the same value)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rowsplit[i][t] = __shfl(ys, (lane >> 3) + 8 * t);
+            }
+        }
+    }
     if constexpr (F16) {
         if constexpr (VEC) {
 #pragma unroll
@@ -578,7 +625,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
         }
     }
     tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
-                                              (F16 && VEC) ? rowscale : nullptr);
+                                              (F16 && VEC) ? rowscale : nullptr, (VEC && !SPLIT) ? rowsplit : nullptr, split_out);
     if (p.trace && tid == 0) {     // debug timeline (ppy_debug_set_trace): wall-clock span + shader-clock phases
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -611,12 +658,15 @@ constexpr X3Cfg kX3[] = {     // the same nine tiles for both schemes (LDS sizes
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
-template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false>
+template <int BM, int BN, int WM, int WN, bool F16, bool SPLIT, bool VEC, bool SLAB = false, bool BNS = false, bool GP = false>
 int launch_x3_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    if constexpr (F16 && !SPLIT && !BNS) {
+    if constexpr (F16 && !SPLIT && !BNS && !GP) {
         if (p.bn_part) return launch_x3_one<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, true>(p, splits, lds, tiles, stream);
     }
-    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, BNS>;
+    if constexpr (F16 && !SPLIT && VEC && !SLAB && !BNS && !GP) {
+        if (p.xscale) return launch_x3_one<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, false, true>(p, splits, lds, tiles, stream);
+    }
+    auto k = conv_igemm_x3_kernel<BM, BN, WM, WN, F16, SPLIT, VEC, SLAB, BNS, GP>;
     static PpyLdsAttr attr;      // (the stage count is a launch parameter: allow the whole LDS)
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(64 * (BM / WM) * (BN / WN)), lds, stream, p);
@@ -659,6 +709,11 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
         if (ceil_div(p.M, BM) * (BM / WM) > p.bn_capacity) return PPY_ERR_WORKSPACE;
         if (p.bn_slices_host) *p.bn_slices_host = ceil_div(p.M, BM) * (BM / WM);
     }
+    // pre-split tensors (ConvArgs::xscale / yscale): f16x2 tiles with one split and the vector epilogue only -- an explicit request
+    // that cannot be honoured is an error (BAD_ARG), never a silently different interpretation of the bytes
+    if ((p.xscale || p.yscale) && (!F16 || SLAB || splits > 1 || !vec || p.bn_part)) return PPY_ERR_BAD_ARG;
+    if (p.yscale && p.ups) return PPY_ERR_BAD_ARG;          // (a pre-split INPUT with an upsampled fp32 store is fine)
+    if (p.yscale && (p.K % 32 != 0 || p.y_ld % 32 != 0)) return PPY_ERR_BAD_ARG;
     int rc;
     if (splits > 1) {
         rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream)
@@ -759,7 +814,7 @@ int ppy_x3_f16_base() { return kNumX3; }
 
 int ppy_x3_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (c < kNumX3) {
-        if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0) return PPY_ERR_BAD_ARG;
+        if (!p.w3 || ((uintptr_t)p.w3 & 15) != 0 || p.xscale || p.yscale) return PPY_ERR_BAD_ARG;      // (pre-split tensors: f16x2 only)
         return dispatch_scheme<false>(p, c, s, st);
     }
     // f16x2 needs the split weights + folded scale, the tracked maximum of the input, and a CoordConv bias map

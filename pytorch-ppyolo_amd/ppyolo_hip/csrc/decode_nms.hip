@@ -15,6 +15,7 @@
 // NaN propagation of torch.max/min) is reproduced op for op, so this file is compiled without
 // fp contraction.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #pragma clang fp contract(off)
@@ -59,6 +60,50 @@ struct DecodeArgs {
     float anchors[16];
     float stride_f, sxy, sxy_bias, e_obj, e_iou, thr;
 };
+
+// One (cell, anchor): IoU-aware objectness (reference model/head.py:121-126 + _de_sigmoid :97-109), the candidate bound in the
+// logit domain, and the box (head.py:40-46, :61-77).  Shared by both decode kernels: the arithmetic is written ONCE.
+__device__ __forceinline__ void decode_pair(const DecodeArgs &p, float ioup_logit, float t0, float t1, float t2, float t3,
+                                            float obj_logit, int w, int h, int a, float im_h, float im_w, float &conf_out,
+                                            float &bound_out, floatx4 &bb_out) {
+    const float Sf = (float)p.S;
+    if (p.iou_aware) {
+        const float ioup = sigmoidf_(ioup_logit);
+        const float obj = sigmoidf_(obj_logit);
+        float nw = powf(obj, p.e_obj) * powf(ioup, p.e_iou);
+        nw = fminf(fmaxf(nw, 1e-7f), 1e7f);
+        nw = 1.0f / nw - 1.0f;
+        nw = fminf(fmaxf(nw, 1e-7f), 1e7f);
+        obj_logit = -logf(nw);
+    }
+    const float conf = sigmoidf_(obj_logit);
+    // candidate bound in the logit domain, with a safety margin (exact test follows)
+    float bound;
+    if (p.thr <= 0.0f) {
+        bound = -INFINITY;
+    } else if (!(conf > p.thr)) {
+        bound = INFINITY;                      // conf*sigmoid(.) <= conf <= thr: nothing passes
+    } else {
+        const float tq = p.thr / conf;         // in (0, 1)
+        bound = logf(tq / (1.0f - tq)) - 0.02f;
+    }
+    conf_out = conf;
+    bound_out = bound;
+    const float bx = (p.sxy * sigmoidf_(t0) + (float)w - p.sxy_bias) * p.stride_f;
+    const float by = (p.sxy * sigmoidf_(t1) + (float)h - p.sxy_bias) * p.stride_f;
+    const float bw = expf(t2) * p.anchors[2 * a], bh = expf(t3) * p.anchors[2 * a + 1];
+    float x0 = (bx - bw / 2.0f) / Sf / p.stride_f * im_w;
+    float y0 = (by - bh / 2.0f) / Sf / p.stride_f * im_h;
+    float x1 = (bx + bw / 2.0f) / Sf / p.stride_f * im_w;
+    float y1 = (by + bh / 2.0f) / Sf / p.stride_f * im_h;
+    if (p.clip) {
+        x0 = x0 < 0.0f ? x0 * 0.0f : x0;   // keeps the reference's -0.0
+        y0 = y0 < 0.0f ? y0 * 0.0f : y0;
+        x1 = x1 > im_w ? im_w : x1;
+        y1 = y1 > im_h ? im_h : y1;
+    }
+    bb_out = floatx4{x0, y0, x1, y1};
+}
 
 // 64 grid cells per 256-thread workgroup, three phases through LDS:
 //   1. the cells' channels (contiguous in NHWC) are staged with coalesced loads;
@@ -148,54 +193,19 @@ __device__ __forceinline__ void yolo_decode_body(const DecodeArgs &p, const int 
 
     // ---- phase 2: one thread per (cell, anchor) ----
     const int off0 = p.iou_aware ? p.A : 0;
-    const float Sf = (float)p.S;
     for (int q = tid; q < ncl * p.A; q += 256) {
         const int c = q / p.A, a = q - c * p.A;
         const long long cell = cell0 + c;
         const int w = (int)(cell % p.S), h = (int)((cell / p.S) % p.S), n = (int)(cell / ((long long)p.S * p.S));
         const float *v = vals + c * nch;
         const float *t = v + off0 + a * per;
-        float obj_logit = t[4];
-        if (p.iou_aware) {
-            // reference model/head.py:121-126 + _de_sigmoid :97-109
-            const float ioup = sigmoidf_(v[a]);
-            const float obj = sigmoidf_(obj_logit);
-            float nw = powf(obj, p.e_obj) * powf(ioup, p.e_iou);
-            nw = fminf(fmaxf(nw, 1e-7f), 1e7f);
-            nw = 1.0f / nw - 1.0f;
-            nw = fminf(fmaxf(nw, 1e-7f), 1e7f);
-            obj_logit = -logf(nw);
-        }
-        const float conf = sigmoidf_(obj_logit);
-        // candidate bound in the logit domain, with a safety margin (exact test follows)
-        float bound;
-        if (p.thr <= 0.0f) {
-            bound = -INFINITY;
-        } else if (!(conf > p.thr)) {
-            bound = INFINITY;                      // conf*sigmoid(.) <= conf <= thr: nothing passes
-        } else {
-            const float tq = p.thr / conf;         // in (0, 1)
-            bound = logf(tq / (1.0f - tq)) - 0.02f;
-        }
+        float conf, bound;
+        floatx4 bb;
+        decode_pair(p, p.iou_aware ? v[a] : 0.0f, t[0], t[1], t[2], t[3], t[4], w, h, a, p.im_size[n * 2 + 0], p.im_size[n * 2 + 1],
+                    conf, bound, bb);
         s_conf[q] = conf;
         s_bound[q] = bound;
-        // reference model/head.py:40-46, :61-77
-        const float im_h = p.im_size[n * 2 + 0], im_w = p.im_size[n * 2 + 1];
-        const float bx = (p.sxy * sigmoidf_(t[0]) + (float)w - p.sxy_bias) * p.stride_f;
-        const float by = (p.sxy * sigmoidf_(t[1]) + (float)h - p.sxy_bias) * p.stride_f;
-        const float bw = expf(t[2]) * p.anchors[2 * a], bh = expf(t[3]) * p.anchors[2 * a + 1];
-        float x0 = (bx - bw / 2.0f) / Sf / p.stride_f * im_w;
-        float y0 = (by - bh / 2.0f) / Sf / p.stride_f * im_h;
-        float x1 = (bx + bw / 2.0f) / Sf / p.stride_f * im_w;
-        float y1 = (by + bh / 2.0f) / Sf / p.stride_f * im_h;
-        if (p.clip) {
-            x0 = x0 < 0.0f ? x0 * 0.0f : x0;   // keeps the reference's -0.0
-            y0 = y0 < 0.0f ? y0 * 0.0f : y0;
-            x1 = x1 > im_w ? im_w : x1;
-            y1 = y1 > im_h ? im_h : y1;
-        }
         const int box = p.box_offset + (h * p.S + w) * p.A + a;
-        floatx4 bb = {x0, y0, x1, y1};
         *reinterpret_cast<floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4) = bb;
     }
     __syncthreads();
@@ -275,6 +285,185 @@ __global__ void __launch_bounds__(256) yolo_decode_multi_kernel(const DecodeMult
         ++l;
     }
     yolo_decode_body(m.lv[l], bx, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------
+// Streaming decode (round 3): the same result as yolo_decode_body, organised for HBM bandwidth instead of around workgroup
+// barriers and an LDS copy of the data.  A WAVE owns groups of 16 consecutive cells of one image and level; FOUR lanes share a
+// cell (lane = 4 * cell + r): load i of lane r is the 16-byte group 4 i + r of the cell's row, so a wave instruction reads 16
+// rows x 64 contiguous bytes, all DS_NJ loads of a group are in flight together, and the data STAYS IN REGISTERS.  Lane r < A
+// of a cell is the cell's pair lane for anchor r: it fetches the pair's 6 header values with scalar loads (same cache lines),
+// runs decode_pair, writes the box and holds conf / bound; its three neighbours get them by a quad permute (DPP, no LDS).  The
+// channel of element (i, e) of lane r is 16 i + 4 r + e -- with A, C and the IoU-aware flag as template parameters the anchor
+// and class of almost every element fold at compile time, so the sweep is one compare per class logit.  Survivors of the
+// logit-domain bound are rare: they go UNSCORED (logit, conf, index) to a wave-private LDS list; the exact fp32 score and the
+// exact `score > thr` test run when the list is flushed, and the image's candidate list is appended to with ONE global atomic
+// per flush (normally one per wave; every 768 entries in the dense regime).  No workgroup barrier anywhere.
+constexpr int DS_GC = 16;                 // cells per group (4 lanes each)
+constexpr int DS_LW = 768;                // wave-private list of unscored survivors (entries)
+constexpr int DS_WAVES = 8;               // waves per workgroup (72 KB of lists: two workgroups per CU)
+struct DecodeStream {
+    DecodeArgs lv[4];
+    int nb[4];                            // workgroups per image of each level
+    int nlevels;
+    int abl;                              // experiments (PPY_DECODE_ABL; results are garbage): 1 = no flush atomic, 2 = no pair phase, 4 = no sweep
+};
+
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {      // value of lane (lane & ~3) + Q
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xf, 0xf, false));
+}
+
+template <int A, int C, bool IOU>
+__global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(const DecodeStream m) {
+    constexpr int PER = 5 + C, OFF0 = IOU ? A : 0, NCH = A * PER + OFF0, N4ROW = (NCH + 3) / 4, NJ = (N4ROW + 3) / 4;
+    static_assert(A >= 1 && A <= 4, "one pair lane per anchor inside a quad");
+    __shared__ float l_lg[DS_WAVES][DS_LW], l_cf[DS_WAVES][DS_LW];
+    __shared__ uint32_t l_ix[DS_WAVES][DS_LW];
+    int bx = blockIdx.x, l = 0;
+    while (l + 1 < m.nlevels && bx >= m.nb[l]) {
+        bx -= m.nb[l];
+        ++l;
+    }
+    const DecodeArgs &p = m.lv[l];
+    const int nbx = m.nb[l];
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cells_img = p.S * p.S;
+    const int ngroups = (cells_img + DS_GC - 1) / DS_GC;
+    const float im_h = p.im_size[n * 2 + 0], im_w = p.im_size[n * 2 + 1];
+    uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
+    uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
+    float *wlg = l_lg[wave], *wcf = l_cf[wave];
+    uint32_t *wix = l_ix[wave];
+    int l_n = 0;                           // wave-uniform
+    const int c = lane >> 2, r = lane & 3;
+
+    // The private list: (1) exact score and test, in place (logit slot <- key, index slot <- ~0 when the entry fails) -> number of
+    // survivors (wave-uniform); (2) append them at `base` of the image's candidate list.
+    auto score_list = [&]() -> int {
+        int total = 0;
+        for (int i0 = 0; i0 < l_n; i0 += 64) {
+            const int i = i0 + lane;
+            bool ok = false;
+            if (i < l_n) {
+                const float sc = wcf[i] * sigmoidf_(wlg[i]);
+                ok = sc > p.thr;
+                wlg[i] = __uint_as_float(score_to_key(sc));
+                if (!ok) wix[i] = 0xffffffffu;
+            }
+            total += __popcll(__ballot(ok));
+        }
+        return total;
+    };
+    auto write_list = [&](int base) {
+        for (int i0 = 0; i0 < l_n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t ix = i < l_n ? wix[i] : 0xffffffffu;
+            const bool ok = ix != 0xffffffffu;
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const int g = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (g < p.cand_cap) {
+                    ckey[g] = __float_as_uint(wlg[i]);
+                    cidx[g] = ix;
+                }
+            }
+            base += __popcll(bal);
+        }
+        l_n = 0;
+    };
+    // A returning device-scope atomic on an image's ONE counter costs ~75 ns of serialised time (measured: 3790 of them, one
+    // per wave, took the launch from 19 to 53 us; tools/decode_bench.py), so the normal case reserves ONCE PER WORKGROUP, at the
+    // end; only a list that fills up mid-way (the all-pass regime) is flushed by its wave alone.
+    auto flush_now = [&]() {
+        const int total = score_list();
+        int base = 0;
+        if (lane == 0 && total > 0 && !(m.abl & 1)) base = atomicAdd(p.cand_count + n, total);
+        write_list(__shfl(base, 0));
+    };
+
+    for (int g = bx * DS_WAVES + wave; g < ngroups; g += nbx * DS_WAVES) {
+        const int cell_base = g * DS_GC;
+        const int ncl = min(DS_GC, cells_img - cell_base);
+        const bool cell_ok = c < ncl;
+        const float *row = p.head + ((long long)n * cells_img + cell_base + c) * p.head_ld;
+        floatx4 v[NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (cell_ok && 4 * i + r < N4ROW) v[i] = *reinterpret_cast<const floatx4 *>(row + 4 * (4 * i + r));
+        }
+        // pair lanes (r < A): header values, decode_pair, box store
+        float conf = 0.0f, bound = INFINITY;
+        if (cell_ok && r < A && !(m.abl & 2)) {
+            const float *t = row + OFF0 + r * PER;
+            const float iou_logit = IOU ? row[r] : 0.0f;
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+            const int cell = cell_base + c;
+            const int h = cell / p.S, w = cell - h * p.S;
+            floatx4 bb;
+            decode_pair(p, iou_logit, t0, t1, t2, t3, t4, w, h, r, im_h, im_w, conf, bound, bb);
+            const int box = p.box_offset + cell * A + r;
+            *reinterpret_cast<floatx4 *>(p.boxes + ((long long)n * p.M_total + box) * 4) = bb;
+        }
+        float bnd[4], cnf[4];
+        bnd[0] = quad_bcast<0>(bound); cnf[0] = quad_bcast<0>(conf);
+        bnd[1] = quad_bcast<1>(bound); cnf[1] = quad_bcast<1>(conf);
+        bnd[2] = quad_bcast<2>(bound); cnf[2] = quad_bcast<2>(conf);
+        bnd[3] = quad_bcast<3>(bound); cnf[3] = quad_bcast<3>(conf);
+        // class sweep: channel of element (i, e) = 16 i + 4 r + e
+        const int box0 = p.box_offset + (cell_base + c) * A;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            if (m.abl & 4) break;
+            if (l_n + 256 > DS_LW) flush_now();       // room for the 4 x 64 elements of this load (fills only in the dense regime)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = 16 * i + 4 * r + e;
+                if (16 * i + e >= NCH) continue;                              // (compile time: beyond the row for every r)
+                const int t = ch - OFF0;
+                int a = 0;
+#pragma unroll
+                for (int q = 1; q < A; ++q) a += (t >= q * PER) ? 1 : 0;
+                const int k = t - a * PER - 5;
+                const bool cls = ch < NCH && t >= 0 && k >= 0;
+                float b = bnd[0], cf = cnf[0];
+#pragma unroll
+                for (int q = 1; q < A; ++q) {
+                    b = a >= q ? bnd[q] : b;
+                    cf = a >= q ? cnf[q] : cf;
+                }
+                const float lg = v[i][e];
+                const bool pass = cls && lg > b;
+                const unsigned long long bal = __ballot(pass);
+                if (bal == 0ull) continue;                                    // (the usual case)
+                if (pass) {
+                    const int pos = l_n + __popcll(bal & ((1ull << lane) - 1ull));
+                    wlg[pos] = lg;
+                    wcf[pos] = cf;
+                    wix[pos] = (uint32_t)((box0 + a) * C + k);
+                }
+                l_n += __popcll(bal);
+            }
+        }
+    }
+    {   // one reservation for the whole workgroup
+        __shared__ int w_tot[DS_WAVES], wg_base;
+        const int total = score_list();
+        if (lane == 0) w_tot[wave] = total;
+        __syncthreads();
+        if (tid == 0) {
+            int sum = 0;
+#pragma unroll
+            for (int w = 0; w < DS_WAVES; ++w) sum += w_tot[w];
+            wg_base = (sum > 0 && !(m.abl & 1)) ? atomicAdd(p.cand_count + n, sum) : 0;
+        }
+        __syncthreads();
+        int base = wg_base;
+        for (int w = 0; w < wave; ++w) base += w_tot[w];
+        write_list(base);
+    }
 }
 
 // Candidate extraction from dense scores [N][M][C] (reference model/matrix_nms.py:110-117).
@@ -375,7 +564,7 @@ struct NmsArgs {
 //   D  nms_finish_kernel  (1 workgroup / image)   rescore, post-threshold, second sort, keep_top_k
 // Kernel boundaries are the synchronisation (no spin-waits, no cross-XCD coherence games); arithmetic and
 // order of every value are unchanged, so the results stay bit-identical.
-constexpr int NMS_G = 8;
+constexpr int NMS_G = 32;     // (round 3: 8 -> 32 workgroups per image: one column per wave at nms_top_k = 500; the two pairwise kernels 8.6 + 12.5 -> us)
 struct NmsWs {                 // one per image
     float box[KMAX][4];
     float score[KMAX], comp[KMAX], decay[KMAX];
@@ -713,6 +902,40 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
         lds = one > lds ? one : lds;
         m.nb[l] = (S[l] * S[l] + DEC_CELLS - 1) / DEC_CELLS;
         blocks += (unsigned)m.nb[l];
+    }
+    // the streaming kernel: compiled for the two head layouts of the configurations (3 anchors, 80 classes, with / without the
+    // IoU-aware channels); rows 16-byte aligned with a pixel stride that is a multiple of 4 floats (what the plan produces:
+    // 258 channels in rows of 260); anything else takes the staged kernel
+    bool stream_ok = getenv("PPY_DECODE_STAGED") == nullptr && A == 3 && num_classes == 80;
+    for (int l = 0; l < nlevels && stream_ok; ++l)
+        stream_ok = (head_ld[l] & 3) == 0 && head_ld[l] >= (A * (5 + num_classes) + (iou_aware ? A : 0) + 3) / 4 * 4 &&
+                    (((uintptr_t)head_out[l]) & 15) == 0;      // (whole 16-byte groups of a row are read, pad channels included)
+    if (stream_ok) {
+        DecodeStream ds;
+        ds.nlevels = nlevels;
+        long long groups_total = 0;
+        for (int l = 0; l < nlevels; ++l) groups_total += (S[l] * S[l] + DS_GC - 1) / DS_GC;
+        // ONE group per wave while the whole launch fits on the chip at once (R50vd-608, 8 images: 3790 groups = 948 workgroups on
+        // 1024 slots of 4 waves): a wave is a latency chain load -> decode_pair -> sweep -> flush of ~8 us, and waves that take
+        // several groups in turn run those chains back to back (36 us measured with ~2 groups per wave, ~2048 waves)
+        const long long wave_slots = 256LL * 16;                  // waves resident at once (two workgroups of eight per CU)
+        long long per_wave = (groups_total * N + wave_slots - 1) / wave_slots;       // groups a wave takes in turn
+        if (const char *e = getenv("PPY_DECODE_PER_WAVE")) per_wave = atoi(e) > 0 ? atoi(e) : per_wave;      // (experiments)
+        ds.abl = getenv("PPY_DECODE_ABL") ? atoi(getenv("PPY_DECODE_ABL")) : 0;
+        unsigned nblocks = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            const long long gl = (S[l] * S[l] + DS_GC - 1) / DS_GC;
+            long long nb = (gl + DS_WAVES * per_wave - 1) / (DS_WAVES * per_wave);
+            if (nb < 1) nb = 1;
+            ds.lv[l] = m.lv[l];
+            ds.nb[l] = (int)nb;
+            nblocks += (unsigned)nb;
+        }
+        if (iou_aware)
+            hipLaunchKernelGGL((yolo_decode_stream_kernel<3, 80, true>), dim3(nblocks, N), dim3(64 * DS_WAVES), 0, (hipStream_t)stream, ds);
+        else
+            hipLaunchKernelGGL((yolo_decode_stream_kernel<3, 80, false>), dim3(nblocks, N), dim3(64 * DS_WAVES), 0, (hipStream_t)stream, ds);
+        return ppy_launch_status();
     }
     static PpyLdsAttr attr;
     if (decode_attr(attr, yolo_decode_multi_kernel) != PPY_OK) return PPY_ERR_LAUNCH;

@@ -118,59 +118,57 @@ __global__ void __launch_bounds__(256) avgpool2x2_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// SPP: max-pool 5 / 9 / 13 (stride 1, "same").  pool9 = pool5(pool5), pool13 = pool5(pool9)
-// (max is associative and the -inf border makes the cascade exact), each pool5 separable.
-// One workgroup = one image x CC channels; the H*W*CC tile and one temp live in LDS.
-constexpr int SPP_CC = 8;
+// SPP: max-pool 5 / 9 / 13 (stride 1, "same"; reference model/custom_layers.py:275-290).  pool9 = pool5(pool5), pool13 =
+// pool5(pool9) (max is associative and the -inf border makes the cascade exact), each pool5 separable.
+// One workgroup = one image x SPP_CC channels; the H*W*SPP_CC tile and one temp live in LDS.  Round 3: a thread owns UNITS of
+// (pixel, 4 channels) -- 16-byte global and LDS accesses, the pixel coordinates of a unit computed once -- and a workgroup takes
+// 16 channels (64 contiguous bytes per pixel): 46 -> us on the 19x19x512 map of the R50vd head (it was 4-byte accesses of
+// 32-byte pixel segments with two integer divisions per element and pass).
+constexpr int SPP_THREADS = 512;
 
-__device__ __forceinline__ void spp_pool5(const float *src, float *tmp, float *dst, int H, int W,
-                                          int tid, int nthr) {
-    const int total = H * W * SPP_CC;
-    for (int i = tid; i < total; i += nthr) {   // horizontal
-        const int c = i % SPP_CC, w = (i / SPP_CC) % W, h = i / (SPP_CC * W);
-        float m = -INFINITY;
-        for (int d = -2; d <= 2; ++d) {
-            const int ww = w + d;
-            if ((unsigned)ww < (unsigned)W) m = fmaxf(m, src[(h * W + ww) * SPP_CC + c]);
-        }
-        tmp[i] = m;
-    }
-    __syncthreads();
-    for (int i = tid; i < total; i += nthr) {   // vertical
-        const int c = i % SPP_CC, w = (i / SPP_CC) % W, h = i / (SPP_CC * W);
-        float m = -INFINITY;
-        for (int d = -2; d <= 2; ++d) {
-            const int hh = h + d;
-            if ((unsigned)hh < (unsigned)H) m = fmaxf(m, tmp[(hh * W + w) * SPP_CC + c]);
-        }
-        dst[i] = m;
-    }
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(256) spp_kernel(const float *__restrict__ x, int x_ld, float *y5,
-                                                  float *y9, float *y13, int y_ld, int H, int W,
-                                                  int C) {
+template <int CC>      // channels per workgroup: 16 (maps up to 29x29 in 160 KB of LDS), 8 beyond
+__global__ void __launch_bounds__(SPP_THREADS) spp_kernel(const float *__restrict__ x, int x_ld, float *y5,
+                                                          float *y9, float *y13, int y_ld, int H, int W,
+                                                          int C) {
+    constexpr int G = CC / 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int total = H * W * SPP_CC;
-    float *t0 = sm, *t1 = sm + total, *t2 = sm + 2 * total;
-    const int n = blockIdx.y, c0 = blockIdx.x * SPP_CC;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int units = H * W * G;
+    floatx4 *t0 = reinterpret_cast<floatx4 *>(sm), *t1 = t0 + units, *t2 = t1 + units;
+    const int n = blockIdx.y, c0 = blockIdx.x * CC;
+    const int tid = threadIdx.x;
     const long long img = (long long)n * H * W;
-    for (int i = tid; i < total; i += nthr) {
-        const int c = i % SPP_CC, pix = i / SPP_CC;
-        t0[i] = x[(img + pix) * x_ld + c0 + c];
-    }
+    const floatx4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int u = tid; u < units; u += SPP_THREADS)
+        t0[u] = *reinterpret_cast<const floatx4 *>(x + (img + u / G) * x_ld + c0 + (u % G) * 4);
     __syncthreads();
     float *outs[3] = {y5, y9, y13};
-    float *src = t0, *dst = t2;
+    floatx4 *src = t0, *dst = t2;
     for (int lvl = 0; lvl < 3; ++lvl) {
-        spp_pool5(src, t1, dst, H, W, tid, nthr);
-        for (int i = tid; i < total; i += nthr) {
-            const int c = i % SPP_CC, pix = i / SPP_CC;
-            outs[lvl][(img + pix) * y_ld + c0 + c] = dst[i];
+        for (int u = tid; u < units; u += SPP_THREADS) {          // horizontal
+            const int pix = u / G, w = pix % W;
+            floatx4 m = ninf;
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const floatx4 v = (unsigned)(w + d) < (unsigned)W ? src[u + d * G] : ninf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+            t1[u] = m;
         }
-        float *t = src;
+        __syncthreads();
+        for (int u = tid; u < units; u += SPP_THREADS) {          // vertical, and out
+            const int pix = u / G, h = pix / W;
+            floatx4 m = ninf;
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const floatx4 v = (unsigned)(h + d) < (unsigned)H ? t1[u + d * W * G] : ninf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+            dst[u] = m;
+            *reinterpret_cast<floatx4 *>(outs[lvl] + (img + pix) * y_ld + c0 + (u % G) * 4) = m;
+        }
+        floatx4 *t = src;
         src = dst;
         dst = t;
         __syncthreads();
@@ -228,16 +226,19 @@ extern "C" int ppy_avgpool2x2_f32(const float *x, int x_ld, float *y, int y_ld, 
 extern "C" int ppy_spp_f32(const float *x, int x_ld, float *y5, float *y9, float *y13, int y_ld, int N, int H,
                            int W, int C, void *stream) {
     ppy_drop_stale_error();
-    PPY_CHECK_ARG(x && y5 && y9 && y13 && N > 0 && H > 0 && W > 0 && C > 0 && C % SPP_CC == 0);
-    PPY_CHECK_ARG(x_ld >= C && y_ld >= C);
-    const size_t lds = (size_t)3 * H * W * SPP_CC * sizeof(float);
+    PPY_CHECK_ARG(x && y5 && y9 && y13 && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    PPY_CHECK_ARG(x_ld >= C && y_ld >= C && x_ld % 4 == 0 && y_ld % 4 == 0);
+    PPY_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y5 & 15) == 0 && ((uintptr_t)y9 & 15) == 0 && ((uintptr_t)y13 & 15) == 0);
+    const int cc = (C % 16 == 0 && (size_t)3 * H * W * 16 * sizeof(float) <= 160 * 1024) ? 16 : 8;
+    const size_t lds = (size_t)3 * H * W * cc * sizeof(float);
     if (lds > 160 * 1024) return PPY_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(spp_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return PPY_ERR_LAUNCH;
+    static PpyLdsAttr attr16, attr8;
+    if (cc == 16) {
+        if (ppy_lds_attr(attr16, reinterpret_cast<const void *>(spp_kernel<16>), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
+        hipLaunchKernelGGL(spp_kernel<16>, dim3(C / 16, N), dim3(SPP_THREADS), lds, (hipStream_t)stream, x, x_ld, y5, y9, y13, y_ld, H, W, C);
+    } else {
+        if (ppy_lds_attr(attr8, reinterpret_cast<const void *>(spp_kernel<8>), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
+        hipLaunchKernelGGL(spp_kernel<8>, dim3(C / 8, N), dim3(SPP_THREADS), lds, (hipStream_t)stream, x, x_ld, y5, y9, y13, y_ld, H, W, C);
     }
-    hipLaunchKernelGGL(spp_kernel, dim3(C / SPP_CC, N), dim3(256), lds, (hipStream_t)stream, x, x_ld, y5, y9,
-                       y13, y_ld, H, W, C);
     return ppy_launch_status();
 }

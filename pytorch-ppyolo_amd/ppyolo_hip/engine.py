@@ -65,7 +65,7 @@ def math_mode():
     return m
 
 
-def tune_key(op):
+def tune_key(op, with_g=True):
     """Shape key of a conv / DCN launch in the measured (tile config, split-K) table.  Launches that can use the
     f16x2 kernels (split fp16 weights at hand, tracked input maximum) carry ':f' -- the same shape without them
     (CoordConv layers, stem side) needs its own entry."""
@@ -74,8 +74,11 @@ def tune_key(op):
     f16 = op.get('wf16') is not None and op.get('amax_in_id') is not None
     # ('dcnf': ids of the fused DCNv2 kernel, ops.dcnv2_num_configs -- not the convolution's numbering)
     # ':p': the layer also owns the 2x2 average of its output (HipExecutor._link_pools)
-    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s%s' % ('dcnf' if op['op'] == 'dcn' else op['op'], x.N, x.H, x.W, C, Kout, R,
-                                                   op['stride'], ':f' if f16 else '', ':p' if op.get('pool') is not None else '')
+    # ':g': the layer's input can arrive pre-split from its one producer (HipExecutor._mark_split_candidates): its main loop has
+    # no split work, another tile may win -- such entries are measured in that form; without one the plain entry is used
+    return '%s:N%d:H%d:W%d:C%d:K%d:R%d:s%d%s%s%s' % ('dcnf' if op['op'] == 'dcn' else op['op'], x.N, x.H, x.W, C, Kout, R,
+                                                     op['stride'], ':f' if f16 else '', ':p' if op.get('pool') is not None else '',
+                                                     ':g' if (op.get('gp_in') and with_g) else '')
 
 
 def tuned_table(mode=None):
@@ -353,11 +356,12 @@ class HipExecutor(object):
         self._link_pools()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
+        self._mark_split_candidates()
         for op in p.ops:
             if op['op'] in ('conv', 'dcn') and op['cfg'] < 0:
-                ent = tab.get(tune_key(op)) or tab_x3.get(tune_key(op))      # (a layer without ':f' behaves as in bf16x3 mode)
+                ent = tab.get(tune_key(op)) or tab.get(tune_key(op, False)) or tab_x3.get(tune_key(op, False))      # (a layer without ':f' behaves as in bf16x3 mode)
                 if not ent and op.get('pool') is not None:                   # no entry for the pooled form: the plain shape's
-                    k0 = tune_key(dict(op, pool=None))
+                    k0 = tune_key(dict(op, pool=None), False)
                     ent = tab.get(k0) or tab_x3.get(k0)
                 if ent:
                     op['cfg'], op['splitk'] = ent[:2]
@@ -381,6 +385,7 @@ class HipExecutor(object):
                 if op.get('wf16') is not None and op.get('posb') is not None:
                     s_w = torch.where(op['scale'] != 0, op['scale'] / op['wf16'][1], torch.ones_like(op['scale']))
                     op['posb_f16'] = (self.bufs[op['posb'].buf] * s_w).contiguous()
+            self._link_splits()
 
     def _assign_amax(self):
         """Tracked per-image tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its
@@ -416,6 +421,93 @@ class HipExecutor(object):
             return
         link_pools(self.plan.ops, self._op_io, lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None,
                    self._want_streams)
+
+    def _split_capable(self, cfg, consumer):
+        """Tile configurations that read (consumer) / write pre-split tensors: the f16x2 tiles of csrc/conv_x3.hip without slab
+        reuse and the specialised-wave tiles of csrc/conv_ws.hip (as consumers: those whose producer waves do not split)."""
+        f0 = NUM_FP32_CFGS + NUM_X3_CFGS
+        if f0 <= cfg < f0 + 27 or f0 + 45 <= cfg < f0 + 54:          # 9 tiles x {2, 3, 4} stages; the 96 / 192-row tiles
+            return True
+        w0 = K.ws_first_cfg()
+        return cfg - w0 in ((0, 1, 2, 3, 7, 8) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8))
+
+    def _split_pairs(self):
+        """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (see _link_splits), whatever
+        tiles they run on: a buffer written by ONE convolution (whole buffer, no shortcut term, no upsampled store, no pooled
+        twin) and read ONLY by convolutions, as their input -- a bottleneck's conv1 -> conv2, the head's 1x1 -> 3x3 -> 1x1
+        chains, and a route with its two readers (the tip 3x3 and the 1x1 in front of the upsampling)."""
+        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_PRESPLIT', '1') != '1':
+            return []
+        ops = self.plan.ops
+        readers, writers = {}, {}
+        for op in ops:
+            ins, outs = self._op_io(op)
+            for b in ins:
+                readers.setdefault(b, []).append(op)
+            for b in outs:
+                writers.setdefault(b, []).append(op)
+        pinned = {a.buf for a in list(self.plan.head_outs) + list(self.plan.feats)}      # read from outside the conv chain
+        only3 = os.environ.get('PPYOLO_HIP_PRESPLIT_3X3_ONLY', '0') == '1'      # (A/B switch: 1x1 consumers gain less -- they split
+        # every activation once per wave column, a 3x3 nine times -- but they gain: R50vd-608 bs 8 +0.9 % on top of the 3x3 links)
+        pairs = []
+        for b, ws_ in writers.items():
+            if len(ws_) != 1 or b in pinned:
+                continue
+            pr = ws_[0]
+            ld = self.plan.buffers[b][3]
+            y = pr.get('y')
+            if pr['op'] != 'conv' or pr.get('wf16') is None or pr.get('amax_in_id') is None or pr['ups'] or pr['res'] is not None \
+                    or pr.get('pool') is not None or y.buf != b or y.coff != 0 or y.C != ld or ld % 32:
+                continue
+            cons = readers.get(b, [])
+            ok = bool(cons)
+            for c in cons:
+                x = c.get('x')
+                if c['op'] != 'conv' or c.get('wf16') is None or c.get('amax_in_id') is None or x is None or x.buf != b or x.coff != 0 \
+                        or x.C != ld or (c['res'] is not None and c['res'].buf == b) or (only3 and c['w'].shape[1] != 3):
+                    ok = False
+            if ok and len(set(id(c) for c in cons)) == len(cons):
+                pairs.append((pr, cons))
+        return pairs
+
+    def _mark_split_candidates(self):
+        for op in self.plan.ops:
+            op.pop('gp_in', None)
+        for _, cons in self._split_pairs():
+            for c in cons:
+                c['gp_in'] = True
+
+    def _unlink_splits(self):
+        for op in self.plan.ops:
+            op.pop('x_split', None)
+            op.pop('y_split', None)
+
+    def _link_splits(self):
+        """"Global pre-split" (DESIGN.md 4.1g): where a convolution's output buffer is read by exactly ONE op, a convolution on
+        an f16x2 tile kernel, the producer stores it as that consumer's finished MFMA operands (two fp16 terms of y * s_image,
+        same bytes per pixel) and the consumer's main loop carries no scale / split work.  s_image comes from a static bound
+        of |y| -- per output channel |scale| * sum|w| times the input's tracked maximum, plus |shift| and the CoordConv bias --
+        so the producer needs no second pass.  Bottleneck conv1 -> conv2 (3x3) and the head's 1x1 -> 3x3 pairs qualify."""
+        self._unlink_splits()
+        n = 0
+        for pr, cons in self._split_pairs():
+            if pr.get('splitk', 0) > 1 or not self._split_capable(pr['cfg'], False) \
+                    or any(c.get('splitk', 0) > 1 or not self._split_capable(c['cfg'], True) for c in cons):
+                continue          # (every reader must take the tensor in that form, or none does)
+            w, sc, sh = pr['w'], pr['scale'], pr['shift']
+            l1 = w.abs().double().sum(dim=(1, 2, 3))
+            mul = float((sc.abs().double() * l1).max())
+            add = sh.abs().double()
+            if pr['posb'] is not None:
+                pb = self.bufs[pr['posb'].buf].abs().double().reshape(-1, w.shape[0]).amax(dim=0)
+                add = add + pb * sc.abs().double()
+            add = float(add.max())
+            ps = torch.ones(self.plan.N, dtype=torch.float32, device=self.device)
+            pr['y_split'] = (ps, mul * (1.0 + 2.0 ** -8), add * (1.0 + 2.0 ** -8) + 1e-30)
+            for c in cons:
+                c['x_split'] = ps
+                n += 1
+        return n
 
     def _amax(self, idx):
         return None if idx is None else self.amax[idx * self._amax_block:(idx + 1) * self._amax_block]
@@ -514,7 +606,7 @@ class HipExecutor(object):
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
                             ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
-                            self._amax(op.get('amax_out_id')), op.get('posb_f16'))
+                            self._amax(op.get('amax_out_id')), op.get('posb_f16'), op.get('x_split'), op.get('y_split'))
             if op.get('pool') is not None:
                 K.avgpool2x2(self.view(op['y']), self.view(op['pool']))
         elif t == 'stem':
@@ -615,6 +707,7 @@ class HipExecutor(object):
         ncfg_dcn = K.dcnv2_num_configs() // 3 * {'fp32': 1, 'bf16x3': 2}.get(self.math, 3)      # schemes up to this mode's
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
+        self._unlink_splits()          # (layers are measured on plain fp32 tensors; the links are re-derived from the new choices)
         with torch.cuda.device(self.device):
             big = 0
             for op in self.plan.ops:
@@ -633,8 +726,15 @@ class HipExecutor(object):
                 chunks = Kred // 32
                 base_cfg, base_split = op['cfg'], op['splitk']
 
+                gp_scales = torch.ones(self.plan.N, dtype=torch.float32, device=self.device) if op.get('gp_in') else None
+
                 def measure(c, s, n):
                     op['cfg'], op['splitk'] = c, s
+                    # a layer whose input will arrive pre-split is measured in that form on the tiles that can read it (the
+                    # bytes it reads are whatever the buffer holds: the timing does not depend on the values)
+                    op.pop('x_split', None)
+                    if gp_scales is not None and s <= 1 and self._split_capable(c, True):
+                        op['x_split'] = gp_scales
                     try:
                         self._run_op(op)
                     except PPYoloHipError:
@@ -682,6 +782,7 @@ class HipExecutor(object):
                     if best is None or again < best[0]:
                         best = (again, c, s)
                 op['_front'] = sorted(front)           # kept for co_tune()
+                op.pop('x_split', None)
                 if best is None:
                     op['cfg'], op['splitk'] = base_cfg, base_split
                     continue
@@ -692,6 +793,7 @@ class HipExecutor(object):
                     print('autotune %s w=%s H=%d -> cfg %d split %d  %.3f ms' % (op['op'], tuple(op['w'].shape),
                                                                                op['x'].H, best[1], best[2], best[0]))
         self._size_workspace()
+        self._link_splits()
         self.graph = None
         return report
 
@@ -702,6 +804,7 @@ class HipExecutor(object):
         The fastest kernel alone is not always the best neighbour: a tile shape that leaves CUs, LDS or power to the
         other lane can finish the pair sooner.  Measured, R50-608 bs8, two lanes: +0.6 %."""
         import time
+        self._unlink_splits()
         with torch.cuda.device(self.device):
             sa, sb = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
             with torch.cuda.stream(sb):
@@ -753,6 +856,7 @@ class HipExecutor(object):
                     print('co_tune %s: %s -> cfg %d split %d' % (tune_key(op), ['%d/%d %.3f' % (c, s, 1e3 * b)
                                                                               for b, c, s, _ in scored], win[1], win[2]))
         self._size_workspace()
+        self._link_splits()
         self.graph = None
         return changed
 

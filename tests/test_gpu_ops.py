@@ -348,6 +348,137 @@ def test_decode_golden(golden):
             assert got == want
 
 
+def _decode_levels(outs, anchors_px, strides, iou_aware, im_size, thr, staged):
+    """All levels through ppy_yolo_decode_levels_f32 on padded NHWC rows (pixel stride = channels rounded up to 4, as the plan
+    lays the head outputs out); staged=True forces the round-1/2 LDS-staged kernel.  -> boxes, per image sorted (idx, key)."""
+    import os
+    from ppyolo_hip import ops
+    N = outs[0].shape[0]
+    views, M = [], 0
+    for o in outs:
+        nch = o.shape[1]
+        ld = (nch + 3) // 4 * 4
+        buf = torch.full((N, o.shape[2], o.shape[3], ld), 123.0).cuda()         # (the pad channels must never be read as classes)
+        buf[..., :nch] = nhwc(o).cuda()
+        views.append(ops.View(buf, 0, nch))
+        M += o.shape[2] * o.shape[3] * 3
+    boxes = torch.zeros(N, M, 4).cuda()
+    ck, ci, cc = _cand_bufs(N, M * 80)
+    if staged:
+        os.environ['PPY_DECODE_STAGED'] = '1'
+    try:
+        ops.yolo_decode_levels(views, anchors_px, strides, 80, 1.05, iou_aware, 0.4, True, im_size.cuda(), boxes, thr, ck, ci, cc)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('PPY_DECODE_STAGED', None)
+    cands = []
+    for n in range(N):
+        k = int(cc[n])
+        pairs = torch.stack([ci[n, :k].long(), ck[n, :k].long() & 0xffffffff], 1).cpu()
+        cands.append(pairs[torch.argsort(pairs[:, 0])])
+    return boxes.cpu(), cands
+
+
+@pytest.mark.parametrize('iou_aware', [True, False])
+def test_streaming_decode_is_bit_identical_to_the_staged_kernel(iou_aware, golden):
+    """The round-3 streaming decode kernel (registers + quad permutes, no LDS copy, no workgroup barrier) against the staged
+    kernel on the same inputs: boxes bit for bit, candidate SETS (index, score key) equal -- three levels incl. one whose cell
+    count is not a multiple of the 16-cell groups, realistic and all-pass score regimes, batch 8; and against the reference's
+    own yolo_box outputs (golden g4) through the padded-row layout."""
+    g = torch.Generator().manual_seed(5)
+    N, nch = 8, 3 * 85 + (3 if iou_aware else 0)
+    anchors = [[[116, 90], [156, 198], [373, 326]], [[30, 61], [62, 45], [59, 119]], [[10, 13], [16, 30], [33, 23]]]
+    strides = [32, 16, 8]
+    im_size = torch.tensor([[480., 640.], [375., 500.], [608., 608.], [1080., 1920.]] * 2)
+    for regime, bias in (('realistic', -4.0), ('every pair passes', 0.0)):
+        outs = []
+        for S in (19, 38, 76):
+            o = torch.randn(N, nch, S, S, generator=g) * 1.5
+            o[:, (3 if iou_aware else 0):] += bias * 0.5                       # objectness / class logits
+            o[0, :, 0, 0] = float('nan')                                       # a NaN cell: never a candidate
+            o[1, :, S - 1, S - 1] = 80.0                                       # saturated logits
+            outs.append(o)
+        b_new, c_new = _decode_levels(outs, anchors, strides, iou_aware, im_size, 0.01, False)
+        b_old, c_old = _decode_levels(outs, anchors, strides, iou_aware, im_size, 0.01, True)
+        assert np.array_equal(b_new.numpy().view(np.int32), b_old.numpy().view(np.int32)), regime
+        tot = 0
+        for n in range(N):
+            assert torch.equal(c_new[n], c_old[n]), (regime, n, c_new[n].shape, c_old[n].shape)
+            tot += c_new[n].shape[0]
+        assert tot > 0
+        if regime != 'realistic':
+            assert tot > 0.5 * N * 22743 * 80
+    if iou_aware:          # the reference's own numbers (g4: one image set per level, all IoU-aware)
+        gd = golden('g4_decode')
+        for i in range(3):
+            meta = [int(v) for v in gd['l%d_meta' % i]]
+            if not meta[2]:
+                continue
+            S, stride, mask = meta[0], meta[1], meta[3:]
+            o = T(gd['l%d_out' % i])
+            b, c = _decode_levels([o], [gd['anchors'][mask].tolist()], [stride], True, T(gd['im_size']), 0.01, False)
+            rb, rs = T(gd['l%d_boxes' % i]), T(gd['l%d_scores' % i])
+            assert ((b - rb).abs() <= 1e-5 * rb.abs().clamp(min=1.0)).all()
+            assert np.array_equal(np.signbit(b.numpy()), np.signbit(rb.numpy()))
+            for n in range(o.shape[0]):
+                want = torch.nonzero(rs[n].flatten() > 0.01).flatten()
+                got = c[n][:, 0]
+                # (scores within 1e-6 of the threshold may fall on either side of it)
+                edge = set(torch.nonzero((rs[n].flatten() - 0.01).abs() < 1e-6).flatten().tolist())
+                assert set(got.tolist()) ^ set(want.tolist()) <= edge
+
+
+def test_worst_case_regime_full_batch():
+    """SURVEY 8(d)'s second regime at the headline batch: 8 images, head logits as a default-initialised head gives them (N(0, 0.1)),
+    so EVERY one of the 1 819 440 (box, class) pairs of an image passes the 0.01 threshold -- the case in which the reference sorts
+    1.8 M keys per image (model/matrix_nms.py:120).  The streaming multi-level decode + radix-select Matrix-NMS must give exactly
+    what the dense route gives on the same scores (staged per-level decode -> dense [N, M, 80] scores -> ppy_nms_candidates_f32 ->
+    Matrix-NMS): same candidate count, same rows, same keep indices; rows sorted, at most keep_top_k."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(3)
+    N, nch = 8, 258
+    anchors = [[[116, 90], [156, 198], [373, 326]], [[30, 61], [62, 45], [59, 119]], [[10, 13], [16, 30], [33, 23]]]
+    strides, sizes = [32, 16, 8], [19, 38, 76]
+    im_size = torch.tensor([[480., 640.], [375., 500.], [608., 608.], [1080., 1920.]] * 2).cuda()
+    M = sum(S * S * 3 for S in sizes)
+    views, dense_views = [], []
+    for S in sizes:
+        buf = torch.zeros(N, S, S, 260).cuda()
+        buf[..., :nch] = (torch.randn(N, S, S, nch, generator=g) * 0.1).cuda()
+        views.append(ops.View(buf, 0, nch))
+    boxes = torch.zeros(N, M, 4).cuda()
+    ck, ci, cc = _cand_bufs(N, M * 80)
+    ops.yolo_decode_levels(views, anchors, strides, 80, 1.05, True, 0.4, True, im_size, boxes, 0.01, ck, ci, cc)
+
+    def nms(ck_, ci_, cc_, bx):
+        dets = torch.zeros(N, 100, 6).cuda()
+        cnt = torch.zeros(N, dtype=torch.int32).cuda()
+        keep = torch.zeros(N, 100, dtype=torch.int32).cuda()
+        ops.matrix_nms(bx, 80, ck_, ci_, cc_, 0.01, 500, 100, False, 2.0, dets, cnt, keep)
+        torch.cuda.synchronize()
+        return dets.cpu(), cnt.cpu(), keep.cpu()
+    d1, n1, k1 = nms(ck, ci, cc, boxes)
+    assert torch.equal(cc.cpu(), torch.full((N,), M * 80, dtype=torch.int32)), 'every pair is a candidate'
+    # the dense route on the same head outputs
+    boxes2 = torch.zeros(N, M, 4).cuda()
+    dense = torch.zeros(N, M, 80).cuda()
+    ck2, ci2, cc2 = _cand_bufs(N, M * 80)
+    off = 0
+    for v, a, st, S in zip(views, anchors, strides, sizes):
+        ops.yolo_decode(v, a, st, 80, 1.05, True, 0.4, True, im_size, boxes2, off, 0.01, ck2, ci2, cc2, dense)
+        off += S * S * 3
+    assert np.array_equal(boxes.cpu().numpy().view(np.int32), boxes2.cpu().numpy().view(np.int32))
+    ck3, ci3, cc3 = _cand_bufs(N, M * 80)
+    ops.nms_candidates(dense, 0.01, ck3, ci3, cc3)
+    d2, n2, k2 = nms(ck3, ci3, cc3, boxes2)
+    assert torch.equal(n1, n2) and torch.equal(d1, d2) and torch.equal(k1, k2)
+    for n in range(N):
+        k = int(n1[n])
+        assert 1 <= k <= 100 and torch.all(d1[n, :k - 1, 1] >= d1[n, 1:k, 1])
+        # the best pair of the image is kept first, undecayed
+        assert float(d1[n, 0, 1]) == float(dense[n].max())
+
+
 def _run_nms(boxes, scores, cfg):
     from ppyolo_hip import ops
     N, M, C = scores.shape
@@ -858,3 +989,118 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
         close(nchw(outs[0]), ref, what=what)
         for i, y in enumerate(outs[1:]):
             assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
+
+
+# ------------------------------------------------------------------------------------------
+# "global pre-split": a producer convolution stores its output as its one consumer's finished MFMA operands
+def test_presplit_pair_matches_fp64_as_well_as_the_plain_pair():
+    """1x1 (+ CoordConv bias map, LeakyReLU) -> 3x3 as in the head, and 1x1 (ReLU) -> strided 3x3 as in a bottleneck: the
+    intermediate tensor travels as two fp16 terms of y * s_image with s from a STATIC bound (ppy_conv2d_bn_act_split_f32).
+    Held to: error vs float64 no larger than 1.5 x the plain f16x2 pair's (which is fp32-grade), every tile family that
+    reads / writes such tensors, images of very different magnitude in one batch, an all-zero image."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(17)
+    f0 = 40                                  # first f16x2 tile id
+    w0 = ops.ws_first_cfg()
+    cases = [dict(C=256, Km=128, K2=256, H=19, stride=1, act='leaky', posb=True, pcfg=f0 + 4, ccfg=f0 + 2),
+             dict(C=512, Km=128, K2=128, H=24, stride=2, act='relu', posb=False, pcfg=w0 + 2, ccfg=w0 + 8),
+             dict(C=128, Km=64, K2=64, H=20, stride=1, act='relu', posb=False, pcfg=f0 + 13, ccfg=w0 + 0),
+             dict(C=64, Km=256, K2=128, H=16, stride=1, act='leaky', posb=False, pcfg=w0 + 1, ccfg=f0 + 1)]
+    for cs in cases:
+        N, C, Km, K2, H = 4, cs['C'], cs['Km'], cs['K2'], cs['H']
+        x = torch.relu(torch.randn(N, H, H, C, generator=g))
+        x[1] *= 300.0
+        x[2] *= 1e-3
+        x[3] = 0.0
+        w1 = torch.randn(Km, 1, 1, C, generator=g) * (2.0 / C) ** 0.5
+        w2 = torch.randn(K2, 3, 3, Km, generator=g) * (2.0 / (9 * Km)) ** 0.5
+        sc1, sh1 = torch.rand(Km, generator=g) + 0.5, torch.randn(Km, generator=g) * 0.1
+        sc2, sh2 = torch.rand(K2, generator=g) + 0.5, torch.randn(K2, generator=g) * 0.1
+        posb = torch.randn(1, H, H, Km, generator=g) * 0.3 if cs['posb'] else None
+        # float64 reference
+        t = torch.einsum('nhwc,kc->nhwk', x.double(), w1[:, 0, 0].double())
+        if posb is not None:
+            t = t + posb.double()
+        t = t * sc1.double() + sh1.double()
+        t = torch.where(t > 0, t, t * (0.1 if cs['act'] == 'leaky' else 0.0))
+        ref = F.conv2d(t.permute(0, 3, 1, 2), w2.permute(0, 3, 1, 2).double(), stride=cs['stride'], padding=1)
+        ref = (ref.permute(0, 2, 3, 1) * sc2.double() + sh2.double())
+        Ho = ref.shape[1]
+
+        def run(split):
+            xd = x.cuda()
+            mid = torch.zeros(N, H, H, Km).cuda()
+            out = torch.zeros(N, Ho, Ho, K2).cuda()
+            a_in, a_mid, a_out = ops.amax_slots(xd), ops.amax_slots(N=N, device='cuda'), ops.amax_slots(N=N, device='cuda')
+            w1d, w2d = w1.cuda(), w2.cuda()
+            f1, f2 = ops.split_weights_f16x2(w1d, sc1.cuda()), ops.split_weights_f16x2(w2d, sc2.cuda())
+            pbd = posb.cuda() if posb is not None else None
+            pbf = None
+            if pbd is not None:
+                s_w = sc1.cuda() / f1[1]
+                pbf = (pbd * s_w).contiguous()
+            ys = None
+            if split:
+                mul = float((sc1.abs().double() * w1.abs().double().sum(dim=(1, 2, 3))).max()) * (1 + 2.0 ** -8)
+                add = sh1.abs().double()
+                if posb is not None:
+                    add = add + posb.abs().double().reshape(-1, Km).amax(0) * sc1.abs().double()
+                ys = (torch.ones(N).cuda(), mul, float(add.max()) * (1 + 2.0 ** -8))
+            ops.conv2d_bn_act(ops.View(xd), w1d, sc1.cuda(), sh1.cuda(), ops.View(mid), 1, 0, cs['act'], None, pbd, False, cs['pcfg'], 1,
+                              None, None, f1, a_in, a_mid, pbf, None, ys)
+            ops.conv2d_bn_act(ops.View(mid), w2d, sc2.cuda(), sh2.cuda(), ops.View(out), cs['stride'], 1, None, None, None, False,
+                              cs['ccfg'], 1, None, None, f2, a_mid, a_out, None, ys[0] if split else None, None)
+            torch.cuda.synchronize()
+            return out.cpu().double(), (ys[0].cpu() if split else None), mid.cpu()
+        plain, _, mid_plain = run(False)
+        split, scales, _ = run(True)
+        for n in range(N):
+            den = ref[n].abs().max().clamp_min(1e-30)
+            e_plain = float((plain[n] - ref[n]).abs().max() / den)
+            e_split = float((split[n] - ref[n]).abs().max() / den)
+            assert e_split <= 1.5 * e_plain + 2e-7, (cs, n, e_split, e_plain)
+            if n < 3:        # the scale is a power of two that keeps the scaled maximum inside fp16, at most 2^8 below 2^14
+                mx = float(mid_plain[n].abs().max()) * float(scales[n])
+                assert 2.0 ** 5 <= mx < 2.0 ** 14, (cs, n, mx)
+                m, e = np.frexp(float(scales[n]))
+                assert m == 0.5
+    # a kernel family that cannot read such tensors refuses instead of misreading them
+    from ppyolo_hip._lib import PPYoloHipError
+    xd = torch.zeros(1, 8, 8, 64).cuda()
+    wd = torch.zeros(64, 1, 1, 64).cuda()
+    one = torch.ones(64).cuda()
+    with pytest.raises(PPYoloHipError):
+        ops.conv2d_bn_act(ops.View(xd), wd, one, one, ops.View(torch.zeros(1, 8, 8, 64).cuda()), 1, 0, None, None, None, False, 3, 1,
+                          None, None, None, None, None, None, torch.ones(1).cuda(), None)
+
+
+def test_presplit_links_in_the_plan_and_same_detections(monkeypatch):
+    """The R50vd plan links its bottleneck conv1 -> conv2 and head 1x1 -> 3x3 pairs; the detections equal those of the unlinked
+    plan to fp32 noise, and an image's result still does not depend on the rest of the batch."""
+    from conftest import build_model
+    from config import PPYOLO_2x_Config
+    from ppyolo_hip import synth
+    cfg = PPYOLO_2x_Config()
+    # (the headline shape: its layers have measured tile choices; a shape without table entries leaves the choice to the library
+    # at launch time and is not linked)
+    x, ims = synth.synth_images(8, 608).cuda(), synth.synth_im_size(8).cuda()
+    model, _ = build_model(cfg, 0, 'cuda')
+    ex = model._plans.executor(x)
+    links = [op for op in ex.plan.ops if op.get('x_split') is not None]
+    prods = [op for op in ex.plan.ops if op.get('y_split') is not None]
+    assert len(links) >= 12 and len(links) >= len(prods) >= 12          # (a route has two readers)
+    assert all(any(op['x_split'] is pr['y_split'][0] for pr in prods) for op in links)
+    assert sum(op['w'].shape[1] == 3 for op in links) >= 12
+    got = [p.cpu() for p in model(x, ims)]
+    monkeypatch.setenv('PPYOLO_HIP_PRESPLIT', '0')
+    model2, _ = build_model(cfg, 0, 'cuda')
+    assert not any(op.get('x_split') is not None for op in model2._plans.executor(x).plan.ops)
+    want = [p.cpu() for p in model2(x, ims)]
+    monkeypatch.delenv('PPYOLO_HIP_PRESPLIT')
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a[:, 0], b[:, 0])
+        assert (a[:, 1] - b[:, 1]).abs().max() <= 2e-6 and (a[:, 2:] - b[:, 2:]).abs().max() <= 2e-3
+    big = x.clone()
+    big[1] *= 50.0
+    again = [p.cpu() for p in model(big, ims)]
+    assert torch.equal(again[0], got[0])
