@@ -292,6 +292,43 @@ def link_pools(ops, op_io, has_f16, two_streams=False):
     return n
 
 
+def split_pairs(ops, op_io, buffers, pinned, has_f16, only_3x3=False):
+    """Host logic of HipExecutor._link_splits, device-free (tests/test_plan_host_logic.py): [(producer, [consumers])] between which
+    a tensor may travel PRE-SPLIT, whatever tiles they run on -- a buffer written by ONE convolution (the whole
+    buffer, no shortcut term, no upsampled store, no pooled twin, a multiple of 32 channels) and read ONLY by convolutions, as
+    their input: a bottleneck's conv1 -> conv2, the head's 1x1 -> 3x3 -> 1x1 chains, and a route with its two readers (the tip
+    3x3 and the 1x1 in front of the upsampling).  pinned: buffers that something outside the convolution chain reads (feature
+    maps, head outputs).  has_f16(op): f16x2 operands at hand.  only_3x3: A/B switch -- 1x1 consumers gain less (they split every
+    activation once per wave column, a 3x3 nine times) but they gain: R50vd-608 bs 8 +0.9 % on top of the 3x3 links."""
+    readers, writers = {}, {}
+    for op in ops:
+        ins, outs = op_io(op)
+        for b in ins:
+            readers.setdefault(b, []).append(op)
+        for b in outs:
+            writers.setdefault(b, []).append(op)
+    pairs = []
+    for b, ws_ in writers.items():
+        if len(ws_) != 1 or b in pinned:
+            continue
+        pr = ws_[0]
+        ld = buffers[b][3]
+        y = pr.get('y')
+        if pr['op'] != 'conv' or not has_f16(pr) or pr['ups'] or pr['res'] is not None or pr.get('pool') is not None \
+                or y.buf != b or y.coff != 0 or y.C != ld or ld % 32:
+            continue
+        cons = readers.get(b, [])
+        ok = bool(cons)
+        for c in cons:
+            x = c.get('x')
+            if c['op'] != 'conv' or not has_f16(c) or x is None or x.buf != b or x.coff != 0 or x.C != ld \
+                    or (c['res'] is not None and c['res'].buf == b) or (only_3x3 and c['w'].shape[1] != 3):
+                ok = False
+        if ok and len(set(id(c) for c in cons)) == len(cons):
+            pairs.append((pr, cons))
+    return pairs
+
+
 # =========================================================================================
 class HipExecutor(object):
     """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
@@ -432,43 +469,13 @@ class HipExecutor(object):
         return cfg - w0 in ((0, 1, 2, 3, 7, 8) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8))
 
     def _split_pairs(self):
-        """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (see _link_splits), whatever
-        tiles they run on: a buffer written by ONE convolution (whole buffer, no shortcut term, no upsampled store, no pooled
-        twin) and read ONLY by convolutions, as their input -- a bottleneck's conv1 -> conv2, the head's 1x1 -> 3x3 -> 1x1
-        chains, and a route with its two readers (the tip 3x3 and the 1x1 in front of the upsampling)."""
+        """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (split_pairs below)."""
         if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_PRESPLIT', '1') != '1':
             return []
-        ops = self.plan.ops
-        readers, writers = {}, {}
-        for op in ops:
-            ins, outs = self._op_io(op)
-            for b in ins:
-                readers.setdefault(b, []).append(op)
-            for b in outs:
-                writers.setdefault(b, []).append(op)
         pinned = {a.buf for a in list(self.plan.head_outs) + list(self.plan.feats)}      # read from outside the conv chain
-        only3 = os.environ.get('PPYOLO_HIP_PRESPLIT_3X3_ONLY', '0') == '1'      # (A/B switch: 1x1 consumers gain less -- they split
-        # every activation once per wave column, a 3x3 nine times -- but they gain: R50vd-608 bs 8 +0.9 % on top of the 3x3 links)
-        pairs = []
-        for b, ws_ in writers.items():
-            if len(ws_) != 1 or b in pinned:
-                continue
-            pr = ws_[0]
-            ld = self.plan.buffers[b][3]
-            y = pr.get('y')
-            if pr['op'] != 'conv' or pr.get('wf16') is None or pr.get('amax_in_id') is None or pr['ups'] or pr['res'] is not None \
-                    or pr.get('pool') is not None or y.buf != b or y.coff != 0 or y.C != ld or ld % 32:
-                continue
-            cons = readers.get(b, [])
-            ok = bool(cons)
-            for c in cons:
-                x = c.get('x')
-                if c['op'] != 'conv' or c.get('wf16') is None or c.get('amax_in_id') is None or x is None or x.buf != b or x.coff != 0 \
-                        or x.C != ld or (c['res'] is not None and c['res'].buf == b) or (only3 and c['w'].shape[1] != 3):
-                    ok = False
-            if ok and len(set(id(c) for c in cons)) == len(cons):
-                pairs.append((pr, cons))
-        return pairs
+        return split_pairs(self.plan.ops, self._op_io, self.plan.buffers, pinned,
+                           lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None,
+                           os.environ.get('PPYOLO_HIP_PRESPLIT_3X3_ONLY', '0') == '1')
 
     def _mark_split_candidates(self):
         for op in self.plan.ops:

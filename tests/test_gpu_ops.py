@@ -1104,3 +1104,58 @@ def test_presplit_links_in_the_plan_and_same_detections(monkeypatch):
     big[1] *= 50.0
     again = [p.cpu() for p in model(big, ims)]
     assert torch.equal(again[0], got[0])
+
+
+def test_presplit_chain_bounds_from_the_tracked_maximum():
+    """1x1 -> 3x3 -> 1x1 -> 3x3 with EVERY intermediate tensor pre-split (the head's runs): a link in the middle is consumer and
+    producer at once and must bound its output from its input's TRACKED maximum -- static bounds multiplied along the chain
+    lose ~2^6 per link and ran the fp16 operands into underflow (detections changed) before that was fixed.  Error vs float64
+    <= 1.5 x the plain chain's; every link's scaled maximum stays within 2^9 of the fp16 target."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(23)
+    N, H, chans, ks = 2, 19, [512, 256, 512, 256, 512], [1, 3, 1, 3]
+    f0, w0 = 40, ops.ws_first_cfg()
+    cfgs = [f0 + 4, w0 + 1, f0 + 16, w0 + 0]
+    x = torch.relu(torch.randn(N, H, H, chans[0], generator=g))
+    x[1] *= 40.0
+    ws, scs, shs = [], [], []
+    for i, k in enumerate(ks):
+        ws.append(torch.randn(chans[i + 1], k, k, chans[i], generator=g) * (2.0 / (k * k * chans[i])) ** 0.5)
+        scs.append(torch.rand(chans[i + 1], generator=g) + 0.5)
+        shs.append(torch.randn(chans[i + 1], generator=g) * 0.1)
+    t = x.double()
+    for w, sc, sh in zip(ws, scs, shs):
+        t = F.conv2d(t.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2).double(), padding=(w.shape[1] - 1) // 2).permute(0, 2, 3, 1)
+        t = t * sc.double() + sh.double()
+        t = torch.where(t > 0, t, t * 0.1)
+    ref = t
+
+    def run(split):
+        cur = x.cuda()
+        amax = ops.amax_slots(cur)
+        xs, mids, scales = None, [], []
+        for i, (w, sc, sh) in enumerate(zip(ws, scs, shs)):
+            wd, scd, shd = w.cuda(), sc.cuda(), sh.cuda()
+            fw = ops.split_weights_f16x2(wd, scd)
+            out = torch.zeros(N, H, H, w.shape[0]).cuda()
+            a_out = ops.amax_slots(N=N, device='cuda')
+            ys = None
+            if split and i + 1 < len(ws):
+                mul = float((sc.abs().double() * w.abs().double().sum(dim=(1, 2, 3))).max()) * (1 + 2.0 ** -8)
+                ys = (torch.ones(N).cuda(), mul, float(sh.abs().max()) * (1 + 2.0 ** -8))
+            ops.conv2d_bn_act(ops.View(cur), wd, scd, shd, ops.View(out), 1, (w.shape[1] - 1) // 2, 'leaky', None, None, False, cfgs[i], 1,
+                              None, None, fw, amax, a_out, None, xs, ys)
+            torch.cuda.synchronize()
+            if ys is not None:
+                scales.append((ys[0].cpu(), a_out.view(N, -1).amax(1).cpu()))
+            cur, amax, xs = out, a_out, (ys[0] if ys is not None else None)
+        return cur.cpu().double(), scales
+    plain, _ = run(False)
+    split, scales = run(True)
+    for n in range(N):
+        den = ref[n].abs().max()
+        e_p, e_s = float((plain[n] - ref[n]).abs().max() / den), float((split[n] - ref[n]).abs().max() / den)
+        assert e_s <= 1.5 * e_p + 2e-7, (n, e_s, e_p)
+    for s, mx in scales:
+        for n in range(N):
+            assert 2.0 ** 5 <= float(s[n]) * float(mx[n]) < 2.0 ** 14, (float(s[n]), float(mx[n]))

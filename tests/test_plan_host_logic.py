@@ -98,3 +98,40 @@ def test_pool_links_of_the_r50_plan():
     feats, outs, _ = CpuPlanRunner(plan).run(x)             # (the interpreter pools where the plan says; same tensors)
     for a, b in zip(feats + outs, base_feats + base_outs):
         assert torch.equal(a, b)
+
+
+def test_split_pairs_of_the_r50_plan():
+    """engine.split_pairs (device-free part of HipExecutor._link_splits): which tensors of the R50vd plan may travel pre-split.
+    Every bottleneck's conv1 -> conv2 except where the DCNv2 reads conv1's output too (stage 5) -- 13 pairs; conv2 -> conv3
+    (the 3x3's output has one reader) -- 13 more; the stem's conv2 -> conv3; the head's chains, incl. the two routes with two
+    readers and the tips feeding the output convolutions.  Never a feature map, a head output, a shortcut operand, a pooled or
+    upsampled tensor; nothing without f16x2 operands."""
+    from ppyolo_hip.engine import HipExecutor, split_pairs
+    cfg = PPYOLO_2x_Config()
+    model, _ = build_model(cfg)
+    plan = build_plan(model, 2, 160, 160, 'cpu')
+    pinned = {a.buf for a in list(plan.head_outs) + list(plan.feats)}
+    assert split_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: False) == []
+    pairs = split_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: True)
+    only3 = split_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: True, True)
+    shape = lambda o: tuple(o['w'].shape)
+    for pr, cons in pairs:
+        b = pr['y'].buf
+        assert pr['op'] == 'conv' and pr['res'] is None and not pr['ups'] and b not in pinned and plan.buffers[b][3] % 32 == 0
+        for c in cons:
+            assert c['op'] == 'conv' and c['x'].buf == b and c['x'].C == plan.buffers[b][3] and (c['res'] is None or c['res'].buf != b)
+        # nobody else touches the buffer
+        for o in plan.ops:
+            ins, outs = HipExecutor._op_io(o)
+            assert (b not in ins or any(o is c for c in cons)) and (b not in outs or o is pr)
+    cons3 = [c for _, cs in pairs for c in cs if shape(c)[1] == 3]
+    n3 = sum(1 for o in plan.ops if o['op'] == 'conv' and shape(o)[1] == 3)
+    # all 3x3 launches but the three conv_offset (their input is shared with the DCNv2 launch) and the stem's second layer (its
+    # input comes from the stem kernel, which is no 'conv' op)
+    assert n3 == 27 and len(cons3) == 23 and len(pairs) == 45
+    assert all(shape(c)[1] == 3 for _, cs in only3 for c in cs) and sum(len(cs) for _, cs in only3) <= len(cons3)
+    two = [(pr, cs) for pr, cs in pairs if len(cs) == 2]
+    assert len(two) == 2 and all(sorted(shape(c)[1] for c in cs) == [1, 3] for _, cs in two)      # the routes of levels 0 and 1
+    # chains: an op can be consumer and producer
+    prods = {id(pr) for pr, _ in pairs}
+    assert any(id(c) in prods for _, cs in pairs for c in cs)

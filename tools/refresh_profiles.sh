@@ -20,3 +20,16 @@ for spec in "r50vd_608 1" "r50vd_320 1" "r18vd_608 1" "r18vd_416 1"; do
   set -- $spec
   python bench.py --workload $1 --batch $2 --no-cpu-baseline --no-alt-math --no-host-input > $O/${TAG}_bench_$1_bs$2.json 2>/dev/null
 done
+# ---- round 3 additions ----
+python tools/decode_bench.py > $O/${TAG}_decode_bench.txt 2>/dev/null
+python tools/fullsize_parity.py > $O/${TAG}_fullsize_parity.txt 2>/dev/null
+python tools/train_fullsize_parity.py --tag $TAG --out $O/${TAG}_train_parity.txt > /dev/null 2>&1
+python bench.py --train > $O/${TAG}_bench_train_r50vd_608.json 2> $O/bench_train.err
+bash tools/prof_train.sh $TAG > $O/prof_train.log 2>&1
+cp gpurun_out/prof_train_$TAG/trace.txt $O/${TAG}_train_kernel_trace_stats.txt 2>/dev/null
+cp gpurun_out/prof_train_$TAG/${TAG}_train_pmc_traffic.json $O/ 2>/dev/null
+cp gpurun_out/prof_train_$TAG/pmc_fetch.txt $O/${TAG}_train_pmc_fetch.txt 2>/dev/null
+cp gpurun_out/prof_train_$TAG/pmc_write.txt $O/${TAG}_train_pmc_write.txt 2>/dev/null
+{ echo "# alternating A/B of the pre-split links (PPYOLO_HIP_PRESPLIT=0/1), one box: value, sustained, one batch at a time, conv TFLOP/s, frac";
+  for v in 0 1 0 1; do PPYOLO_HIP_PRESPLIT=$v python bench.py --no-cpu-baseline --no-alt-math --no-host-input 2>/dev/null | python -c "
+import json,sys;d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]);print('PPYOLO_HIP_PRESPLIT=$v',d['value'],d['sustained']['value'],d['one_batch_at_a_time']['value'],d['roofline']['achieved'],d['roofline']['frac'])"; done; } > $O/${TAG}_presplit_ab.txt
