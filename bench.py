@@ -798,7 +798,7 @@ def main():
         traffic, traffic_src = None, None
         if a.workload == 'r50vd_608' and a.batch == 8:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+            files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')) if '_train_' not in os.path.basename(f))
             if files:
                 with open(files[-1]) as fh:
                     rec = json.load(fh)
