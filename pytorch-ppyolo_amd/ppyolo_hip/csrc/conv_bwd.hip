@@ -38,6 +38,63 @@ __global__ void __launch_bounds__(256) dgrad_weights_kernel(const float *w, floa
     wt[i] = k < K ? w[(((long long)k * R + (R - 1 - r)) * S + (S - 1 - s)) * C + c] : 0.0f;
 }
 
+// The same re-layout AND the f16x2 split of w' in one launch (round 3; it was dgrad_weights_kernel + split_weights_f16_kernel,
+// 23 pairs of ~8 us launches per training step): one workgroup per row c of w' -- kred = R*S*Kp values, at most DW_MAXV per
+// thread, kept in registers between the maximum and the split.  Same arithmetic as conv_x3.hip's split_weights_f16_kernel
+// (power-of-two scale that puts max|w'[c,:]| into [2^13, 2^14), two RNE fp16 terms, chunk-major planes [plane][kred/32][C][32]):
+// bit-identical planes and scales.
+constexpr int DW_MAXV = 40;
+__global__ void __launch_bounds__(256) dgrad_weights_f16_kernel(const float *w, float *wt, float *ones, float *zeros,
+                                                                unsigned short *planes, float *scale_out, int K, int Kp, int R, int S,
+                                                                int C) {
+    __shared__ float smax[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int kred = R * S * Kp;
+    float v[DW_MAXV];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < DW_MAXV; ++j) {
+        const int i = tid + 256 * j;
+        float x = 0.f;
+        if (i < kred) {
+            const int k = i % Kp;
+            const int t = i / Kp;
+            const int s2 = t % S, r2 = t / S;
+            if (k < K) x = w[(((long long)k * R + (R - 1 - r2)) * S + (S - 1 - s2)) * C + c];
+        }
+        v[j] = x;
+        mx = fmaxf(mx, fabsf(x));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) smax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    int f = 267 - e;
+    f = f < 103 ? 103 : (f > 167 ? 167 : f);
+    const float sw = __uint_as_float((unsigned)f << 23), inv = __uint_as_float((unsigned)(254 - f) << 23);
+    const long long n = (long long)C * kred;
+#pragma unroll
+    for (int j = 0; j < DW_MAXV; ++j) {
+        const int i = tid + 256 * j;
+        if (i < kred) {
+            wt[(long long)c * kred + i] = v[j];
+            const float x = v[j] * sw;
+            const _Float16 h0 = (_Float16)x;
+            const _Float16 h1 = (_Float16)(x - (float)h0);
+            const long long o = PPY_X3_BBLOCK ? ((long long)(i >> 5) * C + c) * 32 + (i & 31) : (long long)c * kred + i;
+            planes[o] = __builtin_bit_cast(unsigned short, h0);
+            planes[n + o] = __builtin_bit_cast(unsigned short, h1);
+        }
+    }
+    if (tid == 0) {
+        scale_out[c] = inv;      // (ones[c] * inv)
+        ones[c] = 1.0f;
+        zeros[c] = 0.0f;
+    }
+}
+
 // dy [P][ld] -> padded [P][Kp] (zero channels beyond K): only when K % 32 != 0 (the 258-channel output convolutions)
 __global__ void __launch_bounds__(256) pad_channels_kernel(const float *src, int ld, float *dst, int K, int Kp, long long P) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -402,15 +459,23 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     float *scale_f16 = (float *)base;
     base += align256((size_t)C * 4);
     const long long total = (long long)C * R * S * Kp;
-    hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_krsc, wt, ones, zeros,
-                       K, Kp, R, S, C);
-    int rc = ppy_launch_status();
-    if (rc != PPY_OK) return rc;
+    int rc;
     // amax_dy (tracked per-image maxima of dy, as ppy_bn_train_bwd_f32 records them): the f16x2 kernels -- w' as two fp16 planes
     // scaled per output channel (= input channel of the layer), dy scaled per image; else the exact bf16x3 split
-    rc = amax_dy ? ppy_conv2d_split_weights_f16x2(wt, C, (long long)R * S * Kp, ones, planes, scale_f16, stream)
-                 : ppy_conv2d_split_weights_bf16x3(wt, total, planes, stream);
-    if (rc != PPY_OK) return rc;
+    if (amax_dy && R * S * Kp <= 256 * DW_MAXV) {
+        hipLaunchKernelGGL(dgrad_weights_f16_kernel, dim3(C), dim3(256), 0, st, w_krsc, wt, ones, zeros, (unsigned short *)planes,
+                           scale_f16, K, Kp, R, S, C);
+        rc = ppy_launch_status();
+        if (rc != PPY_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_krsc, wt, ones, zeros,
+                           K, Kp, R, S, C);
+        rc = ppy_launch_status();
+        if (rc != PPY_OK) return rc;
+        rc = amax_dy ? ppy_conv2d_split_weights_f16x2(wt, C, (long long)R * S * Kp, ones, planes, scale_f16, stream)
+                     : ppy_conv2d_split_weights_bf16x3(wt, total, planes, stream);
+        if (rc != PPY_OK) return rc;
+    }
     const float *src = dy;
     int src_ld = dy_ld;
     if (Kp != K) {

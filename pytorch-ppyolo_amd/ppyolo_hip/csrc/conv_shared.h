@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef PPY_X3_BBLOCK
+#define PPY_X3_BBLOCK 1   // f16x2 weight planes in [chunk][K][32] order (0 = [K][Kred], for A/B rebuilds); conv_x3.hip, conv_bwd.hip
+#endif
+
 struct ConvArgs {
     const float *x, *w, *scale, *shift, *res, *posb;
     const unsigned short *w3;    // weights as 3 bf16 planes [3][K][R][S][C] (conv_x3.hip), or NULL

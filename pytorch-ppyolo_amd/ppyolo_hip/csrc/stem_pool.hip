@@ -1,6 +1,7 @@
 // Stem conv (NCHW -> NHWC) and the pooling kernels of the PP-YOLO backbone / SPP.
 // All HBM/L2-bound: 16-byte coalesced NHWC accesses, no MFMA.
 #include <math.h>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -59,6 +60,71 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float *__restrict_
         const long long pc = pix < total ? pix : total - 1;
         amax_track(amx, (int)(pc / ((long long)Wo * Ho)), amax_out, blockIdx.x * 4 + (threadIdx.x >> 6));
     }
+}
+
+// Round 3: the same operator organised around an output ROW SEGMENT (64 pixels x 32 channels per workgroup).  The thread-per-
+// pixel form above reads its 27 taps with stride-2 4-byte loads (half of every line unused, twice: K / 16 = 2 grid rows) and
+// stores 16-byte pieces 128 B apart -- 64 lines per wave instruction: 67-71 us for 130 MB = 1.9 TB/s.  Here the 3 x 3 input
+// rows of the segment are copied into LDS as whole lines (even / odd columns apart, so that the stride-2 taps read
+// consecutive words), wave w computes channels 8w .. 8w+7 of the 64 pixels (weights uniform per wave: scalar loads), and the
+// 64 x 32 outputs leave through LDS as 1 KB of contiguous bytes per wave instruction.  Same fma chain, (c, r, s) ascending:
+// bit-identical to the kernel above (tests/test_gpu_ops.py).
+constexpr int ST_TW = 64, ST_OLD = 36;
+__global__ void __launch_bounds__(256) stem_conv_row_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            float *y, int y_ld, int N, int H, int W, int Ho, int Wo, int K, int act,
+                                                            float *amax_out, int tiles_x) {
+    __shared__ float s_in[3][3][2][ST_TW + 2];
+    __shared__ __attribute__((aligned(16))) float s_out[ST_TW][ST_OLD];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % tiles_x, ho = (blockIdx.x / tiles_x) % Ho, n = blockIdx.x / (tiles_x * Ho);
+    const int wo0 = tile * ST_TW;
+    // ---- input: rows 2 ho - 1 .. 2 ho + 1 of the three channels, columns 2 wo0 - 1 .. 2 wo0 + 127
+    for (int i = tid; i < 9 * (2 * ST_TW + 1); i += 256) {
+        const int j = i % (2 * ST_TW + 1), cr = i / (2 * ST_TW + 1);
+        const int c = cr / 3, r = cr - 3 * c;
+        const int hi = 2 * ho - 1 + r, wi = 2 * wo0 - 1 + j;
+        float v = 0.f;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)n * 3 + c) * H + hi) * W + wi];
+        // j even: odd input column 2 (wo0 + j / 2) - 1 (taps s = 0 of pixel j / 2, s = 2 of pixel j / 2 - 1); j odd: the even column (s = 1)
+        s_in[c][r][(j & 1) ^ 1][j >> 1] = v;
+    }
+    __syncthreads();
+    const int px = tid & 63, wv = tid >> 6;
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            in[c * 9 + r * 3 + 0] = s_in[c][r][1][px];
+            in[c * 9 + r * 3 + 1] = s_in[c][r][0][px];
+            in[c * 9 + r * 3 + 2] = s_in[c][r][1][px + 1];
+        }
+    const int k0 = blockIdx.y * 32 + wv * 8;
+    const bool live = wo0 + px < Wo;
+    float amx = 0.f;
+    floatx4 o4[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = __builtin_amdgcn_readfirstlane(k0 + u);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc = fmaf(in[t], w[k * 27 + t], acc);
+        const float v = ppy_apply_act(fmaf(acc, scale[k], shift[k]), act);
+        o4[u >> 2][u & 3] = v;
+        amx = fmaxf(amx, live ? fabsf(v) : 0.f);
+    }
+    *reinterpret_cast<floatx4 *>(&s_out[px][wv * 8]) = o4[0];
+    *reinterpret_cast<floatx4 *>(&s_out[px][wv * 8 + 4]) = o4[1];
+    __syncthreads();
+    // ---- output: 64 pixels x 128 B, contiguous in HBM (pixel stride y_ld floats)
+    float *yrow = y + (((long long)n * Ho + ho) * Wo + wo0) * y_ld + blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (tid >> 3) + 32 * i, c4 = (tid & 7) * 4;
+        if (wo0 + q < Wo) *reinterpret_cast<floatx4 *>(yrow + (long long)q * y_ld + c4) = *reinterpret_cast<const floatx4 *>(&s_out[q][c4]);
+    }
+    if (amax_out) amax_track(amx, n, amax_out, blockIdx.x * 4 + wv);      // tracked per-image max|y| (f16x2 consumers)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -191,6 +257,13 @@ extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_k
     PPY_CHECK_ARG(((uintptr_t)y & 15) == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo;
+    static const bool old_form = getenv("PPY_STEM_OLD") && getenv("PPY_STEM_OLD")[0] == '1';      // (A/B switch)
+    const int tiles_x = (Wo + ST_TW - 1) / ST_TW;
+    if (K % 32 == 0 && !old_form && (long long)N * Ho * tiles_x < (1LL << 31)) {
+        hipLaunchKernelGGL(stem_conv_row_kernel, dim3((unsigned)(N * Ho * tiles_x), K / 32), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                           w_kcrs, scale, shift, y, y_ld, N, H, W, Ho, Wo, K, act, amax_out, tiles_x);
+        return ppy_launch_status();
+    }
     dim3 grid((unsigned)((total + 255) / 256), K / 16);
     hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, w_kcrs, scale,
                        shift, y, y_ld, N, H, W, Ho, Wo, K, act, amax_out);

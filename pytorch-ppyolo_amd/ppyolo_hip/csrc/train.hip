@@ -437,6 +437,62 @@ __global__ void __launch_bounds__(256) spp_bwd_kernel(const float *dy, int dy_ld
     dx[(((long long)n * H + h) * W + w) * dx_ld + c] = g;
 }
 
+// Round 3: both steps in ONE launch when an image's map fits the LDS (the 19x19 map of the 608 input: 58 KB): a workgroup owns
+// (image, SPP_CG channels), stages x, finds the three argmax maps IN LDS (same scan, same tie rule) and gathers from them -- no
+// workspace traffic, 1 launch instead of 4 (3 x 38 + 273 us -> one pass bound by LDS reads).  Same order of additions as above.
+constexpr int SPP_CG = 16;
+__global__ void __launch_bounds__(256) spp_bwd_fused_kernel(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld,
+                                                            int H, int W, int C) {
+    extern __shared__ float spp_smem[];
+    const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * SPP_CG;
+    float *sx = spp_smem;                                                  // [HW][SPP_CG]
+    short *sarg = reinterpret_cast<short *>(spp_smem + HW * SPP_CG);       // [3][HW][SPP_CG]
+    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+        const int c = i % SPP_CG, q = i / SPP_CG;
+        sx[i] = c0 + c < C ? x[((long long)n * HW + q) * x_ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+        const int c = i % SPP_CG, q = i / SPP_CG;
+        const int h = q / W, w = q - h * W;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int r = 2 + 2 * b;
+            const int h0 = max(h - r, 0), w0 = max(w - r, 0), h1 = min(h + r, H - 1), w1 = min(w + r, W - 1);
+            float best = -__builtin_huge_valf();
+            int bi = h0 * W + w0;
+            for (int hh = h0; hh <= h1; ++hh)
+                for (int ww = w0; ww <= w1; ++ww) {
+                    const float v = sx[(hh * W + ww) * SPP_CG + c];
+                    if (v > best || v != v) {
+                        best = v;
+                        bi = hh * W + ww;
+                    }
+                }
+            sarg[(b * HW + q) * SPP_CG + c] = (short)bi;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+        const int c = i % SPP_CG, q = i / SPP_CG;
+        if (c0 + c >= C) continue;
+        const int h = q / W, w = q - h * W;
+        const float *dyn = dy + (long long)n * HW * dy_ld + c0 + c;
+        float g = dyn[(long long)q * dy_ld];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int r = 2 + 2 * b;
+            const int h0 = max(h - r, 0), w0 = max(w - r, 0), h1 = min(h + r, H - 1), w1 = min(w + r, W - 1);
+            for (int hh = h0; hh <= h1; ++hh)
+                for (int ww = w0; ww <= w1; ++ww) {
+                    const int o = hh * W + ww;
+                    if (sarg[(b * HW + o) * SPP_CG + c] == q) g += dyn[(long long)o * dy_ld + (b + 1) * C];
+                }
+        }
+        dx[((long long)n * HW + q) * dx_ld + c0 + c] = g;
+    }
+}
+
 // ---- DropBlock.  mask (1 = keep) is given; y = x * mask * (numel / sum(mask)).  The mask itself: seeds = u < gamma with a
 // counter-based uniform u (one Philox-style hash per element), mask = 1 - maxpool3x3(seeds) with zero padding
 // (custom_layers.py:330-336); sum(mask) by a deterministic two-level reduction.
@@ -733,6 +789,13 @@ extern "C" int ppy_spp_bwd_f32(const float *x, int x_ld, const float *dy, int dy
     const long long n = (long long)N * H * W * C;
     short *a5 = (short *)ws, *a9 = a5 + n, *a13 = a9 + n;
     hipStream_t st = (hipStream_t)stream;
+    const int lds = H * W * SPP_CG * (int)(sizeof(float) + 3 * sizeof(short));
+    if (lds <= 150 * 1024 && N <= 65535) {
+        static PpyLdsAttr attr;
+        if (ppy_lds_attr(attr, (const void *)spp_bwd_fused_kernel, lds) != PPY_OK) return PPY_ERR_LAUNCH;
+        hipLaunchKernelGGL(spp_bwd_fused_kernel, dim3((C + SPP_CG - 1) / SPP_CG, N), dim3(256), lds, st, x, x_ld, dy, dy_ld, dx, dx_ld, H, W, C);
+        return ppy_launch_status();
+    }
     hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 5, a5);
     hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 9, a9);
     hipLaunchKernelGGL(spp_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, st, x, x_ld, N, H, W, C, 13, a13);

@@ -7,7 +7,13 @@
 // One thread per (image, anchor, grid cell): it reads its 5 + C (+1 IoU) logits from the NHWC head output, its target
 // column from the reference's target layout [N, an, 6 + C, S, S] and the image's ground-truth boxes, and writes its slice
 // of dout plus six loss contributions (reduced afterwards in a fixed order).  HBM-bound by design: every input is read
-// once (the head outputs are a few MB per level).  Faithful to the reference's arithmetic, including
+// once (the head outputs are a few MB per level).
+// Round 3: the head output is channel-minor (a cell's 258 logits are one 1 KB row) and the targets are cell-minor, so a
+// thread per cell read and wrote its row with addresses 1 KB apart -- 64 cache lines per wave instruction, 400 us for the
+// 76x76 level.  Now a workgroup owns LOSS_CELLS consecutive cells of one image: their rows -- one contiguous piece of HBM --
+// are copied into LDS (row pitch odd: a column access by consecutive cells is conflict-free), the pair threads work in LDS
+// and overwrite every logit with its gradient in place, the rows go back as one contiguous stream; the six loss terms of
+// the workgroup are reduced in LDS in a fixed order and a last one-workgroup kernel adds the workgroups' sums.  Faithful to the reference's arithmetic, including
 //   * the IoU-aware term's reduction over grid x before the multiplication with tobj (iou_losses.py:241-242):
 //     loss = sum_h (sum_w tobj[h,w]) * (sum_w' iou[h,w'] * -log(ioup[h,w'] + 1e-9)),
 //   * `+ 1e-9` INSIDE the logarithms, `+ 1e-10` in the IoU union of the IoU losses and none in the ignore-mask IoU,
@@ -32,18 +38,55 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 __device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
 __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
 
-__global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
+constexpr int LOSS_CELLS = 64;          // cells per workgroup (x an anchors = pair threads; 192 of 256 at an = 3)
+constexpr int LOSS_MAXAN = 4;
+
+__global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int blocks_per_image, int pitch) {
+    extern __shared__ float s_rows[];                       // [LOSS_CELLS][pitch] logits -> gradients, then [LOSS_MAXAN][LOSS_CELLS] row sums of tobj
+    __shared__ float s_red[6][256];
     const int cells = p.S * p.S;
-    const long long total = (long long)p.N * p.an * cells;
-    // (threads past the end redo the last element -- identical values to identical addresses -- so that whole waves reach
-    // the maximum reduction at the end)
-    const long long i = min((long long)blockIdx.x * 256 + threadIdx.x, total - 1);
-    const int cell = (int)(i % cells), a = (int)((i / cells) % p.an), n = (int)(i / ((long long)cells * p.an));
+    const int n = blockIdx.x / blocks_per_image;
+    const int cell0 = (blockIdx.x - n * blocks_per_image) * LOSS_CELLS;
+    const int ncell = min(LOSS_CELLS, cells - cell0);
+    const int nch = p.an * (5 + p.C) + (p.iou_aware ? p.an : 0);
+    float *s_T = s_rows + LOSS_CELLS * pitch;
+    // ---- the rows of this workgroup's cells: one contiguous piece of the head output (4-byte accesses, 256 B per wave)
+    {
+        const float *src = p.out + ((long long)n * cells + cell0) * p.out_ld;
+        const int total = ncell * p.out_ld;
+        int row = threadIdx.x / p.out_ld, col = threadIdx.x - row * p.out_ld;
+        const int drow = 256 / p.out_ld, dcol = 256 - drow * p.out_ld;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            if (col < nch) s_rows[row * pitch + col] = src[i];
+            row += drow;
+            col += dcol;
+            if (col >= p.out_ld) { col -= p.out_ld; ++row; }
+        }
+    }
+    // ---- sum over grid x of tobj for the (anchor, row) pairs this workgroup touches (the IoU-aware term's broadcast):
+    // one thread per pair, ascending x like the reference's sum
+    const int h_first = cell0 / p.S, h_last = (cell0 + ncell - 1) / p.S;
+    if (p.iou_aware) {
+        const int nrows = h_last - h_first + 1;
+        for (int j = threadIdx.x; j < nrows * p.an; j += 256) {
+            const int a = j / nrows, hh = h_first + (j - a * nrows);
+            const float *trow = p.target + ((long long)(n * p.an + a) * (6 + p.C) + 5) * cells + hh * p.S;
+            float T = 0.f;
+            for (int q = 0; q < p.S; ++q) T += trow[q];
+            s_T[a * LOSS_CELLS + (hh - h_first)] = T;
+        }
+    }
+    __syncthreads();
+    const int a = threadIdx.x / LOSS_CELLS, lc = threadIdx.x - a * LOSS_CELLS;
+    const bool active = a < p.an && lc < ncell;
+    float dmax = 0.f;
+    float l6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+    const int cell = cell0 + lc;
     const int h = cell / p.S, w = cell - h * p.S;
     const float S = (float)p.S;
-    const float *o = p.out + (((long long)n * p.S + h) * p.S + w) * p.out_ld;
-    float *d = p.dout + (((long long)n * p.S + h) * p.S + w) * p.dout_ld;
-    float dmax = 0.f;
+    float *o = s_rows + lc * pitch;
+    float *d = o;                                          // gradients overwrite the logits in place (each logit has ONE reader: its pair)
     auto put = [&](int idx, float v) {
         d[idx] = v;
         dmax = fmaxf(dmax, fabsf(v));
@@ -92,9 +135,7 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
     float dk = -2.f * k * p.w_iou * ts;                                   // d(all losses) / d k, before the batch mean
     float l_ia = 0.f, g_ioup = 0.f;
     if (p.iou_aware) {
-        const float *trow = p.target + ((long long)(n * p.an + a) * (6 + p.C) + 5) * cells + h * p.S;
-        float T = 0.f;
-        for (int q = 0; q < p.S; ++q) T += trow[q];                       // sum over grid x of tobj: the reference's broadcast
+        const float T = s_T[a * LOSS_CELLS + (h - h_first)];              // sum over grid x of tobj: the reference's broadcast
         const float ip = sigm(o[a]);
         const float ce = 0.f - logf(ip + 1e-9f);
         l_ia = T * k * ce * p.w_iou_aware;
@@ -162,12 +203,36 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p) {
     put(base + 3, g_h * p.inv_n);
     put(base + 4, g_obj * p.inv_n);
     if (p.iou_aware) put(a, g_ioup * p.inv_n);
-    float *lp = p.part + i * 6;
-    lp[0] = l_xy; lp[1] = l_wh; lp[2] = l_obj; lp[3] = l_cls; lp[4] = l_iou; lp[5] = l_ia;
+    l6[0] = l_xy; l6[1] = l_wh; l6[2] = l_obj; l6[3] = l_cls; l6[4] = l_iou; l6[5] = l_ia;
+    }
     if (p.amax_dout) amax_track(dmax, n, p.amax_dout, blockIdx.x * 4 + (threadIdx.x >> 6));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s_red[j][threadIdx.x] = l6[j];
+    __syncthreads();
+    // ---- the gradient rows back as one contiguous stream
+    {
+        float *dst = p.dout + ((long long)n * cells + cell0) * p.dout_ld;
+        const int total = ncell * p.dout_ld;
+        int row = threadIdx.x / p.dout_ld, col = threadIdx.x - row * p.dout_ld;
+        const int drow = 256 / p.dout_ld, dcol = 256 - drow * p.dout_ld;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            if (col < nch) dst[i] = s_rows[row * pitch + col];
+            row += drow;
+            col += dcol;
+            if (col >= p.dout_ld) { col -= p.dout_ld; ++row; }
+        }
+    }
+    // ---- the workgroup's six sums: a tree over the 256 threads, fixed order
+    for (int o2 = 128; o2 > 0; o2 >>= 1) {
+        if ((int)threadIdx.x < o2)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s_red[j][threadIdx.x] += s_red[j][threadIdx.x + o2];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) p.part[(long long)blockIdx.x * 6 + threadIdx.x] = s_red[threadIdx.x][0];
 }
 
-// loss[j] = inv_n * sum over the cells, fixed order: one workgroup, strided partial sums, tree
+// loss[j] = inv_n * sum over the workgroups' sums, fixed order: one workgroup, strided partial sums, tree
 __global__ void __launch_bounds__(256) loss_reduce_kernel(const float *part, long long cells, float inv_n, float *loss, int accumulate) {
     __shared__ float red[6][256];
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -209,9 +274,16 @@ extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const floa
     }
     p.downsample = (float)downsample; p.scale_x_y = (float)scale_x_y; p.ignore_thresh = (float)ignore_thresh;
     p.w_iou = (float)iou_loss_weight; p.w_iou_aware = (float)iou_aware_loss_weight; p.inv_n = 1.0f / (float)N;
-    const long long cells = (long long)N * an * S * S;
+    // (a row must fit the staging: C up to a few hundred classes; the pair threads are LOSS_CELLS x an <= 256)
+    const int pitch = nch | 1;
+    const int lds = (LOSS_CELLS * pitch + LOSS_MAXAN * LOSS_CELLS) * (int)sizeof(float);
+    PPY_CHECK_ARG(lds <= 150 * 1024);
+    static PpyLdsAttr attr;
+    if (ppy_lds_attr(attr, (const void *)yolo_loss_kernel, lds) != PPY_OK) return PPY_ERR_LAUNCH;
+    const int blocks_per_image = (S * S + LOSS_CELLS - 1) / LOSS_CELLS;
+    const long long blocks = (long long)N * blocks_per_image;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(yolo_loss_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, cells, p.inv_n, loss6, accumulate);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p, blocks_per_image, pitch);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, blocks, p.inv_n, loss6, accumulate);
     return ppy_launch_status();
 }
