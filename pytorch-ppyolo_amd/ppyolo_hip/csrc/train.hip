@@ -529,6 +529,55 @@ __global__ void __launch_bounds__(256) dropblock_mask_kernel(float *mask, int N,
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// Round 3: the same mask from ONE hash per element instead of nine (the hashes -- 64-bit multiplies -- were the kernel's whole
+// time: 72 us per level).  A workgroup owns (image, DB_TH rows, DB_CG channels): the seeds of its rows and a one-row / one-column
+// halo go to LDS as bytes (the halo rows are hashed again by the neighbour: 1.5x instead of 9x), then every element ORs its 3x3
+// neighbourhood from LDS.  Same hash of the same element id: bit-identical masks; the block sums are counts (exact in fp32).
+constexpr int DB_TH = 4, DB_CG = 32;
+__global__ void __launch_bounds__(256) dropblock_mask_tile_kernel(float *mask, int N, int H, int W, int C, float gamma,
+                                                                  unsigned long long seed, float *block_sums) {
+    extern __shared__ unsigned char s_seed[];      // [DB_TH + 2][W + 2][DB_CG]
+    __shared__ float red[4];
+    const int cgs = (C + DB_CG - 1) / DB_CG, hbs = (H + DB_TH - 1) / DB_TH;
+    int b = blockIdx.x;
+    const int cgi = b % cgs;
+    b /= cgs;
+    const int hb = b % hbs, n = b / hbs;
+    const int c0 = cgi * DB_CG, h0 = hb * DB_TH, PW = W + 2;
+    for (int i = threadIdx.x; i < (DB_TH + 2) * PW * DB_CG; i += 256) {
+        const int c = i % DB_CG, q = i / DB_CG;
+        const int pw = q % PW, ph = q / PW;
+        const int hh = h0 - 1 + ph, ww = pw - 1;
+        unsigned char sd = 0;
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W && c0 + c < C) {
+            const unsigned long long id = ((((unsigned long long)n * H + hh) * W + ww) * C + c0 + c);
+            const float u = (float)(mix32(seed ^ (id * 0xD1342543DE82EF95ull)) >> 8) * (1.0f / 16777216.0f);
+            sd = u < gamma ? 1 : 0;
+        }
+        s_seed[i] = sd;
+    }
+    __syncthreads();
+    float m = 0.f;
+    for (int i = threadIdx.x; i < DB_TH * W * DB_CG; i += 256) {
+        const int c = i % DB_CG, q = i / DB_CG;
+        const int w = q % W, hl = q / W;
+        if (h0 + hl < H && c0 + c < C) {
+            unsigned hit = 0;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) hit |= s_seed[((hl + dh) * PW + (w + dw)) * DB_CG + c];
+            const float v = hit ? 0.f : 1.f;
+            mask[(((long long)n * H + h0 + hl) * W + w) * C + c0 + c] = v;
+            m += v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ void __launch_bounds__(256) sum_blocks_kernel(const float *block_sums, int n, float numel, float *scale_out) {
     __shared__ float red[256];
     float s = 0.f;
@@ -803,8 +852,12 @@ extern "C" int ppy_spp_bwd_f32(const float *x, int x_ld, const float *dy, int dy
     return ppy_launch_status();
 }
 
+static long long dropblock_tiles(int N, int H, int W, int C) {
+    return (long long)N * ((H + DB_TH - 1) / DB_TH) * ((C + DB_CG - 1) / DB_CG);
+}
 extern "C" size_t ppy_dropblock_workspace_bytes(int N, int H, int W, int C) {
-    return ((size_t)blocks_for((long long)N * H * W * C) + 1) * sizeof(float);
+    const long long a = blocks_for((long long)N * H * W * C), b = dropblock_tiles(N, H, W, C);
+    return ((size_t)(a > b ? a : b) + 1) * sizeof(float);
 }
 extern "C" int ppy_dropblock_mask_f32(float *mask, float *scale_out, int N, int H, int W, int C, int block_size, float keep_prob,
                                       unsigned long long seed, void *ws, size_t ws_bytes, void *stream) {
@@ -816,6 +869,13 @@ extern "C" int ppy_dropblock_mask_f32(float *mask, float *scale_out, int N, int 
     const float gamma = (h * h * (1.0f - keep_prob)) / (bs * bs * ((h - bs + 1.0f) * (h - bs + 1.0f)));
     const long long n = (long long)N * H * W * C;
     hipStream_t st = (hipStream_t)stream;
+    const int lds = (DB_TH + 2) * (W + 2) * DB_CG;
+    const long long tiles = dropblock_tiles(N, H, W, C);
+    if (lds <= 64 * 1024 && tiles < (1LL << 31)) {
+        hipLaunchKernelGGL(dropblock_mask_tile_kernel, dim3((unsigned)tiles), dim3(256), lds, st, mask, N, H, W, C, gamma, seed, (float *)ws);
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, (int)tiles, (float)n, scale_out);
+        return ppy_launch_status();
+    }
     hipLaunchKernelGGL(dropblock_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, st, mask, N, H, W, C, gamma, seed, (float *)ws);
     hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, (int)blocks_for(n), (float)n, scale_out);
     return ppy_launch_status();

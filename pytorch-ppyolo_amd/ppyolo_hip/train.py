@@ -33,10 +33,11 @@ NUM_X3_F16_FIRST, NUM_X3_F16_LAST = 40, 66      # ids of the f16x2 tiles with 2 
 class Act(object):
     """NHWC activation: channel slice [coff, coff + C) of a buffer [N, H, W, ld]; `g` = its gradient (an Act) once a
     consumer has produced one; `req` = whether anything upstream wants that gradient."""
-    __slots__ = ('t', 'coff', 'C', 'g', 'req', 'amax')
+    __slots__ = ('t', 'coff', 'C', 'g', 'req', 'amax', 'coordp')
 
     def __init__(self, t, coff=0, C=None, req=False, amax=None):
         self.t, self.coff, self.C, self.g, self.req = t, coff, (t.shape[3] - coff if C is None else C), None, req
+        self.coordp = 0           # > 0: channels [C, coordp) of the buffer already hold a CoordConv's coordinates + zero padding (new_coord)
         self.amax = amax          # tracked per-image max|.| (ops.amax_slots block) or None: the operand scale of an f16x2 convolution
 
     @property
@@ -126,6 +127,7 @@ class TrainStep(object):
         self.train_keys = want
         self._wcache = {}
         self._const = {}
+        self._coord_bufs = {}
         self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
         self.steps_done = 0
         self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
@@ -194,6 +196,24 @@ class TrainStep(object):
         ld = C if ld is None else ld
         t = (torch.zeros if zero else torch.empty)((N, H, W, ld), dtype=torch.float32, device=self.dev)
         return Act(t, 0, C, req)
+
+    def new_coord(self, tag, N, H, W, C, req=False):
+        """An activation whose only consumer is a CoordConv: a PERSISTENT buffer [N, H, W, r32(C + 2)] per layer whose channels
+        [C, ...) hold x_range, y_range and the zero padding (written once); the producer fills [0, C) and coord_concat() hands
+        the whole buffer to the convolution -- no concatenation copy per step (it was 12 x 27 us).  A step's forward and
+        backward finish inside one call (loss_dict snapshots the gradients), so a layer's buffer is free again at the next
+        step."""
+        Cp = _r32(C + 2)
+        key = (tag, N, H, W, C)
+        t = self._coord_bufs.get(key)
+        if t is None:
+            t = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=self.dev)
+            t[..., C] = (torch.arange(0, W, dtype=torch.float32, device=self.dev) / (W - 1) * 2.0 - 1).view(1, 1, W)
+            t[..., C + 1] = (torch.arange(0, H, dtype=torch.float32, device=self.dev) / (H - 1) * 2.0 - 1).view(1, H, 1)
+            self._coord_bufs[key] = t
+        a = Act(t, 0, C, req)
+        a.coordp = Cp
+        return a
 
     def new_amax(self, N):
         """A zeroed block of per-image maximum slots (one arena, zeroed once per step)."""
@@ -285,6 +305,8 @@ class TrainStep(object):
         """CoordConv.__call__ (reference model/custom_layers.py:261-272) as a real concatenation, zero-padded to a multiple
         of 32 channels for the implicit GEMM: [x, x_range, y_range, 0 ...]."""
         Cp = _r32(x.C + 2)
+        if x.coordp == Cp and x.coff == 0:               # produced into a coordinate-ready buffer (new_coord): nothing to copy
+            return Act(x.t, 0, Cp, x.req, None if x.amax is None else torch.clamp_min(x.amax, 1.0))
         key = ('coord', x.H, x.W, Cp - x.C)
         if key not in self._const:
             xr = torch.arange(0, x.W, dtype=torch.float32, device=self.dev) / (x.W - 1) * 2.0 - 1
@@ -353,7 +375,7 @@ class TrainStep(object):
                         json.dump(part, fh, indent=0, sort_keys=True)
         return dict(self._measured)
 
-    def conv_unit(self, prefix, x, stride=1, act=None, res=None, coord=False, out=None):
+    def conv_unit(self, prefix, x, stride=1, act=None, res=None, coord=False, out=None, coord_out=False):
         """Conv2dUnit.forward in training mode (reference model/custom_layers.py:243-253): conv -> BatchNorm on batch
         statistics -> activation; records its backward when its parameters train."""
         sd = self.sd
@@ -402,7 +424,7 @@ class TrainStep(object):
             else:
                 K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
             self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
-            y = out if out is not None else self.new(xin.N, Ho, Wo, Kout)
+            y = out if out is not None else (self.new_coord(prefix, xin.N, Ho, Wo, Kout) if coord_out else self.new(xin.N, Ho, Wo, Kout))
             y.req = trainable
             y.amax = self.new_amax(xin.N) if self.f16 else None
             K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act,
@@ -627,7 +649,7 @@ class TrainStep(object):
         return [feats[s] for s in (2, 3, 4, 5) if s in cfg.backbone['feature_maps']]
 
     # ---- head (trains) --------------------------------------------------------------------------------------------------------
-    def drop_block(self, x, keep_prob):
+    def drop_block(self, x, keep_prob, coord_tag=None):
         """DropBlock in training mode (reference model/custom_layers.py:303-342)."""
         if self.masks is not None:                         # parity tests: the reference's own mask ([N, C, H, W], 1 = keep)
             m = self.masks.pop(0).to(self.dev).permute(0, 2, 3, 1).contiguous()
@@ -637,7 +659,7 @@ class TrainStep(object):
             scale = torch.empty(1, dtype=torch.float32, device=self.dev)
             self.seed += 1
             K.dropblock_mask(m, scale, keep_prob, (self.seed_base + self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
-        y = self.new(x.N, x.H, x.W, x.C, req=True)
+        y = self.new(x.N, x.H, x.W, x.C, req=True) if coord_tag is None else self.new_coord(coord_tag, x.N, x.H, x.W, x.C, req=True)
         y.amax = None if x.amax is None else x.amax * scale     # y = x * mask * scale, mask in {0, 1}
         K.dropblock_apply(x.view(), m, scale, y.view())
 
@@ -654,7 +676,10 @@ class TrainStep(object):
         use_spp, drop, keep = hcfg.get('spp', True), hcfg.get('drop_block', True), hcfg.get('keep_prob', 0.9)
         active = hcfg.get('drop_active', True)
         idx = 0
+        # (coord_out / coord_tag: the tensor's one consumer is a CoordConv -> produced into that layer's coordinate-ready buffer)
         for j in range(nblk):
+            last = j == nblk - 1
+            drop_here = drop and active and ((j == 0 and not is_first) or (last and is_first))
             if use_spp and is_first and j == 1:
                 Cw = self.sd['%s.layers.%d.conv.weight' % (p, idx + 1)].shape[0]
                 wide = self.new(x.N, x.H, x.W, 4 * Cw, req=True)
@@ -669,19 +694,19 @@ class TrainStep(object):
                     self.accum(slot0, g)
                 self.tape.append(spp_bwd)
                 x = self.conv_unit('%s.layers.%d' % (p, idx + 3), wide, 1, 'leaky')
-                x = self.conv_unit('%s.layers.%d' % (p, idx + 4), x, 1, 'leaky')
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 4), x, 1, 'leaky', coord_out=coord and not drop_here)
                 idx += 5
             else:
                 x = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord)
-                x = self.conv_unit('%s.layers.%d' % (p, idx + 2), x, 1, 'leaky')
+                x = self.conv_unit('%s.layers.%d' % (p, idx + 2), x, 1, 'leaky', coord_out=coord and not drop_here)
                 idx += 3
             if drop and j == 0 and not is_first:
-                x = self.drop_block(x, keep) if active else x
+                x = self.drop_block(x, keep, '%s.drop%d' % (p, j) if coord else None) if active else x
                 idx += 1
         if drop and is_first:
-            x = self.drop_block(x, keep) if active else x
+            x = self.drop_block(x, keep, '%s.drop_last' % p if coord else None) if active else x
             idx += 1
-        route = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord)
+        route = self.conv_unit('%s.layers.%d' % (p, idx + 1), x, 1, 'leaky', coord=coord, coord_out=coord)
         tip = self.conv_unit('%s.tip_layers.1' % p, route, 1, 'leaky', coord=coord)
         return route, tip
 
@@ -694,10 +719,11 @@ class TrainStep(object):
         for i, feat in enumerate(blocks):
             if i > 0:
                 Cr = route.C
-                wide = self.new(feat.N, feat.H, feat.W, Cr + feat.C, req=True)
+                wide = (self.new_coord('head.route%d' % i, feat.N, feat.H, feat.W, Cr + feat.C, req=True) if hcfg.get('coord_conv', True)
+                        else self.new(feat.N, feat.H, feat.W, Cr + feat.C, req=True))
                 up = wide.slice(0, Cr)
                 K.upsample2x(route.view(), up.view())
-                wide.t[..., Cr:].copy_(feat.t[..., feat.coff:feat.coff + feat.C])
+                wide.t[..., Cr:Cr + feat.C].copy_(feat.t[..., feat.coff:feat.coff + feat.C])
                 wide.amax = None if (route.amax is None or feat.amax is None) else torch.maximum(route.amax, feat.amax)
 
                 def up_bwd(route=route, wide=wide, Cr=Cr, feat=feat):
