@@ -257,7 +257,8 @@ extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_k
     PPY_CHECK_ARG(((uintptr_t)y & 15) == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo;
-    static const bool old_form = getenv("PPY_STEM_OLD") && getenv("PPY_STEM_OLD")[0] == '1';      // (A/B switch)
+    const char *sw = getenv("PPY_STEM_OLD");      // A/B switch, read per call: tests compare the two forms bit for bit
+    const bool old_form = sw && sw[0] == '1';
     const int tiles_x = (Wo + ST_TW - 1) / ST_TW;
     if (K % 32 == 0 && !old_form && (long long)N * Ho * tiles_x < (1LL << 31)) {
         hipLaunchKernelGGL(stem_conv_row_kernel, dim3((unsigned)(N * Ho * tiles_x), K / 32), dim3(256), 0, (hipStream_t)stream, x_nchw,

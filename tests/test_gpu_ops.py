@@ -233,6 +233,37 @@ def test_stem_conv(golden):
     close(nchw(y), ref, what='stem')
 
 
+def test_stem_row_kernel_is_bit_identical_to_the_pixel_kernel():
+    """Round 3: the stem as row segments through LDS (csrc/stem_pool.hip, stem_conv_row_kernel) keeps the fma chain of the
+    thread-per-pixel form (PPY_STEM_OLD=1 selects it per call): same bits, incl. several / partial 64-pixel segments, odd
+    sizes, the image border taps, a padded pixel stride, and the tracked per-image maxima."""
+    import os
+    from ppyolo_hip import ops
+    gen = torch.Generator().manual_seed(11)
+    for (N, H, W, K, ld) in [(2, 37, 150, 32, 32), (1, 64, 259, 32, 40), (3, 9, 130, 64, 64), (2, 608, 608, 32, 32)]:
+        x = torch.randn(N, 3, H, W, generator=gen).cuda()
+        x[0] *= 7.0
+        w = (torch.randn(K, 3, 3, 3, generator=gen) * 0.2).cuda()
+        sc, sh = (torch.rand(K, generator=gen) + 0.5).cuda(), torch.randn(K, generator=gen).cuda()
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        got = {}
+        for form in ('0', '1'):
+            os.environ['PPY_STEM_OLD'] = form
+            try:
+                y = torch.full((N, Ho, Wo, ld), -3.0).cuda()
+                amax = ops.amax_slots(device='cuda', N=N)
+                ops.stem_conv(x, w, sc, sh, ops.View(y, 0, K), 'relu', amax_out=amax)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop('PPY_STEM_OLD', None)
+            got[form] = (y.cpu(), amax.view(N, -1).amax(dim=1).cpu())
+        assert torch.equal(got['0'][0], got['1'][0]), (N, H, W, K)
+        assert torch.equal(got['0'][1], got['1'][1]), 'tracked maxima differ'
+        assert torch.equal(got['0'][1], got['0'][0][..., :K].reshape(N, -1).abs().amax(dim=1))
+        if ld > K:
+            assert bool((got['0'][0][..., K:] == -3.0).all()), 'channels beyond K were written'
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('shape', [
     # N, H, W, C, K, stride        (stage-5 shapes of R50vd in small, ragged tiles, K % 4 != 0 = scalar epilogue)

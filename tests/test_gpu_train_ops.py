@@ -79,6 +79,52 @@ def test_upsample_spp_act_backward():
     assert torch.equal(out.cpu(), d * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.1)))
 
 
+def test_spp_backward_fused_and_fallback_forms():
+    """Round 3: ppy_spp_bwd_f32 runs as ONE launch when an image's map fits the LDS (argmax maps built there) and as the
+    four-launch gather otherwise: both against torch autograd, with a channel count that leaves a partial 16-channel group,
+    ties, and a map too large for the fused form (52 x 52)."""
+    from oracle import ppyolo_oracle as orc
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(21)
+    for (N, C, H, W) in [(2, 24, 19, 19), (1, 40, 13, 10), (1, 16, 52, 52)]:
+        xs = torch.randn(N, C, H, W, generator=g)
+        xs[0, 0, 3, 3] = xs[0, 0, 3, 4] = 9.0                       # first in scan order wins
+        xs[:, 1] = 0.25                                               # a constant channel: every window is one big tie
+        xs.requires_grad_(True)
+        dys = torch.randn(N, 4 * C, H, W, generator=g)
+        orc.spp(xs).backward(dys)
+        dxs = torch.full((N, H, W, C + 8), 5.0).cuda()
+        ops.spp_bwd(ops.View(nhwc(xs.detach()).cuda()), ops.View(nhwc(dys).cuda()), ops.View(dxs, 0, C))
+        torch.cuda.synchronize()
+        assert rel(nchw(dxs[..., :C]), xs.grad) <= 2e-6, (N, C, H, W)
+        assert bool((dxs[..., C:] == 5.0).all())
+
+
+@pytest.mark.parametrize('shape', [(1, 13, 11, 40, 0.85), (2, 19, 19, 512, 0.9), (1, 3, 5, 4, 0.5)])
+def test_dropblock_mask_odd_shapes(shape):
+    """The tiled mask kernel (one hash per element, seeds + halo in LDS) on shapes that leave partial row blocks / channel
+    groups: the same bits as nine hashes per element (replicated in numpy)."""
+    from ppyolo_hip import ops
+    N, H, W, C, keep = shape
+    seed = 987654321
+    mask, scale = torch.zeros(N, H, W, C).cuda(), torch.zeros(1).cuda()
+    ops.dropblock_mask(mask, scale, keep, seed)
+    torch.cuda.synchronize()
+    ids = np.arange(N * H * W * C, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        key = (np.uint64(seed) ^ (ids * np.uint64(0xD1342543DE82EF95))) + np.uint64(0x9E3779B97F4A7C15)
+        key = (key ^ (key >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        key = (key ^ (key >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        key = (key ^ (key >> np.uint64(31))) >> np.uint64(32)
+    u = ((key >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(N, H, W, C)
+    gamma = np.float32(H * H * (1 - keep)) / np.float32(9 * (H - 2) ** 2)
+    seeds = torch.from_numpy((u < gamma).astype(np.float32)).permute(0, 3, 1, 2)
+    want = 1.0 - F.max_pool2d(seeds, 3, 1, 1)
+    assert torch.equal(nchw(mask.cpu()), want)
+    if float(want.sum()) > 0:
+        assert abs(float(scale) - mask.numel() / float(want.sum())) <= 1e-6 * float(scale)
+
+
 def test_dropblock_mask_and_apply():
     """mask = 1 - maxpool3x3(u < gamma) with the counter-based generator (replicated here bit for bit), gamma from the
     reference's formula, scale = numel / sum(mask); forward y = x * mask * scale."""
