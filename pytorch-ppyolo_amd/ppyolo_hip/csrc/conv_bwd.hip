@@ -109,9 +109,32 @@ struct WgradArgs {
     float *out;              // dw (one slice) or the partial sums [slices][K][R][S][C]
     int x_ld, dy_ld;
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad;
-    int P, pix_per_slice, tiles_c;
+    int P, pix_per_slice, tiles_c, tiles_kc;
     const float *amax_x, *amax_dy;      // f16x2 kernel: tracked per-image maxima of x and dy (N * AMAX_SLOTS slots each)
 };
+
+// Workgroup -> (tile, tap, pixel slice).  The (k tile, c tile, tap) workgroups of ONE pixel slice read the same rows of dy and
+// x; the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (8 private L2s), so in plain (x, y, z) order the
+// 18 ... 288 workgroups of a slice fetched it into every L2 (PMC, round 3: the weight-gradient launches pulled 4 GB per step
+// through the fabric for 0.6 GB of operands, with ONE step of prefetch to hide the misses behind).  XCD-contiguous order
+// (conv_x3.hip): XCD x owns a contiguous range of virtual ids, virtual ids are slice-major -- a slice's workgroups share
+// an L2 and start together.  PPY_WGRAD_XCD=0 at build time restores the plain order.
+#ifndef PPY_WGRAD_XCD
+#define PPY_WGRAD_XCD 1
+#endif
+__device__ __forceinline__ void wgrad_block(int tiles, int taps, int &tile, int &tap, int &slice) {
+    int v = (int)blockIdx.x;
+    if (PPY_WGRAD_XCD) {
+        const int nb = (int)gridDim.x, qd = nb >> 3, r = nb & 7;
+        const int xcd = v & 7, idx = v >> 3;
+        v = xcd * qd + min(xcd, r) + idx;
+    }
+    const int tt = tiles * taps;
+    slice = v / tt;
+    const int w = v - slice * tt;
+    tap = w / tiles;
+    tile = w - tap * tiles;
+}
 
 constexpr int WG_TK = 128, WG_TC = 128;       // workgroup tile: output channels x input channels
 constexpr int PIX = 16;                       // pixels per pipeline step (8 MFMA depths of 2)
@@ -120,12 +143,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wk = wave >> 1, wc = wave & 1;                   // 2 x 2 waves, 64 x 64 each
-    const int tile = blockIdx.x;
+    int tile, tap, slice;
+    wgrad_block(p.tiles_kc, p.R * p.S, tile, tap, slice);
     const int tk = tile / p.tiles_c, tc = tile - tk * p.tiles_c;
-    const int tap = blockIdx.y, r = tap / p.S, s = tap - r * p.S;
+    const int r = tap / p.S, s = tap - r * p.S;
     const int k_base = tk * WG_TK + wk * 64, c_base = tc * WG_TC + wc * 64;
     const int half = lane >> 5, l32 = lane & 31;
-    const int p_begin = blockIdx.z * p.pix_per_slice;
+    const int p_begin = slice * p.pix_per_slice;
     const int p_end = min(p_begin + p.pix_per_slice, p.P);
 
     floatx16 acc[2][2];
@@ -189,7 +213,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs p) {
             }
     }
     // accumulator element e of tile (i, j): row k = (e&3) + 8*(e>>2) + 4*half, column c = l32
-    float *out = p.out + (long long)blockIdx.z * p.K * p.R * p.S * p.C;
+    float *out = p.out + (long long)slice * p.K * p.R * p.S * p.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -271,11 +295,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
     char *sA = smem, *sB = smem + X3_TILE;                      // dy (k rows), x (c rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wc = wave & 1;
-    const int tile = blockIdx.x;
+    int tile, tap, slice;
+    wgrad_block(p.tiles_kc, p.R * p.S, tile, tap, slice);
     const int tk = tile / p.tiles_c, tc = tile - tk * p.tiles_c;
-    const int tap = blockIdx.y, r = tap / p.S, s = tap - r * p.S;
+    const int r = tap / p.S, s = tap - r * p.S;
     const int k0 = tk * WG_TK, c0 = tc * WG_TC;
-    const int p_begin = blockIdx.z * p.pix_per_slice;
+    const int p_begin = slice * p.pix_per_slice;
     const int p_end = min(p_begin + p.pix_per_slice, p.P);
     // loader role: pixel quad pq (4 pixels), channel group cg (4 channels)
     const int pq = tid & 7, cg = tid >> 3;
@@ -365,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
                     }
         }
     }
-    float *out = p.out + (long long)blockIdx.z * p.K * p.R * p.S * p.C;
+    float *out = p.out + (long long)slice * p.K * p.R * p.S * p.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -531,9 +556,11 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     p.pix_per_slice = ceil_div(ceil_div(p.P, sl), gran) * gran;
     const int slices = ceil_div(p.P, p.pix_per_slice);
     p.tiles_c = ceil_div(C, WG_TC);
+    p.tiles_kc = ceil_div(K, WG_TK) * p.tiles_c;
     p.out = slices > 1 ? (float *)ws : dw_krsc;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ceil_div(K, WG_TK) * p.tiles_c, R * S, slices);
+    PPY_CHECK_ARG((long long)p.tiles_kc * R * S * slices < (1LL << 31));
+    const dim3 grid(p.tiles_kc * R * S * slices);
     if (x3 && amax_x && amax_dy) {
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(256), 0, st, p);
     } else if (x3) {

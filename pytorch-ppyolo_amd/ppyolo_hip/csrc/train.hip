@@ -437,10 +437,14 @@ __global__ void __launch_bounds__(256) spp_bwd_kernel(const float *dy, int dy_ld
     dx[(((long long)n * H + h) * W + w) * dx_ld + c] = g;
 }
 
-// Round 3: both steps in ONE launch when an image's map fits the LDS (the 19x19 map of the 608 input: 58 KB): a workgroup owns
-// (image, SPP_CG channels), stages x, finds the three argmax maps IN LDS (same scan, same tie rule) and gathers from them -- no
-// workspace traffic, 1 launch instead of 4 (3 x 38 + 273 us -> one pass bound by LDS reads).  Same order of additions as above.
-constexpr int SPP_CG = 16;
+// Round 3: both steps in ONE launch when an image's map fits the LDS: a workgroup owns (image, SPP_CG channels), stages x,
+// finds the three argmax maps IN LDS (same scan, same tie rule) and gathers from them -- no workspace traffic, 1 launch instead
+// of 4.  The loops are LDS-latency chains (a read, a compare), so the two things that matter are waves per CU -- SPP_CG = 4:
+// 14 KB of LDS per workgroup, 1024 workgroups for the 19x19x512 map of the 608 input (a first version with 16 channels per
+// workgroup ran ONE wave per SIMD and took 1055 us against 388 us for the four launches) -- and a row of a window as ONE
+// batch of independent reads (fixed trip count 2r+1 with a validity flag instead of lane-dependent bounds).  Same order of
+// additions as the four-launch form.
+constexpr int SPP_CG = 4;
 __global__ void __launch_bounds__(256) spp_bwd_fused_kernel(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld,
                                                             int H, int W, int C) {
     extern __shared__ float spp_smem[];
@@ -458,17 +462,25 @@ __global__ void __launch_bounds__(256) spp_bwd_fused_kernel(const float *x, int 
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const int r = 2 + 2 * b;
-            const int h0 = max(h - r, 0), w0 = max(w - r, 0), h1 = min(h + r, H - 1), w1 = min(w + r, W - 1);
+            const int h0 = max(h - r, 0), h1 = min(h + r, H - 1);
             float best = -__builtin_huge_valf();
-            int bi = h0 * W + w0;
-            for (int hh = h0; hh <= h1; ++hh)
-                for (int ww = w0; ww <= w1; ++ww) {
-                    const float v = sx[(hh * W + ww) * SPP_CG + c];
-                    if (v > best || v != v) {
-                        best = v;
+            int bi = h0 * W + max(w - r, 0);
+            for (int hh = h0; hh <= h1; ++hh) {
+                float v[13];
+#pragma unroll
+                for (int j = 0; j <= 2 * r; ++j) {
+                    const int ww = min(max(w - r + j, 0), W - 1);
+                    v[j] = sx[(hh * W + ww) * SPP_CG + c];
+                }
+#pragma unroll
+                for (int j = 0; j <= 2 * r; ++j) {
+                    const int ww = w - r + j;
+                    if ((unsigned)ww < (unsigned)W && (v[j] > best || v[j] != v[j])) {
+                        best = v[j];
                         bi = hh * W + ww;
                     }
                 }
+            }
             sarg[(b * HW + q) * SPP_CG + c] = (short)bi;
         }
     }
@@ -482,12 +494,20 @@ __global__ void __launch_bounds__(256) spp_bwd_fused_kernel(const float *x, int 
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const int r = 2 + 2 * b;
-            const int h0 = max(h - r, 0), w0 = max(w - r, 0), h1 = min(h + r, H - 1), w1 = min(w + r, W - 1);
-            for (int hh = h0; hh <= h1; ++hh)
-                for (int ww = w0; ww <= w1; ++ww) {
-                    const int o = hh * W + ww;
-                    if (sarg[(b * HW + o) * SPP_CG + c] == q) g += dyn[(long long)o * dy_ld + (b + 1) * C];
+            const int h0 = max(h - r, 0), h1 = min(h + r, H - 1);
+            for (int hh = h0; hh <= h1; ++hh) {
+                short a[13];
+#pragma unroll
+                for (int j = 0; j <= 2 * r; ++j) {
+                    const int ww = min(max(w - r + j, 0), W - 1);
+                    a[j] = sarg[(b * HW + hh * W + ww) * SPP_CG + c];
                 }
+#pragma unroll
+                for (int j = 0; j <= 2 * r; ++j) {
+                    const int ww = w - r + j;
+                    if ((unsigned)ww < (unsigned)W && a[j] == q) g += dyn[(long long)(hh * W + ww) * dy_ld + (b + 1) * C];
+                }
+            }
         }
         dx[((long long)n * HW + q) * dx_ld + c0 + c] = g;
     }

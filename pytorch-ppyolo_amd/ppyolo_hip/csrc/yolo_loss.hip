@@ -38,12 +38,17 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 __device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
 __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
 
-constexpr int LOSS_CELLS = 64;          // cells per workgroup (x an anchors = pair threads; 192 of 256 at an = 3)
+constexpr int LOSS_CELLS = 64;          // cells per workgroup = lanes of a wave
 constexpr int LOSS_MAXAN = 4;
+// Waves of a workgroup: (anchor a, part q), q = 0: box, objectness, ignore mask and the first C / 10 classes; q = 1 .. 3: a third
+// of the remaining classes each (the class loop -- exp, two logs, three divisions per class -- is most of the arithmetic, and
+// one wave per pair left a CU with 6 waves: 124 us per level on average; 12 waves per workgroup, two workgroups per CU).
+constexpr int LOSS_Q = 4;
 
-__global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int blocks_per_image, int pitch) {
+__global__ void __launch_bounds__(LOSS_CELLS * LOSS_MAXAN * LOSS_Q) yolo_loss_kernel(const LossArgs p, int blocks_per_image, int pitch) {
     extern __shared__ float s_rows[];                       // [LOSS_CELLS][pitch] logits -> gradients, then [LOSS_MAXAN][LOSS_CELLS] row sums of tobj
-    __shared__ float s_red[6][256];
+    __shared__ float s_red[LOSS_MAXAN * LOSS_Q][6];
+    const int nt = (int)blockDim.x;
     const int cells = p.S * p.S;
     const int n = blockIdx.x / blocks_per_image;
     const int cell0 = (blockIdx.x - n * blocks_per_image) * LOSS_CELLS;
@@ -55,8 +60,8 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int bl
         const float *src = p.out + ((long long)n * cells + cell0) * p.out_ld;
         const int total = ncell * p.out_ld;
         int row = threadIdx.x / p.out_ld, col = threadIdx.x - row * p.out_ld;
-        const int drow = 256 / p.out_ld, dcol = 256 - drow * p.out_ld;
-        for (int i = threadIdx.x; i < total; i += 256) {
+        const int drow = nt / p.out_ld, dcol = nt - drow * p.out_ld;
+        for (int i = threadIdx.x; i < total; i += nt) {
             if (col < nch) s_rows[row * pitch + col] = src[i];
             row += drow;
             col += dcol;
@@ -68,7 +73,7 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int bl
     const int h_first = cell0 / p.S, h_last = (cell0 + ncell - 1) / p.S;
     if (p.iou_aware) {
         const int nrows = h_last - h_first + 1;
-        for (int j = threadIdx.x; j < nrows * p.an; j += 256) {
+        for (int j = threadIdx.x; j < nrows * p.an; j += nt) {
             const int a = j / nrows, hh = h_first + (j - a * nrows);
             const float *trow = p.target + ((long long)(n * p.an + a) * (6 + p.C) + 5) * cells + hh * p.S;
             float T = 0.f;
@@ -77,8 +82,9 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int bl
         }
     }
     __syncthreads();
-    const int a = threadIdx.x / LOSS_CELLS, lc = threadIdx.x - a * LOSS_CELLS;
-    const bool active = a < p.an && lc < ncell;
+    const int grp = threadIdx.x / LOSS_CELLS, lc = threadIdx.x - grp * LOSS_CELLS;
+    const int qq = grp / p.an, a = grp - qq * p.an;          // (wave-uniform)
+    const bool active = lc < ncell;
     float dmax = 0.f;
     float l6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -93,7 +99,9 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int bl
     };
     const int base = (p.iou_aware ? p.an : 0) + a * (5 + p.C);
     const float *t = p.target + ((long long)(n * p.an + a) * (6 + p.C)) * cells + cell;
-    const float tx = t[0], ty = t[cells], tw = t[2 * cells], th = t[3 * cells], tscale = t[4 * cells], tobj = t[5 * cells];
+    const float tobj = t[5 * cells];
+    if (qq == 0) {
+    const float tx = t[0], ty = t[cells], tw = t[2 * cells], th = t[3 * cells], tscale = t[4 * cells];
     const float ts = tscale * tobj;
     const float x = o[base], y = o[base + 1], lw = o[base + 2], lh = o[base + 3], obj = o[base + 4];
     const float sx = sigm(x), sy = sigm(y);
@@ -189,47 +197,54 @@ __global__ void __launch_bounds__(256) yolo_loss_kernel(const LossArgs p, int bl
     const float l_obj = tobj * (0.f - logf(so + 1e-9f)) + noobj * (0.f - logf(1.f - so + 1e-9f));
     const float g_obj = (-tobj / (so + 1e-9f) + noobj / (1.f - so + 1e-9f)) * so * (1.f - so);
 
-    // ---- classification
-    float l_cls = 0.f;
-    for (int c = 0; c < p.C; ++c) {
-        const float sc = sigm(o[base + 5 + c]), tc = t[(long long)(6 + c) * cells];
-        l_cls += tc * (0.f - logf(sc + 1e-9f)) + (1.f - tc) * (0.f - logf(1.f - sc + 1e-9f));
-        put(base + 5 + c, tobj * (-tc / (sc + 1e-9f) + (1.f - tc) / (1.f - sc + 1e-9f)) * sc * (1.f - sc) * p.inv_n);
-    }
-    l_cls *= tobj;
     put(base, g_x * p.inv_n);
     put(base + 1, g_y * p.inv_n);
     put(base + 2, g_w * p.inv_n);
     put(base + 3, g_h * p.inv_n);
     put(base + 4, g_obj * p.inv_n);
     if (p.iou_aware) put(a, g_ioup * p.inv_n);
-    l6[0] = l_xy; l6[1] = l_wh; l6[2] = l_obj; l6[3] = l_cls; l6[4] = l_iou; l6[5] = l_ia;
+    l6[0] = l_xy; l6[1] = l_wh; l6[2] = l_obj; l6[4] = l_iou; l6[5] = l_ia;
+    }
+
+    // ---- classification: this wave's share of the classes
+    const int n0 = p.C / 10, per = (p.C - n0 + LOSS_Q - 2) / (LOSS_Q - 1);
+    const int c_lo = qq == 0 ? 0 : min(p.C, n0 + (qq - 1) * per), c_hi = qq == 0 ? n0 : min(p.C, n0 + qq * per);
+    float l_cls = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float sc = sigm(o[base + 5 + c]), tc = t[(long long)(6 + c) * cells];
+        l_cls += tc * (0.f - logf(sc + 1e-9f)) + (1.f - tc) * (0.f - logf(1.f - sc + 1e-9f));
+        put(base + 5 + c, tobj * (-tc / (sc + 1e-9f) + (1.f - tc) / (1.f - sc + 1e-9f)) * sc * (1.f - sc) * p.inv_n);
+    }
+    l6[3] = l_cls * tobj;
     }
     if (p.amax_dout) amax_track(dmax, n, p.amax_dout, blockIdx.x * 4 + (threadIdx.x >> 6));
+    // ---- the six sums: a shuffle tree inside every wave, then the waves in index order (fixed order: run-to-run identical)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s_red[j][threadIdx.x] = l6[j];
+    for (int j = 0; j < 6; ++j) {
+        float v = l6[j];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2);
+        if ((threadIdx.x & 63) == 0) s_red[grp][j] = v;
+    }
     __syncthreads();
     // ---- the gradient rows back as one contiguous stream
     {
         float *dst = p.dout + ((long long)n * cells + cell0) * p.dout_ld;
         const int total = ncell * p.dout_ld;
         int row = threadIdx.x / p.dout_ld, col = threadIdx.x - row * p.dout_ld;
-        const int drow = 256 / p.dout_ld, dcol = 256 - drow * p.dout_ld;
-        for (int i = threadIdx.x; i < total; i += 256) {
+        const int drow = nt / p.dout_ld, dcol = nt - drow * p.dout_ld;
+        for (int i = threadIdx.x; i < total; i += nt) {
             if (col < nch) dst[i] = s_rows[row * pitch + col];
             row += drow;
             col += dcol;
             if (col >= p.dout_ld) { col -= p.dout_ld; ++row; }
         }
     }
-    // ---- the workgroup's six sums: a tree over the 256 threads, fixed order
-    for (int o2 = 128; o2 > 0; o2 >>= 1) {
-        if ((int)threadIdx.x < o2)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) s_red[j][threadIdx.x] += s_red[j][threadIdx.x + o2];
-        __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = 0.f;
+        for (int g2 = 0; g2 < p.an * LOSS_Q; ++g2) v += s_red[g2][threadIdx.x];
+        p.part[(long long)blockIdx.x * 6 + threadIdx.x] = v;
     }
-    if (threadIdx.x < 6) p.part[(long long)blockIdx.x * 6 + threadIdx.x] = s_red[threadIdx.x][0];
 }
 
 // loss[j] = inv_n * sum over the workgroups' sums, fixed order: one workgroup, strided partial sums, tree
@@ -283,7 +298,7 @@ extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const floa
     const int blocks_per_image = (S * S + LOSS_CELLS - 1) / LOSS_CELLS;
     const long long blocks = (long long)N * blocks_per_image;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(yolo_loss_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p, blocks_per_image, pitch);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3((unsigned)blocks), dim3(LOSS_CELLS * an * LOSS_Q), lds, st, p, blocks_per_image, pitch);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, blocks, p.inv_n, loss6, accumulate);
     return ppy_launch_status();
 }
