@@ -114,13 +114,13 @@ struct WgradArgs {
 };
 
 // Workgroup -> (tile, tap, pixel slice).  The (k tile, c tile, tap) workgroups of ONE pixel slice read the same rows of dy and
-// x; the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (8 private L2s), so in plain (x, y, z) order the
-// 18 ... 288 workgroups of a slice fetched it into every L2 (PMC, round 3: the weight-gradient launches pulled 4 GB per step
-// through the fabric for 0.6 GB of operands, with ONE step of prefetch to hide the misses behind).  XCD-contiguous order
-// (conv_x3.hip): XCD x owns a contiguous range of virtual ids, virtual ids are slice-major -- a slice's workgroups share
-// an L2 and start together.  PPY_WGRAD_XCD=0 at build time restores the plain order.
+// x, and the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (8 private L2s): PMC (round 3) shows the
+// weight-gradient launches pulling 4 GB per step through the fabric for 0.6 GB of operands.  PPY_WGRAD_XCD=1 (build time) gives
+// XCD x a contiguous range of slice-major virtual ids (conv_x3.hip's order), so that a slice's workgroups share one L2 --
+// measured and NOT kept: 99.3 instead of 93.3 us per launch on the R50 head (the fabric reads are served by the Infinity Cache
+// and were not what the loop waits for; eight slices in flight spread the CUs' requests better than one).  Default: plain order.
 #ifndef PPY_WGRAD_XCD
-#define PPY_WGRAD_XCD 1
+#define PPY_WGRAD_XCD 0
 #endif
 __device__ __forceinline__ void wgrad_block(int tiles, int taps, int &tile, int &tap, int &slice) {
     int v = (int)blockIdx.x;
@@ -405,6 +405,171 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_x3_kernel(const WgradArgs p
 #endif
 }
 
+// ---- 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS in one workgroup (round 3; f16x2 only).
+// What bounds the kernel above is bytes through the CU's vector memory path: a step delivers 32 KB (128 channels x 32 pixels of
+// dy and of x) for 24 MFMAs per wave -- ~910 cycles of delivery at the ~36 B/clk a CU sustains against 768 cycles of MFMA, per
+// workgroup, two workgroups per CU -- and the nine taps of a 3x3 layer are nine workgroups that each fetch and split the same
+// dy tile and overlapping windows of x.  Here a workgroup owns 128 output channels x 32 input channels x 9 taps:
+//   * dy tile split ONCE for nine taps; x: thread (row shift r, pixel quad, channel group) loads the SIX pixels wo0-1 .. wo0+4
+//     of row ho+r-1, splits them once, and builds the three column-shifted quads of the taps (r, 0..2) in registers (the middle
+//     one with two v_alignbit per plane) -- 34 KB per step for 54 MFMAs per wave: 2.4x fewer bytes per MFMA, 1.4x fewer
+//     operand splits;
+//   * so that a quad never straddles an image row the reduction runs over VIRTUAL pixels of rows padded to a multiple of 4
+//     (19 -> 20: the padding pixels carry dy = 0);
+//   * same LDS operand layout ([plane][channel][pixel], 80-byte pitch), same three products in the same order, 144 accumulator
+//     registers per lane, 66.5 KB of LDS: two workgroups per CU.
+constexpr int W9_TK = 128, W9_TC = 32;
+constexpr int W9_SA = 2 * W9_TK * X3_PITCH, W9_SBT = 2 * W9_TC * X3_PITCH;      // dy planes; x planes of ONE tap
+struct Wgrad9Args {
+    const float *x, *dy;
+    float *out;
+    int x_ld, dy_ld;
+    int N, H, W, Wp, C, K;
+    int Pv, pix_per_slice, tiles_c;
+    const float *amax_x, *amax_dy;
+};
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad9_kernel(const Wgrad9Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem9[];
+    char *sA = smem9, *sB = smem9 + W9_SA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, slice = blockIdx.y;
+    const int tk = tile / p.tiles_c, tc = tile - tk * p.tiles_c;
+    const int k0 = tk * W9_TK, c0 = tc * W9_TC;
+    const int p_begin = slice * p.pix_per_slice, p_end = min(p_begin + p.pix_per_slice, p.Pv);
+    const int hwp = p.H * p.Wp;
+    // loader roles.  dy: pixel quad pq, channel group cg (4 of the 128 channels).  x (threads 0 .. 191): row shift xr, pixel quad
+    // xpq, channel group xcg (4 of the 32 channels)
+    const int pq = tid & 7, cg = tid >> 3;
+    const int xr = tid >> 6, xpq = lane & 7, xcg = lane >> 3;
+    const bool a_ok = k0 + cg * 4 < p.K, x_thread = tid < 192;
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    floatx4 ra[4], rb[6];
+    auto fetch = [&](int vbase) {
+        {   // dy: the four pixels of this thread's quad
+            const int v0 = vbase + pq * 4;
+            const int n = v0 / hwp, rem = v0 - n * hwp;
+            const int ho = rem / p.Wp, wo0 = rem - ho * p.Wp;
+            const float *row = p.dy + (((long long)n * p.H + ho) * p.W + wo0) * p.dy_ld + k0 + cg * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (a_ok && v0 < p_end && wo0 + q < p.W) ra[q] = *reinterpret_cast<const floatx4 *>(row + (long long)q * p.dy_ld);
+            }
+        }
+        if (x_thread) {
+            const int v0 = vbase + xpq * 4;
+            const int n = v0 / hwp, rem = v0 - n * hwp;
+            const int ho = rem / p.Wp, wo0 = rem - ho * p.Wp;
+            const int yi = ho + xr - 1;
+            const bool rok = v0 < p_end && (unsigned)yi < (unsigned)p.H;
+            const float *row = p.x + (((long long)n * p.H + yi) * p.W + wo0) * p.x_ld + c0 + xcg * 4;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                rb[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (rok && (unsigned)(wo0 + j - 1) < (unsigned)p.W) rb[j] = *reinterpret_cast<const floatx4 *>(row + (long long)(j - 1) * p.x_ld);
+            }
+        }
+    };
+    float s_dy, s_x, inv_dy, inv_x;
+    s_dy = tensor_scale(p.amax_dy, p.N * AMAX_SLOTS, lane, &inv_dy);
+    s_x = tensor_scale(p.amax_x, p.N * AMAX_SLOTS, lane, &inv_x);
+    auto stage = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float va[4] = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+            uintx2_t ta[2];
+            split4_f16(va, s_dy, ta);
+            const int row = cg * 4 + e;
+            *reinterpret_cast<uintx2_t *>(sA + (0 * W9_TK + row) * X3_PITCH + pq * 8) = ta[0];
+            *reinterpret_cast<uintx2_t *>(sA + (1 * W9_TK + row) * X3_PITCH + pq * 8) = ta[1];
+        }
+        if (x_thread) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned P[3], Q[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float u0 = rb[2 * j][e], u1 = rb[2 * j + 1][e];
+                    P[j] = cvt_pk_f16(u0 * s_x, u1 * s_x);
+                    Q[j] = cvt_pk_f16(fmaf(u0, s_x, -f16_lo(P[j])), fmaf(u1, s_x, -f16_hi(P[j])));
+                }
+                const int row = xcg * 4 + e;
+                char *b0 = sB + (xr * 3) * W9_SBT + row * X3_PITCH + xpq * 8;
+                // tap (xr, 0): pixels wo-1 = loaded 0..3; (xr, 1): loaded 1..4; (xr, 2): loaded 2..5
+                *reinterpret_cast<uintx2_t *>(b0) = uintx2_t{P[0], P[1]};
+                *reinterpret_cast<uintx2_t *>(b0 + W9_TC * X3_PITCH) = uintx2_t{Q[0], Q[1]};
+                *reinterpret_cast<uintx2_t *>(b0 + W9_SBT) = uintx2_t{__builtin_amdgcn_alignbit(P[1], P[0], 16), __builtin_amdgcn_alignbit(P[2], P[1], 16)};
+                *reinterpret_cast<uintx2_t *>(b0 + W9_SBT + W9_TC * X3_PITCH) =
+                    uintx2_t{__builtin_amdgcn_alignbit(Q[1], Q[0], 16), __builtin_amdgcn_alignbit(Q[2], Q[1], 16)};
+                *reinterpret_cast<uintx2_t *>(b0 + 2 * W9_SBT) = uintx2_t{P[1], P[2]};
+                *reinterpret_cast<uintx2_t *>(b0 + 2 * W9_SBT + W9_TC * X3_PITCH) = uintx2_t{Q[1], Q[2]};
+            }
+        }
+    };
+    const int frow = lane & 31, fh = lane >> 5;
+    fetch(p_begin);
+    for (int v = p_begin; v < p_end; v += X3_PIX) {
+        __syncthreads();                        // everybody has finished reading the previous step
+        stage();
+        __syncthreads();
+        fetch(v + X3_PIX);                      // next step's global loads fly under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uintx4_t fa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                fa[t] = *reinterpret_cast<const uintx4_t *>(sA + (t * W9_TK + wave * 32 + frow) * X3_PITCH + ks * 32 + fh * 16);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                uintx4_t fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    fb[t] = *reinterpret_cast<const uintx4_t *>(sB + tap * W9_SBT + (t * W9_TC + frow) * X3_PITCH + ks * 32 + fh * 16);
+                // the three leading products, smallest first (as conv_wgrad_x3_kernel<true>): lo x hi, hi x lo, hi x hi
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[1]), __builtin_bit_cast(f16x8, fb[0]), acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, fb[1]), acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, fb[0]), acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    float *out = p.out + (long long)slice * p.K * 9 * p.C;
+    const int c = c0 + frow;
+    const float inv = inv_dy * inv_x;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = k0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (k < p.K && c < p.C) out[((long long)k * 9 + tap) * p.C + c] = acc[tap][e] * inv;
+        }
+#endif
+}
+
+// virtual pixels (rows padded to a multiple of 4) and slice count of the nine-tap kernel: ~2 workgroups per CU in one round,
+// at least 8 steps per slice, at most 64 slices (the partial sums are written and read once each)
+static int wgrad9_slices(int K, int C, int Pv) {
+    const int tiles = ceil_div(K, W9_TK) * (C / W9_TC);
+    int sl = ceil_div(512, tiles);
+    const int maxsl = Pv / 256 > 0 ? Pv / 256 : 1;
+    if (sl > maxsl) sl = maxsl;
+    if (sl > 64) sl = 64;
+    return sl < 1 ? 1 : sl;
+}
+static bool wgrad9_applies(int C, int R, int S, int stride, int pad) {
+    const char *sw = getenv("PPY_WGRAD9");      // A/B switch, read per call (tests compare the two kernels)
+    const bool off = sw && sw[0] == '0';
+    return !off && R == 3 && S == 3 && stride == 1 && pad == 1 && C % W9_TC == 0;
+}
+
 // dw[i] = sum over the slices in index order (a fixed summation order: run-to-run identical results)
 __global__ void __launch_bounds__(256) wgrad_combine_kernel(const float *part, float *dw, long long n, int slices) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -525,7 +690,11 @@ extern "C" size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, i
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0) return 0;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
-    const int sl = wgrad_slices(K, C, R, S, N * Ho * Wo);
+    int sl = wgrad_slices(K, C, R, S, N * Ho * Wo);
+    if (wgrad9_applies(C, R, S, stride, pad)) {
+        const int s9 = wgrad9_slices(K, C, N * H * ((W + 3) / 4 * 4));
+        if (s9 > sl) sl = s9;
+    }
     return sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
 }
 
@@ -543,7 +712,7 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     p.P = N * Ho * Wo;
     p.amax_x = amax_x; p.amax_dy = amax_dy;
     const int sl = wgrad_slices(K, C, R, S, p.P);
-    const size_t need = sl > 1 ? (size_t)sl * K * R * S * C * 4 : 0;
+    const size_t need = ppy_conv2d_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad);
     if (need && (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0)) return PPY_ERR_WORKSPACE;
     // the bf16x3 kernel reads whole float4 channel groups: pixel strides and base pointers 16-byte aligned, and the last group
     // of a tensor whose channel count is not a multiple of 4 must be readable up to the multiple (what lies there only
@@ -561,7 +730,29 @@ extern "C" int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, i
     hipStream_t st = (hipStream_t)stream;
     PPY_CHECK_ARG((long long)p.tiles_kc * R * S * slices < (1LL << 31));
     const dim3 grid(p.tiles_kc * R * S * slices);
-    if (x3 && amax_x && amax_dy) {
+    if (x3 && amax_x && amax_dy && wgrad9_applies(C, R, S, stride, pad)) {
+        Wgrad9Args q;
+        q.x = x; q.dy = dy; q.x_ld = x_ld; q.dy_ld = dy_ld; q.N = N; q.H = H; q.W = W; q.Wp = (W + 3) / 4 * 4; q.C = C; q.K = K;
+        q.Pv = N * H * q.Wp;
+        q.amax_x = amax_x; q.amax_dy = amax_dy;
+        const int s9 = wgrad9_slices(K, C, q.Pv);
+        q.pix_per_slice = ceil_div(ceil_div(q.Pv, s9), X3_PIX) * X3_PIX;
+        const int slices9 = ceil_div(q.Pv, q.pix_per_slice);
+        q.tiles_c = C / W9_TC;
+        q.out = slices9 > 1 ? (float *)ws : dw_krsc;
+        static PpyLdsAttr attr9;
+        const int lds9 = W9_SA + 9 * W9_SBT;
+        if (ppy_lds_attr(attr9, (const void *)conv_wgrad9_kernel, lds9) != PPY_OK) return PPY_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(ceil_div(K, W9_TK) * q.tiles_c, slices9), dim3(256), lds9, st, q);
+        int rc9 = ppy_launch_status();
+        if (rc9 != PPY_OK) return rc9;
+        if (slices9 > 1) {
+            const long long n = (long long)K * 9 * C;
+            hipLaunchKernelGGL(wgrad_combine_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, (const float *)ws, dw_krsc, n, slices9);
+            rc9 = ppy_launch_status();
+        }
+        return rc9;
+    } else if (x3 && amax_x && amax_dy) {
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(256), 0, st, p);
     } else if (x3) {
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<false>, grid, dim3(256), 0, st, p);

@@ -437,76 +437,132 @@ __global__ void __launch_bounds__(256) spp_bwd_kernel(const float *dy, int dy_ld
     dx[(((long long)n * H + h) * W + w) * dx_ld + c] = g;
 }
 
-// Round 3: both steps in ONE launch when an image's map fits the LDS: a workgroup owns (image, SPP_CG channels), stages x,
-// finds the three argmax maps IN LDS (same scan, same tie rule) and gathers from them -- no workspace traffic, 1 launch instead
-// of 4.  The loops are LDS-latency chains (a read, a compare), so the two things that matter are waves per CU -- SPP_CG = 4:
-// 14 KB of LDS per workgroup, 1024 workgroups for the 19x19x512 map of the 608 input (a first version with 16 channels per
-// workgroup ran ONE wave per SIMD and took 1055 us against 388 us for the four launches) -- and a row of a window as ONE
-// batch of independent reads (fixed trip count 2r+1 with a validity flag instead of lane-dependent bounds).  Same order of
-// additions as the four-launch form.
+// Round 3: ONE launch when an image's map fits the LDS, and 86 window visits per element instead of 550.  A workgroup owns
+// (image, SPP_CG channels) and keeps everything in LDS.  The pools are nested -- a 9x9 window is the union of the nine 5x5
+// windows centred at offsets {-2, 0, 2}^2 from its centre, a 13x13 window the union of nine 9x9 windows (centres outside the
+// image add nothing: their in-image part lies inside a neighbour's) -- and "the FIRST maximum in scan order" composes: the
+// first position of the big window attaining its maximum is the first position of every sub-window that contains it, so it is
+// the smallest index among the sub-windows' own argmaxes with the maximal value.  Forward: argmax of the 5x5 windows (25
+// visits), then which of its nine sub-windows a 9x9 / 13x13 window selects (9 + 9 visits).  Backward the other way round:
+// a 13x13 window's gradient goes to the 9x9 sub-window it selected, that one's total to its 5x5 sub-window, that one's to its
+// argmax -- 9 + 9 + 25 visits, every sum in a fixed order.  (NaN inputs: the 5x5 level keeps torch's rule; above it NaN maxima
+// never win -- the four-launch form below is NaN-faithful at every level.)  Two earlier fused forms that visited all
+// 25 + 81 + 169 window elements twice from LDS took 1055 us (16 channels per workgroup: one wave per SIMD) and 416 us (4
+// channels) against 388 us for the four launches: the visits, not where they are served from, are the cost.
 constexpr int SPP_CG = 4;
 __global__ void __launch_bounds__(256) spp_bwd_fused_kernel(const float *x, int x_ld, const float *dy, int dy_ld, float *dx, int dx_ld,
                                                             int H, int W, int C) {
     extern __shared__ float spp_smem[];
-    const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * SPP_CG;
-    float *sx = spp_smem;                                                  // [HW][SPP_CG]
-    short *sarg = reinterpret_cast<short *>(spp_smem + HW * SPP_CG);       // [3][HW][SPP_CG]
-    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+    const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * SPP_CG, E = HW * SPP_CG;
+    float *sx = spp_smem, *m5 = sx + E, *m9 = m5 + E, *g9 = m9 + E, *g5 = g9 + E;      // [HW][SPP_CG] each
+    short *a5 = reinterpret_cast<short *>(g5 + E), *a9 = a5 + E, *s9 = a9 + E, *s13 = s9 + E;
+    for (int i = threadIdx.x; i < E; i += 256) {
         const int c = i % SPP_CG, q = i / SPP_CG;
         sx[i] = c0 + c < C ? x[((long long)n * HW + q) * x_ld + c0 + c] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+    // ---- 5x5: torch's CPU kernel -- maxval = -inf, index = first element of the window; take v when v > maxval or isnan(v)
+    for (int i = threadIdx.x; i < E; i += 256) {
         const int c = i % SPP_CG, q = i / SPP_CG;
         const int h = q / W, w = q - h * W;
+        const int h0 = max(h - 2, 0), h1 = min(h + 2, H - 1);
+        float best = -__builtin_huge_valf();
+        int bi = h0 * W + max(w - 2, 0);
+        for (int hh = h0; hh <= h1; ++hh) {
+            float v[5];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int r = 2 + 2 * b;
-            const int h0 = max(h - r, 0), h1 = min(h + r, H - 1);
-            float best = -__builtin_huge_valf();
-            int bi = h0 * W + max(w - r, 0);
-            for (int hh = h0; hh <= h1; ++hh) {
-                float v[13];
+            for (int j = 0; j < 5; ++j) v[j] = sx[(hh * W + min(max(w - 2 + j, 0), W - 1)) * SPP_CG + c];
 #pragma unroll
-                for (int j = 0; j <= 2 * r; ++j) {
-                    const int ww = min(max(w - r + j, 0), W - 1);
-                    v[j] = sx[(hh * W + ww) * SPP_CG + c];
-                }
-#pragma unroll
-                for (int j = 0; j <= 2 * r; ++j) {
-                    const int ww = w - r + j;
-                    if ((unsigned)ww < (unsigned)W && (v[j] > best || v[j] != v[j])) {
-                        best = v[j];
-                        bi = hh * W + ww;
-                    }
+            for (int j = 0; j < 5; ++j) {
+                const int ww = w - 2 + j;
+                if ((unsigned)ww < (unsigned)W && (v[j] > best || v[j] != v[j])) {
+                    best = v[j];
+                    bi = hh * W + ww;
                 }
             }
-            sarg[(b * HW + q) * SPP_CG + c] = (short)bi;
         }
+        m5[i] = best;
+        a5[i] = (short)bi;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HW * SPP_CG; i += 256) {
+    // ---- 9x9 from the nine 5x5 sub-windows, 13x13 from the nine 9x9 ones: larger value, then smaller (= earlier) argmax index
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        const float *mv = lvl ? m9 : m5;
+        const short *av = lvl ? a9 : a5;
+        for (int i = threadIdx.x; i < E; i += 256) {
+            const int c = i % SPP_CG, q = i / SPP_CG;
+            const int h = q / W, w = q - h * W;
+            float best = -__builtin_huge_valf();
+            int bi = 0x7fffffff, bc = q;
+#pragma unroll
+            for (int dh = -2; dh <= 2; dh += 2)
+#pragma unroll
+                for (int dw = -2; dw <= 2; dw += 2) {
+                    const int hh = h + dh, ww = w + dw;
+                    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+                        const int o = hh * W + ww;
+                        const float v = mv[o * SPP_CG + c];
+                        const int ai = av[o * SPP_CG + c];
+                        if (v > best || (v == best && ai < bi) || bi == 0x7fffffff) {
+                            best = v;
+                            bi = ai;
+                            bc = o;
+                        }
+                    }
+                }
+            if (lvl == 0) {
+                m9[i] = best;
+                a9[i] = (short)bi;
+                s9[i] = (short)bc;
+            } else {
+                s13[i] = (short)bc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- backward: 13x13 -> its 9x9 sub-window -> its 5x5 sub-window -> the argmax
+    const float *dyn = dy + (long long)n * HW * dy_ld + c0;
+    for (int lvl = 1; lvl >= 0; --lvl) {
+        const short *sel = lvl ? s13 : s9;
+        float *gout = lvl ? g9 : g5;
+        for (int i = threadIdx.x; i < E; i += 256) {
+            const int c = i % SPP_CG, q = i / SPP_CG;
+            const int h = q / W, w = q - h * W;
+            const bool live = c0 + c < C;
+            float g = live ? dyn[(long long)q * dy_ld + (lvl ? 2 : 1) * C + c] : 0.f;      // the 9x9 / 5x5 branch's own gradient
+#pragma unroll
+            for (int dh = -2; dh <= 2; dh += 2)
+#pragma unroll
+                for (int dw = -2; dw <= 2; dw += 2) {
+                    const int hh = h - dh, ww = w - dw;                                  // the window whose sub-window (dh, dw) is centred here
+                    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+                        const int o = hh * W + ww;
+                        if (sel[o * SPP_CG + c] == q) g += lvl ? (live ? dyn[(long long)o * dy_ld + 3 * C + c] : 0.f) : g9[o * SPP_CG + c];
+                    }
+                }
+            gout[i] = g;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < E; i += 256) {
         const int c = i % SPP_CG, q = i / SPP_CG;
         if (c0 + c >= C) continue;
         const int h = q / W, w = q - h * W;
-        const float *dyn = dy + (long long)n * HW * dy_ld + c0 + c;
-        float g = dyn[(long long)q * dy_ld];
+        float g = dyn[(long long)q * dy_ld + c];                                          // identity branch
+        const int h0 = max(h - 2, 0), h1 = min(h + 2, H - 1);
+        for (int hh = h0; hh <= h1; ++hh) {
+            short a[5];
+            float gv[5];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int r = 2 + 2 * b;
-            const int h0 = max(h - r, 0), h1 = min(h + r, H - 1);
-            for (int hh = h0; hh <= h1; ++hh) {
-                short a[13];
+            for (int j = 0; j < 5; ++j) {
+                const int o = hh * W + min(max(w - 2 + j, 0), W - 1);
+                a[j] = a5[o * SPP_CG + c];
+                gv[j] = g5[o * SPP_CG + c];
+            }
 #pragma unroll
-                for (int j = 0; j <= 2 * r; ++j) {
-                    const int ww = min(max(w - r + j, 0), W - 1);
-                    a[j] = sarg[(b * HW + hh * W + ww) * SPP_CG + c];
-                }
-#pragma unroll
-                for (int j = 0; j <= 2 * r; ++j) {
-                    const int ww = w - r + j;
-                    if ((unsigned)ww < (unsigned)W && a[j] == q) g += dyn[(long long)(hh * W + ww) * dy_ld + (b + 1) * C];
-                }
+            for (int j = 0; j < 5; ++j) {
+                const int ww = w - 2 + j;
+                if ((unsigned)ww < (unsigned)W && a[j] == q) g += gv[j];
             }
         }
         dx[((long long)n * HW + q) * dx_ld + c0 + c] = g;
@@ -858,7 +914,7 @@ extern "C" int ppy_spp_bwd_f32(const float *x, int x_ld, const float *dy, int dy
     const long long n = (long long)N * H * W * C;
     short *a5 = (short *)ws, *a9 = a5 + n, *a13 = a9 + n;
     hipStream_t st = (hipStream_t)stream;
-    const int lds = H * W * SPP_CG * (int)(sizeof(float) + 3 * sizeof(short));
+    const int lds = H * W * SPP_CG * (int)(5 * sizeof(float) + 4 * sizeof(short));
     if (lds <= 150 * 1024 && N <= 65535) {
         static PpyLdsAttr attr;
         if (ppy_lds_attr(attr, (const void *)spp_bwd_fused_kernel, lds) != PPY_OK) return PPY_ERR_LAUNCH;

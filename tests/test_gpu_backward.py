@@ -102,6 +102,41 @@ def test_wgrad_f16x2_with_tracked_maxima():
         assert err['f16x2'] <= max(2.0 * err['bf16x3'], 2e-6) and err['f16x2'] <= 1e-5
 
 
+def test_wgrad_nine_tap_kernel_edge_shapes():
+    """Round 3: 3x3 / stride 1 weight gradients run with all nine taps in one workgroup (conv_wgrad9_kernel: rows padded to a
+    multiple of 4 as virtual pixels, column-shifted quads built in registers).  Against float64 and against the one-tap kernel
+    (PPY_WGRAD9=0) on shapes with W % 4 != 0, one-row / one-column maps, a K tail, several 32-channel tiles, channel slices of
+    wider buffers, and more pixels than one slice."""
+    import os
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(29)
+    for (N, H, W, C, K) in ((2, 7, 10, 32, 72), (1, 1, 5, 64, 128), (3, 6, 1, 32, 40), (2, 19, 19, 96, 260), (8, 38, 38, 64, 128)):
+        x = torch.randn(N, H, W, C, generator=g) * torch.tensor([1.0, 30.0, 0.02, 5.0, 1.0, 2.0, 0.5, 1.0][:N]).view(N, 1, 1, 1)
+        dy = torch.randn(N, H, W, K, generator=g) * torch.exp(torch.randn(N, H, W, K, generator=g) * 2.0) * 1e-3
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (K, C, 3, 3), dy.permute(0, 3, 1, 2).double(), stride=1,
+                                          padding=1).permute(0, 2, 3, 1)
+        xw = torch.randn(N, H, W, C + 32, generator=g).cuda()
+        xw[..., 16:16 + C] = x.cuda()
+        Kp = (K + 3) // 4 * 4
+        dyw = torch.zeros(N, H, W, Kp + 8).cuda()
+        dyw[..., 4:4 + K] = dy.cuda()
+        xv, dyv = ops.View(xw, 16, C), ops.View(dyw, 4, K)
+        ax, ady = ops.amax_slots(x.cuda()), ops.amax_slots(dy.cuda())
+        err = {}
+        for form in ('1', '0'):
+            os.environ['PPY_WGRAD9'] = form
+            try:
+                dw = torch.full((K, 3, 3, C), float('nan'), device='cuda')
+                ops.conv2d_wgrad(xv, dyv, dw, 1, 1, amax_x=ax, amax_dy=ady)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop('PPY_WGRAD9', None)
+            err[form] = float((dw.cpu().double() - ref).abs().max() / ref.abs().max())
+        print('wgrad 3x3 N%d %dx%d C%d K%d: max error / max|dw| vs float64: nine taps %.2e, one tap per workgroup %.2e'
+              % (N, H, W, C, K, err['1'], err['0']))
+        assert err['1'] <= max(2.0 * err['0'], 2e-6) and err['1'] <= 1e-5
+
+
 def test_dgrad_f16x2_with_tracked_maxima():
     """The data gradient on the f16x2 kernels (dy scaled per image by its tracked maximum, the flipped weights per channel)
     against float64: at the level of the bf16x3 path, incl. a 258-channel dy (padded copy) and images of very different scale."""
