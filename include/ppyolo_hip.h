@@ -196,6 +196,33 @@ int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_krsc, float 
                          size_t ws_bytes, void *stream);
 size_t ppy_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int cfg,
                                         int splitk);
+/* Round 3: the f16x2 operand forms of ALL trainable convolution weights in three launches per step instead of two or three
+ * per layer (train.py:442 `optimizer.step()` changes every weight every iteration, so the forward planes and the flipped /
+ * transposed planes of the data gradients are rebuilt every step: 47 launches of 7-15 us for the R50vd head).
+ *   desc[i]: one weight tensor [K][R][S][C] (C % 32 == 0).  fwd_planes / fwd_scale: exactly what
+ *   ppy_conv2d_split_weights_f16x2(w, K, R*S*C, ones, ...) writes.  dgrad_planes / dgrad_scale / dgrad_wt (all three or none):
+ *   w'[c][r'][s'][k] = w[k][R-1-r'][S-1-s'][c], K padded with zeros to Kp = K rounded up to 32 -- the planes
+ *   [2][R*S*Kp/32][C][32], per-row scales [C] and fp32 copy [C][R][S][Kp] that ppy_conv2d_dgrad_f32 builds in its workspace
+ *   (bit-identical).  row0 / blk0: prefix sums over the descriptors of K and of (C / 32) * PPY_PREP_SPLIT.  The table lives in
+ *   device memory.  colmax: scratch of blocks_total * 32 floats.
+ *   ppy_conv2d_dgrad_prepared_f32 = ppy_conv2d_dgrad_f32 (stride 1, f16x2: amax_dy required) on such buffers; ones / zeros: [C]
+ *   constants; workspace as ppy_conv2d_dgrad_workspace_bytes says (the padded copy of a dy with K % 32 != 0, split-K). */
+#define PPY_PREP_SPLIT 8
+typedef struct PpyWeightPrep {
+    const float *w;
+    void *fwd_planes;
+    float *fwd_scale;
+    void *dgrad_planes;
+    float *dgrad_scale;
+    float *dgrad_wt;
+    int K, R, S, C;
+    int row0, blk0;
+} PpyWeightPrep;
+int ppy_train_prepare_weights_f16x2(const PpyWeightPrep *desc_dev, int count, int rows_total, int blocks_total, float *colmax,
+                                    size_t colmax_bytes, void *stream);
+int ppy_conv2d_dgrad_prepared_f32(const float *dy, int dy_ld, const float *wt, const void *planes, const float *scale_f16x2,
+                                  const float *ones, const float *zeros, float *dx, int dx_ld, int N, int H, int W, int C, int K, int R,
+                                  int S, int pad, int cfg, int splitk, const float *amax_dy, void *ws, size_t ws_bytes, void *stream);
 int ppy_conv2d_wgrad_f32(const float *x, int x_ld, const float *dy, int dy_ld, float *dw_krsc, int N, int H, int W,
                          int C, int K, int R, int S, int stride, int pad, const float *amax_x, const float *amax_dy, void *ws,
                          size_t ws_bytes, void *stream);

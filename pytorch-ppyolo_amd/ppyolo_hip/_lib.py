@@ -48,6 +48,9 @@ _PROTOS = {
     'ppy_conv2d_pick': (c_int, [c_int] * 9 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'ppy_conv2d_dgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_int] * 11 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int] * 11),
+    'ppy_train_prepare_weights_f16x2': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'ppy_conv2d_dgrad_prepared_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 10
+                                      + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_wgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int] * 9),
     'ppy_bn_train_workspace_bytes': (c_size_t, [c_int, c_int]),

@@ -95,6 +95,128 @@ __global__ void __launch_bounds__(256) dgrad_weights_f16_kernel(const float *w, 
     }
 }
 
+// ---- the same products for ALL trainable weights of a step (ppy_train_prepare_weights_f16x2): three launches.
+// prep_fwd_kernel: one workgroup per row k of some tensor = conv_x3.hip's split_weights_f16_kernel with scale = 1.
+// prep_colmax_kernel / prep_dgrad_kernel: workgroup (tensor, 32 consecutive c, row split); a unit = (tap', 32 k): the 32 x 32
+// tile w[k][R-1-r'][S-1-s'][c] is read as 32 rows of 128 contiguous bytes, turned in LDS and leaves as 2 KB of contiguous plane
+// bytes per plane (and 32 x 128 B of the fp32 copy) -- dgrad_weights_f16_kernel reads the same tensor with one 4-byte load
+// per line.  Same scale rule and the same two roundings: bit-identical planes.
+__device__ __forceinline__ int prep_find(const PpyWeightPrep *d, int count, int id, bool rows) {
+    int t = 0;
+    while (t + 1 < count && (rows ? d[t + 1].row0 : d[t + 1].blk0) <= id) ++t;
+    return t;
+}
+__global__ void __launch_bounds__(256) prep_fwd_kernel(const PpyWeightPrep *desc, int count) {
+    __shared__ float smax[4];
+    const int t = prep_find(desc, count, (int)blockIdx.x, true);
+    const PpyWeightPrep d = desc[t];
+    const int k = (int)blockIdx.x - d.row0, tid = threadIdx.x, K = d.K;
+    const long long kred = (long long)d.R * d.S * d.C;
+    const float *row = d.w + (long long)k * kred;
+    unsigned short *out = (unsigned short *)d.fwd_planes;
+    float mx = 0.f;
+    for (long long i = tid; i < kred; i += 256) mx = fmaxf(mx, fabsf(row[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) smax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    int f = 267 - e;
+    f = f < 103 ? 103 : (f > 167 ? 167 : f);
+    const float sw = __uint_as_float((unsigned)f << 23), inv = __uint_as_float((unsigned)(254 - f) << 23);
+    const long long n = (long long)K * kred;
+    for (long long i = tid; i < kred; i += 256) {
+        const float v = row[i] * sw;
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)(v - (float)h0);
+        const long long o = PPY_X3_BBLOCK ? ((i >> 5) * K + k) * 32 + (i & 31) : (long long)k * kred + i;
+        out[o] = __builtin_bit_cast(unsigned short, h0);
+        out[n + o] = __builtin_bit_cast(unsigned short, h1);
+    }
+    if (tid == 0) d.fwd_scale[k] = inv;
+}
+// units of a (tensor, split): u = split, split + PPY_PREP_SPLIT, ... < R * S * (Kp / 32); unit u = (tap' = u / kchunks, kc = u % kchunks)
+__global__ void __launch_bounds__(256) prep_colmax_kernel(const PpyWeightPrep *desc, int count, float *colmax) {
+    __shared__ float red[8][32];
+    const int t = prep_find(desc, count, (int)blockIdx.x, false);
+    const PpyWeightPrep d = desc[t];
+    const int local = (int)blockIdx.x - d.blk0, cgrp = local / PPY_PREP_SPLIT, sp = local - cgrp * PPY_PREP_SPLIT;
+    const int c = cgrp * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+    const int kchunks = (d.K + 31) / 32, units = d.R * d.S * kchunks;
+    float mx = 0.f;
+    if (d.dgrad_planes)
+        for (int u = sp; u < units; u += PPY_PREP_SPLIT) {
+            const int tap = u / kchunks, kc = u - tap * kchunks;       // (max over all taps: the flip does not matter here)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kc * 32 + kl + 8 * j;
+                if (k < d.K) mx = fmaxf(mx, fabsf(d.w[((long long)k * d.R * d.S + tap) * d.C + c]));
+            }
+        }
+    red[kl][threadIdx.x & 31] = mx;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, red[j][threadIdx.x]);
+        colmax[(long long)blockIdx.x * 32 + threadIdx.x] = mx;
+    }
+}
+__global__ void __launch_bounds__(256) prep_dgrad_kernel(const PpyWeightPrep *desc, int count, const float *colmax) {
+    __shared__ float tile[32][33], ssw[32];
+    const int t = prep_find(desc, count, (int)blockIdx.x, false);
+    const PpyWeightPrep d = desc[t];
+    if (!d.dgrad_planes) return;
+    const int local = (int)blockIdx.x - d.blk0, cgrp = local / PPY_PREP_SPLIT, sp = local - cgrp * PPY_PREP_SPLIT;
+    const int c0 = cgrp * 32, tid = threadIdx.x;
+    const int Kp = (d.K + 31) / 32 * 32, kchunks = Kp / 32, units = d.R * d.S * kchunks;
+    if (tid < 32) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < PPY_PREP_SPLIT; ++j) mx = fmaxf(mx, colmax[((long long)(d.blk0 + cgrp * PPY_PREP_SPLIT + j)) * 32 + tid]);
+        const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        int f = 267 - e;
+        f = f < 103 ? 103 : (f > 167 ? 167 : f);
+        ssw[tid] = __uint_as_float((unsigned)f << 23);
+        if (sp == 0) d.dgrad_scale[c0 + tid] = __uint_as_float((unsigned)(254 - f) << 23);
+    }
+    __syncthreads();
+    unsigned short *planes = (unsigned short *)d.dgrad_planes;
+    const long long n = (long long)d.C * d.R * d.S * Kp;
+    const int lc = tid & 31, kl = tid >> 5;              // read role: column (channel) lc, rows kl + 8 j
+    const int wc = tid >> 3, kq = (tid & 7) * 4;         // write role: channel wc, four consecutive k
+    for (int u = sp; u < units; u += PPY_PREP_SPLIT) {
+        const int tap = u / kchunks, kc = u - tap * kchunks;
+        const int r2 = tap / d.S, s2 = tap - r2 * d.S;
+        const int src_tap = (d.R - 1 - r2) * d.S + (d.S - 1 - s2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kc * 32 + kl + 8 * j;
+            tile[kl + 8 * j][lc] = k < d.K ? d.w[((long long)k * d.R * d.S + src_tap) * d.C + c0 + lc] : 0.f;
+        }
+        __syncthreads();
+        const float sw = ssw[wc];
+        float v[4];
+        unsigned short h0[4], h1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = tile[kq + j][wc];
+            const float x = v[j] * sw;
+            const _Float16 a = (_Float16)x;
+            const _Float16 b = (_Float16)(x - (float)a);
+            h0[j] = __builtin_bit_cast(unsigned short, a);
+            h1[j] = __builtin_bit_cast(unsigned short, b);
+        }
+        // row c of w' has kred' = R*S*Kp values, index i = tap * Kp + kc * 32 + kk: chunk i >> 5 = u, column kk
+        const long long o = PPY_X3_BBLOCK ? ((long long)u * d.C + c0 + wc) * 32 + kq : (long long)(c0 + wc) * d.R * d.S * Kp + (long long)u * 32 + kq;
+        typedef __attribute__((ext_vector_type(4))) unsigned short ushortx4;
+        *reinterpret_cast<ushortx4 *>(planes + o) = ushortx4{h0[0], h0[1], h0[2], h0[3]};
+        *reinterpret_cast<ushortx4 *>(planes + n + o) = ushortx4{h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<floatx4 *>(d.dgrad_wt + ((long long)(c0 + wc) * d.R * d.S + tap) * Kp + kc * 32 + kq) = floatx4{v[0], v[1], v[2], v[3]};
+        __syncthreads();
+    }
+}
+
 // dy [P][ld] -> padded [P][Kp] (zero channels beyond K): only when K % 32 != 0 (the 258-channel output convolutions)
 __global__ void __launch_bounds__(256) pad_channels_kernel(const float *src, int ld, float *dst, int K, int Kp, long long P) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -558,7 +680,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad9_kernel(const Wgrad9Args p)
 // at least 8 steps per slice, at most 64 slices (the partial sums are written and read once each)
 static int wgrad9_slices(int K, int C, int Pv) {
     const int tiles = ceil_div(K, W9_TK) * (C / W9_TC);
-    int sl = ceil_div(512, tiles);
+    const char *e = getenv("PPY_WGRAD9_WGS");            // (experiments: the workgroup count the slices aim at)
+    const int target = e && atoi(e) > 0 ? atoi(e) : 512;
+    int sl = ceil_div(target, tiles);
     const int maxsl = Pv / 256 > 0 ? Pv / 256 : 1;
     if (sl > maxsl) sl = maxsl;
     if (sl > 64) sl = 64;
@@ -684,6 +808,51 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
     return ppy_conv2d_bn_act_f32(src, src_ld, wt, amax_dy ? nullptr : planes, amax_dy ? planes : nullptr, ones, amax_dy ? scale_f16 : nullptr,
                                  zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0,
                                  cfg, splitk, amax_dy, nullptr, base, rest, stream);
+}
+
+extern "C" int ppy_train_prepare_weights_f16x2(const PpyWeightPrep *desc_dev, int count, int rows_total, int blocks_total, float *colmax,
+                                               size_t colmax_bytes, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(desc_dev && count > 0 && rows_total > 0 && blocks_total >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(prep_fwd_kernel, dim3(rows_total), dim3(256), 0, st, desc_dev, count);
+    if (blocks_total > 0) {
+        if (!colmax || colmax_bytes < (size_t)blocks_total * 32 * sizeof(float)) return PPY_ERR_WORKSPACE;
+        hipLaunchKernelGGL(prep_colmax_kernel, dim3(blocks_total), dim3(256), 0, st, desc_dev, count, colmax);
+        hipLaunchKernelGGL(prep_dgrad_kernel, dim3(blocks_total), dim3(256), 0, st, desc_dev, count, (const float *)colmax);
+    }
+    return ppy_launch_status();
+}
+
+extern "C" int ppy_conv2d_dgrad_prepared_f32(const float *dy, int dy_ld, const float *wt, const void *planes, const float *scale_f16x2,
+                                             const float *ones, const float *zeros, float *dx, int dx_ld, int N, int H, int W, int C, int K,
+                                             int R, int S, int pad, int cfg, int splitk, const float *amax_dy, void *ws, size_t ws_bytes,
+                                             void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(dy && wt && planes && scale_f16x2 && ones && zeros && dx && amax_dy && N > 0 && C > 0 && K > 0 && dy_ld >= K && dx_ld >= C);
+    Geometry g;
+    if (!bwd_geometry(N, H, W, C, K, R, S, 1, pad, &g)) return PPY_ERR_BAD_ARG;
+    const int Kp = (K + 31) / 32 * 32;
+    PPY_CHECK_ARG(R - 1 - pad >= 0 && (Kp != K || (dy_ld % 4 == 0 && ((uintptr_t)dy & 15) == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)ws;
+    const float *src = dy;
+    int src_ld = dy_ld;
+    if (Kp != K) {
+        const size_t pad_bytes = align256((size_t)g.M * Kp * 4);
+        if (!ws || ws_bytes < pad_bytes || ((uintptr_t)ws & 255) != 0) return PPY_ERR_WORKSPACE;
+        float *padded = (float *)base;
+        base += pad_bytes;
+        const long long n = (long long)g.M * Kp;
+        hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, dy_ld, padded, K, Kp, (long long)g.M);
+        const int rc = ppy_launch_status();
+        if (rc != PPY_OK) return rc;
+        src = padded;
+        src_ld = Kp;
+    }
+    const size_t rest = ws ? ws_bytes - (size_t)(base - (char *)ws) : 0;
+    return ppy_conv2d_bn_act_f32(src, src_ld, wt, nullptr, planes, ones, scale_f16x2, zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N, g.Ho,
+                                 g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, cfg, splitk, amax_dy, nullptr, ws ? base : nullptr, rest, stream);
 }
 
 extern "C" size_t ppy_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {

@@ -223,6 +223,73 @@ def conv2d_dgrad(dy, w_krsc, dx, stride=1, pad=0, ws=None, cfg=-1, splitk=0, ama
     return ws
 
 
+PREP_SPLIT = 8      # PPY_PREP_SPLIT (include/ppyolo_hip.h)
+
+
+class _WeightPrep(ctypes.Structure):      # PpyWeightPrep
+    _fields_ = [('w', ctypes.c_void_p), ('fwd_planes', ctypes.c_void_p), ('fwd_scale', ctypes.c_void_p), ('dgrad_planes', ctypes.c_void_p),
+                ('dgrad_scale', ctypes.c_void_p), ('dgrad_wt', ctypes.c_void_p), ('K', ctypes.c_int), ('R', ctypes.c_int), ('S', ctypes.c_int),
+                ('C', ctypes.c_int), ('row0', ctypes.c_int), ('blk0', ctypes.c_int)]
+
+
+class WeightPrepTable(object):
+    """The operand forms of a set of trainable convolution weights, rebuilt by ONE call per step (ppy_train_prepare_weights_f16x2).
+    entries: list of dicts with `w` ([K,R,S,C] fp32, contiguous, C % 32 == 0) and `dgrad` (bool).  After build(): per entry
+    `planes`, `scale` (what split_weights_f16x2 returns) and, with dgrad, `dg_planes`, `dg_scale`, `dg_wt`."""
+
+    def __init__(self, entries):
+        self.entries = entries
+        dev = entries[0]['w'].device
+        rows = blks = 0
+        arr = (_WeightPrep * len(entries))()
+        for i, e in enumerate(entries):
+            w = e['w']
+            _dev(w)
+            assert w.is_contiguous() and w.dtype == torch.float32 and w.dim() == 4 and w.shape[3] % 32 == 0
+            K, R, S, C = w.shape
+            Kp = (K + 31) // 32 * 32
+            e['planes'] = torch.empty((2, K, R, S, C), dtype=torch.int16, device=dev)
+            e['scale'] = torch.empty(K, dtype=torch.float32, device=dev)
+            if e.get('dgrad'):
+                e['dg_planes'] = torch.empty((2, C, R, S, Kp), dtype=torch.int16, device=dev)
+                e['dg_scale'] = torch.empty(C, dtype=torch.float32, device=dev)
+                e['dg_wt'] = torch.empty((C, R, S, Kp), dtype=torch.float32, device=dev)
+            arr[i] = _WeightPrep(w.data_ptr(), e['planes'].data_ptr(), e['scale'].data_ptr(),
+                                 e['dg_planes'].data_ptr() if e.get('dgrad') else None, e['dg_scale'].data_ptr() if e.get('dgrad') else None,
+                                 e['dg_wt'].data_ptr() if e.get('dgrad') else None, K, R, S, C, rows, blks)
+            rows += K
+            blks += (C // 32) * PREP_SPLIT
+        self.rows, self.blocks = rows, blks
+        raw = bytes(bytearray(arr))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.colmax = torch.empty(max(1, blks * 32), dtype=torch.float32, device=dev)
+        self.ptrs = [e['w'].data_ptr() for e in entries]
+
+    def current(self):
+        """The masters still live where the table says (a caller may have re-bound them)."""
+        return all(e['w'].data_ptr() == q for e, q in zip(self.entries, self.ptrs))
+
+    def build(self):
+        check(lib().ppy_train_prepare_weights_f16x2(self.table.data_ptr(), len(self.entries), self.rows, self.blocks, self.colmax.data_ptr(),
+                                                    self.colmax.numel() * 4, _stream()), 'ppy_train_prepare_weights_f16x2')
+
+
+def conv2d_dgrad_prepared(dy, prep, dx, pad, ones, zeros, ws, cfg=-1, splitk=0, amax_dy=None):
+    """conv2d_dgrad (stride 1, f16x2) on the flipped / transposed planes of a WeightPrepTable entry (`prep`)."""
+    _dev(dy.t, dx.t, prep['dg_planes'])
+    C, R, S, Kp = prep['dg_wt'].shape
+    K = prep['w'].shape[0]
+    assert K == dy.C and C == dx.C and amax_dy is not None
+    need = int(lib().ppy_conv2d_dgrad_workspace_bytes(dx.N, dx.H, dx.W, C, K, R, S, 1, pad, cfg, splitk))
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = _bwd_ws(need, dx.t.device)
+    check(lib().ppy_conv2d_dgrad_prepared_f32(dy.ptr, dy.ld, prep['dg_wt'].data_ptr(), prep['dg_planes'].data_ptr(), prep['dg_scale'].data_ptr(),
+                                              ones.data_ptr(), zeros.data_ptr(), dx.ptr, dx.ld, dx.N, dx.H, dx.W, C, K, R, S, pad, cfg, splitk,
+                                              _p(amax_dy), ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
+          'ppy_conv2d_dgrad_prepared_f32')
+    return ws
+
+
 def conv2d_wgrad(x, dy, dw_krsc, stride=1, pad=0, ws=None, amax_x=None, amax_dy=None):
     """x: View [N,H,W,C]; dy: View [N,Ho,Wo,K]; dw_krsc [K,R,S,C] (written); amax_x / amax_dy (both or neither): tracked per-image
     maxima of the operands (amax_slots blocks) -> the f16x2 kernel.  See ppy_conv2d_wgrad_f32."""

@@ -128,6 +128,7 @@ class TrainStep(object):
         self._wcache = {}
         self._const = {}
         self._coord_bufs = {}
+        self._prep, self._prep_done = None, False      # ops.WeightPrepTable of the trainable convolutions (built after the first step)
         self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
         self.steps_done = 0
         self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
@@ -239,6 +240,9 @@ class TrainStep(object):
             krsc[..., :Cin] = w.permute(0, 2, 3, 1)
             ent = dict(krsc=krsc, planes=None, f16=None, Cin=Cin, trainable=key in self.train_keys)
             self._wcache[key] = ent
+        if ent.get('prep') is not None:    # f16x2 planes rebuilt for all trainable weights at the start of the step (_prepare_weights)
+            ent['planes'] = None           # (bf16x3 planes, should a launch want them: split on demand from the current master)
+            return ent
         if ent['trainable'] or (ent['planes'] is None and ent['f16'] is None):
             ent['planes'] = None       # bf16x3 planes: split on demand (_planes) -- a layer on the f16x2 kernels never needs them
             if self.f16:      # (planes, per-channel epilogue scale with the weight scale folded in) for a unit scale
@@ -438,10 +442,44 @@ class TrainStep(object):
             self.acts[prefix] = y
         return y
 
-    def _dgrad(self, d_raw, krsc, dxin, stride, pad, cfg_id=-1, splitk=0, f16=False):
+    def _prepare_weights(self):
+        """Once per step, in front of the first convolution: the f16x2 operand planes of every trainable convolution weight (forward
+        layout, and the flipped / transposed one of its data gradient) in three launches (ops.WeightPrepTable) -- the optimizer changed
+        all of them.  The table is built after the first step, when the layers that ran on the f16x2 kernels are known."""
+        if self._prep_done:
+            return
+        self._prep_done = True
+        if self._prep is not None:
+            if self._prep.current():
+                self._prep.build()
+            else:                       # somebody re-bound a master copy: back to the per-layer splits, rebuild the table after this step
+                for e in self._prep.entries:
+                    self._wcache[e['key']]['prep'] = None
+                self._prep = None
+
+    def _build_prep(self):
+        ents = [(k, e) for k, e in self._wcache.items() if e['trainable'] and e.get('f16') is not None and e['krsc'].shape[3] % 32 == 0
+                and k in self.P]
+        if not (self.f16 and ents) or os.environ.get('PPYOLO_HIP_TRAIN_PREP', '1') != '1':
+            return
+        entries = [dict(key=k, w=e['krsc'], dgrad=bool(e.get('dgrad_f16'))) for k, e in ents]
+        self._prep = K.WeightPrepTable(entries)
+        for (k, e), pe in zip(ents, entries):
+            e['prep'] = pe
+            e['f16'] = (pe['planes'], pe['scale'])
+
+    def _dgrad(self, d_raw, krsc, dxin, stride, pad, cfg_id=-1, splitk=0, f16=False, ent=None):
         """Data gradient of a convolution; stride > 1 as the stride-1 data gradient of the zero-inserted output gradient.
         f16: on the f16x2 kernels, scaled by the tracked maxima of d_raw."""
         amax = d_raw.amax if f16 else None
+        if stride == 1 and f16 and ent is not None:
+            ent['dgrad_f16'] = True
+            pe = ent.get('prep')
+            if pe is not None and pe.get('dgrad'):
+                C = krsc.shape[3]
+                K.conv2d_dgrad_prepared(d_raw.view(), pe, dxin.view(), pad, self._vec('one', C, 1.0), self._vec('zero', C, 0.0), self.ws,
+                                        cfg=cfg_id, splitk=splitk, amax_dy=amax)
+                return
         if stride == 1:
             K.conv2d_dgrad(d_raw.view(), krsc, dxin.view(), 1, pad, self.ws, cfg=cfg_id, splitk=splitk, amax_dy=amax)
             return
@@ -486,7 +524,7 @@ class TrainStep(object):
             df16 = self.f16 and d_raw.amax is not None
             if stride == 1:
                 def run(cfg_id, splitk):
-                    self._dgrad(d_raw, ent['krsc'], dxin, 1, pad, cfg_id, splitk, df16)
+                    self._dgrad(d_raw, ent['krsc'], dxin, 1, pad, cfg_id, splitk, df16, ent)
                 # the data gradient runs the forward kernel on the transposed geometry: C' = K rounded up to 32, K' = C
                 run(*self._choose('conv:N%d:H%d:W%d:C%d:K%d:R%d:s1' % (raw.N, raw.H, raw.W, _r32(Kk), xin.C, R), run, R * R * _r32(Kk) // 32,
                                   df16))
@@ -761,6 +799,7 @@ class TrainStep(object):
         with torch.no_grad():
             if self.external:
                 self._pull_params()
+            self._prepare_weights()
             feats = self.backbone(x_nchw.float().contiguous())
         return self.head_loss_backward(feats, gt_box, targets, inject_douts)
 
@@ -768,6 +807,7 @@ class TrainStep(object):
         """Head forward on the given backbone features (list of Act, shallowest first), loss, backward, -> loss terms [6]."""
         cfg, hcfg = self.cfg, self.cfg.head
         with torch.no_grad():
+            self._prepare_weights()
             outs = self.head(feats)
             if self._nbt:      # BatchNorm's num_batches_tracked of every layer this forward normalised: one launch
                 torch._foreach_add_(self._nbt, 1)
@@ -792,6 +832,9 @@ class TrainStep(object):
                 fn()
         self.outs = outs
         self.tape = []
+        self._prep_done = False
+        if self._prep is None and self.gflat is not None:
+            self._build_prep()
         return loss6
 
     # ---- data parallelism: gradient averaging overlapped with the backward --------------------------------------------------------

@@ -137,6 +137,42 @@ def test_wgrad_nine_tap_kernel_edge_shapes():
         assert err['1'] <= max(2.0 * err['0'], 2e-6) and err['1'] <= 1e-5
 
 
+def test_weight_prep_table_is_bit_identical_to_the_per_layer_splits():
+    """Round 3: ppy_train_prepare_weights_f16x2 rebuilds the forward planes and the flipped / transposed data-gradient planes
+    of ALL trainable weights in three launches; every buffer must equal what the per-layer calls produce (split_weights_f16x2,
+    the workspace of ppy_conv2d_dgrad_f32) -- checked through the planes themselves and through a data gradient on them."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(31)
+    shapes = [(258, 1, 1, 512), (64, 3, 3, 96), (512, 3, 3, 32), (40, 1, 1, 64), (1024, 3, 3, 544)]
+    ws_ = [(torch.randn(K, R, S, C, generator=g) * torch.exp(torch.randn(K, 1, 1, C, generator=g))).cuda().contiguous() for K, R, S, C in shapes]
+    ws_[1][:, :, :, 5] = 0.0                                    # an all-zero input channel: its dgrad row scale comes from the clamp
+    entries = [dict(key=i, w=w, dgrad=(i != 3)) for i, w in enumerate(ws_)]
+    tab = ops.WeightPrepTable(entries)
+    tab.build()
+    torch.cuda.synchronize()
+    for e, w in zip(entries, ws_):
+        K, R, S, C = w.shape
+        planes, sc = ops.split_weights_f16x2(w, torch.ones(K).cuda())
+        assert torch.equal(planes, e['planes']) and torch.equal(sc, e['scale']), ('forward planes', tuple(w.shape))
+        if not e['dgrad']:
+            continue
+        N, H, W = 2, 9, 7
+        pad = (R - 1) // 2
+        dy = (torch.randn(N, H, W, K, generator=g) * torch.tensor([1.0, 40.0]).view(N, 1, 1, 1)).cuda()
+        amax = ops.amax_slots(dy)
+        dx0 = torch.full((N, H, W, C), float('nan'), device='cuda')
+        dx1 = torch.full((N, H, W, C), float('nan'), device='cuda')
+        ops.conv2d_dgrad(ops.View(dy), w, ops.View(dx0), 1, pad, amax_dy=amax)
+        ops.conv2d_dgrad_prepared(ops.View(dy), e, ops.View(dx1), pad, torch.ones(C).cuda(), torch.zeros(C).cuda(), None, amax_dy=amax)
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1), ('data gradient', tuple(w.shape))
+    # the table follows its masters: an update in place is picked up by the next build()
+    ws_[2].mul_(0.5)
+    tab.build()
+    planes, sc = ops.split_weights_f16x2(ws_[2], torch.ones(512).cuda())
+    assert torch.equal(planes, entries[2]['planes']) and torch.equal(sc, entries[2]['scale']) and tab.current()
+
+
 def test_dgrad_f16x2_with_tracked_maxima():
     """The data gradient on the f16x2 kernels (dy scaled per image by its tracked maximum, the flipped weights per channel)
     against float64: at the level of the bf16x3 path, incl. a 258-channel dy (padded copy) and images of very different scale."""
