@@ -179,7 +179,8 @@ class TrainStep(object):
         self.fuse_stats = os.environ.get('PPYOLO_HIP_TRAIN_FUSE_STATS', '1') == '1'      # BatchNorm statistics from the conv epilogue
         self._bn_part = None
         self._measured = {}
-        self._nbt = []                      # BatchNorm step counters touched by this forward (bumped in one launch)
+        self._nbt = []                      # keys of the BatchNorm step counters touched by this forward (bumped in one launch)
+        self._nbt_flat, self._nbt_keys = None, None
 
     @staticmethod
     def _stage_of(key):
@@ -427,7 +428,7 @@ class TrainStep(object):
                 K.bn_train_stats_merge(self._bn_part, slices, 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'])
             else:
                 K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
-            self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
+            self._nbt.append(prefix + '.bn.num_batches_tracked')
             y = out if out is not None else (self.new_coord(prefix, xin.N, Ho, Wo, Kout) if coord_out else self.new(xin.N, Ho, Wo, Kout))
             y.req = trainable
             y.amax = self.new_amax(xin.N) if self.f16 else None
@@ -555,7 +556,7 @@ class TrainStep(object):
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var'], self.ws)
-        self._nbt.append(sd[prefix + '.bn.num_batches_tracked'])
+        self._nbt.append(prefix + '.bn.num_batches_tracked')
         y = self.new(x.N, Ho, Wo, Kout, req=trainable)
         y.amax = self.new_amax(x.N) if self.f16 else None
         K.bn_train_apply(raw.view(), mean, invstd, self.param(prefix + '.bn.weight'), self.param(prefix + '.bn.bias'), y.view(), act, None,
@@ -605,7 +606,7 @@ class TrainStep(object):
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         invstd = torch.empty(Kout, dtype=torch.float32, device=self.dev)
         K.bn_train_stats(raw.view(), 1e-5, 0.1, mean, invstd, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], self.ws)
-        self._nbt.append(sd[p + '.bn.num_batches_tracked'])
+        self._nbt.append(p + '.bn.num_batches_tracked')
         y0 = self.new(N, Ho, Wo, Kout, req=trainable)
         y0.amax = self.new_amax(N) if self.f16 else None
         K.bn_train_apply(raw.view(), mean, invstd, self.param(p + '.bn.weight'), self.param(p + '.bn.bias'), y0.view(), 'relu', None, y0.amax)
@@ -810,8 +811,7 @@ class TrainStep(object):
             self._prepare_weights()
             outs = self.head(feats)
             if self._nbt:      # BatchNorm's num_batches_tracked of every layer this forward normalised: one launch
-                torch._foreach_add_(self._nbt, 1)
-                self._nbt = []
+                self._bump_counters()
             if self.gflat is None:
                 self._alloc_flat()
             loss6 = torch.zeros(6, dtype=torch.float32, device=self.dev)
@@ -836,6 +836,25 @@ class TrainStep(object):
         if self._prep is None and self.gflat is not None:
             self._build_prep()
         return loss6
+
+    def _bump_counters(self):
+        """num_batches_tracked += 1 for the BatchNorm layers of this forward.  The 76 counters of a R50vd are 76 zero-dimensional
+        int64 buffers; torch._foreach_add_ on them turned out to be 72 tiny device copies per step (0.35 ms: rocprofv3,
+        tools/probes/train_copy_probe.py).  They become views into ONE flat tensor (the modules' buffers are re-bound to the views,
+        values kept; state_dict() keeps returning one 0-dim tensor per layer) and the bump is one `add_`."""
+        keys, self._nbt = self._nbt, []
+        if self._nbt_keys != keys or any(self.sd[k].data_ptr() != self._nbt_flat[i].data_ptr() for i, k in enumerate(keys)):
+            try:
+                flat = torch.stack([self.sd[k].detach().to(torch.int64) for k in keys])
+                for i, k in enumerate(keys):
+                    mod_name, leaf = k.rsplit('.', 1)
+                    self.model.get_submodule(mod_name)._buffers[leaf] = flat[i]
+                self.sd = self.model.state_dict()
+                self._nbt_flat, self._nbt_keys = flat, keys
+            except (AttributeError, KeyError):          # a model without that module tree: the counters one by one
+                torch._foreach_add_([self.sd[k] for k in keys], 1)
+                return
+        self._nbt_flat.add_(1)
 
     # ---- data parallelism: gradient averaging overlapped with the backward --------------------------------------------------------
     @staticmethod
