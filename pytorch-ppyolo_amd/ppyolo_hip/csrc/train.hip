@@ -735,12 +735,22 @@ __global__ void __launch_bounds__(256) chan_sum_partial_kernel(const float *dy, 
     __syncthreads();
     if (pl == 0 && c < C) part[(long long)blockIdx.y * C + c] = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
 }
+// 16 channels x 16 lanes per workgroup: lane l adds the slices l, l + 16, ... in order, then a 4-level tree over the lanes (fixed
+// order: run-to-run identical).  (One thread per channel walking up to 256 slices took 25 us per call.)
 __global__ void __launch_bounds__(256) chan_sum_final_kernel(const float *part, int C, int slices, float *out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float s_a[16][16];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float a = 0.f;
-    for (int s = 0; s < slices; ++s) a += part[(long long)s * C + c];
-    out[c] = a;
+    if (c < C)
+        for (int s = l; s < slices; s += 16) a += part[(long long)s * C + c];
+    s_a[l][cl] = a;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (l < w) s_a[l][cl] += s_a[l + w][cl];
+        __syncthreads();
+    }
+    if (l == 0 && c < C) out[c] = s_a[0][cl];
 }
 
 // ---- ExponentialMovingAverage of the trainable parameters (reference model/EMA.py:29-44): numpy's float32 arithmetic,
@@ -998,7 +1008,7 @@ extern "C" int ppy_channel_sum_f32(const float *dy, int dy_ld, int P, int C, flo
     sl = ceil_div(P, pps);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_sum_partial_kernel, dim3(ceil_div(C, BN_CH), sl), dim3(256), 0, st, dy, dy_ld, P, C, pps, (float *)ws);
-    hipLaunchKernelGGL(chan_sum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float *)ws, C, sl, out);
+    hipLaunchKernelGGL(chan_sum_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const float *)ws, C, sl, out);
     return ppy_launch_status();
 }
 
