@@ -7,6 +7,8 @@
 // 16-byte accesses, one or two passes over the data, deterministic reductions (fixed slice order, no float atomics).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BN_CH = 64;         // channels per workgroup of the statistics kernels (one wave = one pixel x 64 channels)
@@ -90,12 +92,12 @@ __device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, flo
 // (fixed order: run-to-run identical); mean, 1/sqrt(biased var + eps); running statistics as torch.nn.BatchNorm2d does:
 // running = (1 - momentum) * running + momentum * {mean, UNBIASED var}
 constexpr int FIN_CH = 16;
-__global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, int C, int slices, float eps, float momentum,
-                                                             float *mean_out, float *invstd_out, float *running_mean,
-                                                             float *running_var) {
-    __shared__ float s_n[16][FIN_CH], s_m[16][FIN_CH], s_q[16][FIN_CH];
+// body of bn_stats_final_kernel for the channel block `cb` (16 channels); all 256 threads call
+__device__ __forceinline__ void bn_stats_final_body(const float *part, int C, int slices, float eps, float momentum, float *mean_out,
+                                                    float *invstd_out, float *running_mean, float *running_var, int cb,
+                                                    float (&s_n)[16][FIN_CH], float (&s_m)[16][FIN_CH], float (&s_q)[16][FIN_CH]) {
     const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
-    const int c = blockIdx.x * FIN_CH + cl;
+    const int c = cb * FIN_CH + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C)
         for (int s = l; s < slices; s += 16) {
@@ -118,10 +120,40 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, 
     if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
 }
+__global__ void __launch_bounds__(256) bn_stats_final_kernel(const float *part, int C, int slices, float eps, float momentum,
+                                                             float *mean_out, float *invstd_out, float *running_mean,
+                                                             float *running_var) {
+    __shared__ float s_n[16][FIN_CH], s_m[16][FIN_CH], s_q[16][FIN_CH];
+    bn_stats_final_body(part, C, slices, eps, momentum, mean_out, invstd_out, running_mean, running_var, (int)blockIdx.x, s_n, s_m, s_q);
+}
+
+// Round 3: "the last workgroup finalises".  A reduction kernel whose partial results are combined by a second, tiny launch (6 us of
+// launch latency for a few KB: 132 such launches per training step) takes a ticket per column block when its partials are
+// written (release fence, device-scope atomic); the workgroup that draws the last ticket (acquire fence) runs the second launch's
+// body itself -- the same code, the same order, so the results are bit-identical to the two-launch form.  atomicInc wraps the
+// counter back to 0 with the last ticket: the counters need no reset.  One set per reduction kind; launches of one kind must
+// not overlap on a device (the training step is one stream).  PPY_BN_FUSE_FINAL=0 restores the separate launches.
+struct FinArgs {
+    float eps, momentum;
+    float *mean, *invstd, *running_mean, *running_var;      // forward statistics
+    float *dbeta, *dgamma;                                   // backward sums
+    int fuse;
+};
+__device__ unsigned g_tickets[3][512];      // [merge | slice statistics | backward sums][column block]
+__device__ __forceinline__ bool last_ticket(int kind, int col, unsigned count) {
+    __shared__ unsigned s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicInc(&g_tickets[kind][col], count - 1) == count - 1 ? 1u : 0u;
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
 
 // First level of a long list of slices (the convolution epilogues write one per wave row-tile: thousands for the 152x152 maps):
 // workgroup (channel group, g) merges the slices [g * per_group, (g + 1) * per_group) into one triple, same order as the final kernel
-__global__ void __launch_bounds__(256) bn_stats_merge_kernel(const float *part, int C, int slices, int per_group, float *out) {
+__global__ void __launch_bounds__(256) bn_stats_merge_kernel(const float *part, int C, int slices, int per_group, float *out, const FinArgs fin) {
     __shared__ float s_n[16][FIN_CH], s_m[16][FIN_CH], s_q[16][FIN_CH];
     const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
     const int c = blockIdx.x * FIN_CH + cl;
@@ -141,9 +173,13 @@ __global__ void __launch_bounds__(256) bn_stats_merge_kernel(const float *part, 
         }
         __syncthreads();
     }
-    if (l != 0 || c >= C) return;
-    float *o = out + ((long long)blockIdx.y * C + c) * 3;
-    o[0] = n; o[1] = mean; o[2] = m2;
+    if (l == 0 && c < C) {
+        float *o = out + ((long long)blockIdx.y * C + c) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+    if (!fin.fuse || !last_ticket(0, (int)blockIdx.x, gridDim.y)) return;
+    bn_stats_final_body(out, C, (int)gridDim.y, fin.eps, fin.momentum, fin.mean, fin.invstd, fin.running_mean, fin.running_var, (int)blockIdx.x,
+                        s_n, s_m, s_q);
 }
 
 // ---- forward apply: y = act((x - mean) * invstd * gamma + beta [+ res]); 4 channels per element of work, the per-channel
@@ -189,8 +225,35 @@ __device__ __forceinline__ float act_grad(float y, int act) {      // derivative
 }
 
 // ---- backward reduction: per channel sum(dz), sum(dz * xhat), dz = dy * act'(y), xhat = (x - mean) * invstd
-__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs p) {
+// body of bn_bwd_final_kernel for the channel block `cb` (16 channels); all 256 threads call
+__device__ __forceinline__ void bn_bwd_final_body(const float *part, int C, int slices, float *dbeta, float *dgamma, int cb,
+                                                  float (&s_a)[16][FIN_CH], float (&s_b)[16][FIN_CH]) {
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = cb * FIN_CH + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int s = l; s < slices; s += 16) {
+            a += part[((long long)s * C + c) * 2];
+            b += part[((long long)s * C + c) * 2 + 1];
+        }
+    s_a[l][cl] = a; s_b[l][cl] = b;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (l < w) {
+            s_a[l][cl] += s_a[l + w][cl];
+            s_b[l][cl] += s_b[l + w][cl];
+        }
+        __syncthreads();
+    }
+    if (l == 0 && c < C) {
+        dbeta[c] = s_a[0][cl];
+        dgamma[c] = s_b[0][cl];
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs p, const FinArgs fin) {
     __shared__ float s_a[4][BN_CH], s_b[4][BN_CH];
+    __shared__ float f_a[16][FIN_CH], f_b[16][FIN_CH];
     const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     const int c = blockIdx.x * BN_CH + cl;
     const int p0 = blockIdx.y * p.pix_per_slice, p1 = min(p0 + p.pix_per_slice, p.P);
@@ -211,30 +274,14 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs p) {
         p.part[((long long)blockIdx.y * p.C + c) * 2] = a;
         p.part[((long long)blockIdx.y * p.C + c) * 2 + 1] = b;
     }
+    if (!fin.fuse || !last_ticket(2, (int)blockIdx.x, gridDim.y)) return;
+#pragma unroll 1
+    for (int g = 0; g < BN_CH / FIN_CH; ++g)
+        bn_bwd_final_body(p.part, p.C, (int)gridDim.y, fin.dbeta, fin.dgamma, (int)blockIdx.x * (BN_CH / FIN_CH) + g, f_a, f_b);
 }
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float *part, int C, int slices, float *dbeta, float *dgamma) {
     __shared__ float s_a[16][FIN_CH], s_b[16][FIN_CH];
-    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
-    const int c = blockIdx.x * FIN_CH + cl;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int s = l; s < slices; s += 16) {
-            a += part[((long long)s * C + c) * 2];
-            b += part[((long long)s * C + c) * 2 + 1];
-        }
-    s_a[l][cl] = a; s_b[l][cl] = b;
-    __syncthreads();
-    for (int w = 8; w > 0; w >>= 1) {
-        if (l < w) {
-            s_a[l][cl] += s_a[l + w][cl];
-            s_b[l][cl] += s_b[l + w][cl];
-        }
-        __syncthreads();
-    }
-    if (l == 0 && c < C) {
-        dbeta[c] = s_a[0][cl];
-        dgamma[c] = s_b[0][cl];
-    }
+    bn_bwd_final_body(part, C, slices, dbeta, dgamma, (int)blockIdx.x, s_a, s_b);
 }
 // dx = gamma * invstd * (dz - (sum_dz + xhat * sum_dzx) / P); a workgroup owns a run of pixels, as bn_apply_kernel, so that the
 // optional per-image max|dx| (operand scale of an f16x2 weight gradient) costs one or two atomics per wave
@@ -772,6 +819,10 @@ static int slices_for(int P, int C) {
     return sl < 1 ? 1 : sl;
 }
 static inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+static inline bool fuse_final() {      // A/B switch, read per call (tests compare the two forms bit for bit)
+    const char *e = getenv("PPY_BN_FUSE_FINAL");
+    return !(e && e[0] == '0');
+}
 
 }  // namespace
 
@@ -808,8 +859,12 @@ extern "C" int ppy_bn_train_stats_merge_f32(float *partials, size_t partials_byt
         const int per_group = 64, groups = ceil_div(slices, per_group);
         float *lvl = partials + (size_t)slices * C * 3;
         if (partials_bytes < ((size_t)slices + groups) * C * 3 * sizeof(float)) return PPY_ERR_WORKSPACE;
+        FinArgs fin = {};
+        fin.eps = eps; fin.momentum = momentum; fin.mean = mean; fin.invstd = invstd; fin.running_mean = running_mean; fin.running_var = running_var;
+        fin.fuse = fuse_final() && ceil_div(C, FIN_CH) <= 512;
         hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(ceil_div(C, FIN_CH), groups), dim3(256), 0, st, (const float *)partials, C, slices,
-                           per_group, lvl);
+                           per_group, lvl, fin);
+        if (fin.fuse) return ppy_launch_status();
         src = lvl;
         slices = groups;
     } else if (partials_bytes < (size_t)slices * C * 3 * sizeof(float)) {
@@ -856,8 +911,12 @@ extern "C" int ppy_bn_train_bwd_f32(const float *x, int x_ld, const float *y, in
     p.slices = ceil_div(P, p.pix_per_slice);
     p.sum_dz = dbeta; p.sum_dzx = dgamma;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
+    FinArgs fin = {};
+    fin.dbeta = dbeta; fin.dgamma = dgamma;
+    fin.fuse = fuse_final() && ceil_div(C, BN_CH) <= 512;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(ceil_div(C, BN_CH), p.slices), dim3(256), 0, st, p, fin);
+    if (!fin.fuse)
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, C, p.slices, dbeta, dgamma);
     const int hw = amax_dx ? pixels_per_image : P;
     if (amax_dx && (pixels_per_image <= 0 || P % pixels_per_image != 0)) return PPY_ERR_BAD_ARG;
     int ppb = ceil_div(P, 4096);

@@ -281,6 +281,63 @@ def test_pool_backward_and_strided_data_gradient():
         assert err <= 2e-6, ((N, C, K, H, W, R, s), err)
 
 
+def test_last_workgroup_finalisation_is_bit_identical_to_the_second_launch():
+    """Round 3: the BatchNorm statistics merge and the BatchNorm backward sums finish inside their reduction kernels (the
+    workgroup that draws the last ticket of a column block runs the final step: csrc/train.hip, last_ticket) instead of in a
+    second 6 us launch.  Same code, same order: every output equals the two-launch form (PPY_BN_FUSE_FINAL=0) bit for bit --
+    repeated, so that a counter that did not wrap back to zero would show."""
+    import os
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(77)
+
+    def both(fn):
+        out = {}
+        for form in ('1', '0', '1'):
+            os.environ['PPY_BN_FUSE_FINAL'] = form
+            try:
+                r = fn()
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop('PPY_BN_FUSE_FINAL', None)
+            if form in out:
+                assert all(torch.equal(a, b) for a, b in zip(out[form], r)), 'second fused run differs from the first'
+            out[form] = r
+        assert all(torch.equal(a, b) for a, b in zip(out['1'], out['0']))
+
+    # backward sums: channel counts that leave partial 64- and 16-channel blocks, one- and many-slice maps
+    for (N, C, H, W, act) in ((8, 256, 38, 38, 'leaky'), (2, 100, 7, 5, 'relu'), (1, 520, 3, 3, None), (8, 64, 76, 76, 'leaky')):
+        x = torch.randn(N, H, W, C, generator=g).cuda()
+        dy = torch.randn(N, H, W, C, generator=g).cuda()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+
+        def bwd():
+            mean, invstd = torch.empty(C).cuda(), torch.empty(C).cuda()
+            ops.bn_train_stats(ops.View(x), 1e-5, 0.1, mean, invstd)
+            y = torch.empty_like(x)
+            ops.bn_train_apply(ops.View(x), mean, invstd, gamma, beta, ops.View(y), act)
+            dx, dg, db = torch.empty_like(x), torch.empty(C).cuda(), torch.empty(C).cuda()
+            ops.bn_train_bwd(ops.View(x), ops.View(y), ops.View(dy), mean, invstd, gamma, ops.View(dx), dg, db, act)
+            return dx, dg, db
+        both(bwd)
+    # statistics from a convolution's epilogue with more than 256 slices (the two-level merge)
+    N, H, W, C, K = 8, 76, 76, 32, 64
+    xd = (torch.randn(N, H, W, C, generator=g) + 0.3).cuda()
+    wk = (torch.randn(K, 3, 3, C, generator=g) * 0.06).cuda()
+    wf = ops.split_weights_f16x2(wk, torch.ones(K).cuda())
+    bias = torch.randn(K, generator=g).cuda()
+
+    def stats():
+        y = torch.empty(N, H, W, K).cuda()
+        part = torch.full((ops.conv2d_bn_partials_bytes(N * H * W, K) // 4,), float('nan')).cuda()
+        slices = ops.conv2d_train_fwd(ops.View(xd), wk, wf, bias, ops.View(y), 1, 1, 44, ops.amax_slots(xd), part)
+        assert slices > 256
+        m, i = torch.empty(K).cuda(), torch.empty(K).cuda()
+        rm, rv = torch.full((K,), 0.25).cuda(), torch.full((K,), 2.0).cuda()
+        ops.bn_train_stats_merge(part, slices, 1e-5, 0.1, m, i, rm, rv)
+        return m, i, rm, rv
+    both(stats)
+
+
 def test_batchnorm_statistics_from_the_convolution_epilogue():
     """ppy_conv2d_train_fwd_f32 + ppy_bn_train_stats_merge_f32 against the two-kernel form (ppy_conv2d_bn_act_f32, then
     ppy_bn_train_stats_f32 reading y back): y is EQUAL (same tile, same epilogue), mean / invstd / running statistics agree to
