@@ -120,7 +120,7 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
         cfg = op['cfg']
         if op['op'] == 'dcn':      # ids of the fused DCNv2 kernel: scheme * tiles + tile; < 0 = the library picks by operands
             from ppyolo_hip import ops as K
-            fam = (('fp32', 'bf16x3', 'f16x2')[cfg // (K.dcnv2_num_configs() // 3)] if cfg >= 0 else
+            fam = (K.dcnv2_scheme(cfg) if cfg >= 0 else
                    ('f16x2' if op.get('wf16') is not None else ('bf16x3' if op.get('w3') is not None else 'fp32')))
         else:
             fam = 'fp32' if cfg < NUM_FP32_CFGS else ('bf16x3' if cfg < NUM_FP32_CFGS + NUM_X3_CFGS else 'f16x2')

@@ -36,26 +36,27 @@ struct DcnArgs {
 
 constexpr unsigned DCN_OOB = 0x80000000u;      // beyond any tensor this kernel accepts (< 2 GB)
 
-template <int BM, int BN, int MODE, bool SPLIT, bool VEC>
-__global__ void __launch_bounds__(256) dcn_fused_kernel(const DcnArgs q) {
+template <int BM, int BN, int MODE, bool SPLIT, bool VEC, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) dcn_fused_kernel(const DcnArgs q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
-    constexpr int NW = 4, WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int WCOLS = NW / 2;                               // waves: 2 (rows) x NW / 2 (columns)
+    constexpr int WM = BM / 2, WN = BN / WCOLS, TM = WM / 32, TN = WN / 32;
     constexpr int NP = MODE == 2 ? 2 : (MODE == 1 ? 3 : 1);      // operand pieces = planes in LDS
     constexpr int ROWB = MODE == 0 ? 128 : 64;                   // bytes of a 32-deep row
     constexpr int A_BYTES = NP * BM * ROWB, B_BYTES = NP * BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int RPI = 1024 / ROWB;                             // weight rows per DMA instruction
     constexpr int B_PASS = NP * BN / (RPI * NW);
     static_assert(NP * BN % (RPI * NW) == 0, "whole DMA instructions per wave");
-    constexpr int TPR = 256 / BM;                                // gather threads per tile row (2 or 4)
-    constexpr int NV = 8 / TPR;                                  // 16-byte loads per corner per thread (4 or 2)
+    constexpr int TPR = NW * 64 / BM;                            // gather threads per tile row (2, 4 or 8)
+    constexpr int NV = 8 / TPR;                                  // 16-byte loads per corner per thread (4, 2 or 1)
     typedef __attribute__((address_space(3))) void *lds_ptr;
 
     extern __shared__ __attribute__((aligned(16))) char smem_dcn[];
     char *smem = smem_dcn;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WCOLS, wn = wave - wm * WCOLS;
     const int tiles_n = (p.K + BN - 1) / BN;
     int tile_id;       // XCD-contiguous tile order (conv_x3.hip): the N-tiles that gather the same rows meet in one L2
     {
@@ -213,6 +214,21 @@ __global__ void __launch_bounds__(256) dcn_fused_kernel(const DcnArgs q) {
                 const int pos = (cseg * NV + v) ^ ((grow >> 1) & 7);
                 *reinterpret_cast<floatx4 *>(a_base + grow * 128 + pos * 16) = floatx4{r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]};
             }
+        } else if constexpr (NV == 1) {      // eight gather threads per row: 4 channels = half a 16-byte slot per plane (f16x2 only)
+            static_assert(NV != 1 || MODE == 2, "the 8-wave tiles are f16x2 tiles");
+            const int pos = (cseg >> 1) ^ ((grow >> 2) & 3);
+            char *dst = a_base + grow * 64 + pos * 16 + (cseg & 1) * 8;
+            typedef __attribute__((ext_vector_type(2))) unsigned uintx2;
+            uintx2 P0, P1;
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd) {
+                const float xa = r[2 * qd], xb = r[2 * qd + 1];
+                const unsigned h = cvt_pk_f16(xa * gsa, xb * gsa);
+                P0[qd] = h;
+                P1[qd] = cvt_pk_f16(fmaf(xa, gsa, -f16_lo(h)), fmaf(xb, gsa, -f16_hi(h)));
+            }
+            *reinterpret_cast<uintx2 *>(dst) = P0;
+            *reinterpret_cast<uintx2 *>(dst + BM * 64) = P1;
         } else {
 #pragma unroll
             for (int s8 = 0; s8 < NV / 2; ++s8) {       // one 16-byte slot = 8 channels per plane
@@ -367,34 +383,40 @@ struct DcnTile {
 };
 constexpr DcnTile kTiles[] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {64, 256}, {128, 256}};      // 4 waves (2 x 2) each
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+// Round 3: f16x2 tiles with EIGHT waves (2 x 4), ids 3 * kNumTiles + i.  What bounds the kernel is the bytes of the gather
+// through the CU (4 corner pixels per sample: 4x the bytes of a dense A tile) plus the weights every M-tile re-reads; 64 x 512
+// gathers every sample ONCE for all 512 output channels (0.09 B per MAC against 0.18 at 64 x 128), and with eight gather threads
+// per row a thread holds 4 corners x 16 B per chunk.  144 KB of LDS: one workgroup per CU, split-K fills the chip.
+constexpr DcnTile kTiles8[] = {{64, 512}, {64, 256}};
+constexpr int kNumTiles8 = sizeof(kTiles8) / sizeof(kTiles8[0]);
 
-template <int BM, int BN, int MODE, bool SPLIT, bool VEC>
+template <int BM, int BN, int MODE, bool SPLIT, bool VEC, int NW = 4>
 int launch_one(const DcnArgs &q, int splits, size_t lds, int tiles, hipStream_t stream) {
-    auto k = dcn_fused_kernel<BM, BN, MODE, SPLIT, VEC>;
+    auto k = dcn_fused_kernel<BM, BN, MODE, SPLIT, VEC, NW>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
-    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), lds, stream, q);
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(NW * 64), lds, stream, q);
     return PPY_OK;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NW = 4>
 int launch_tile(DcnArgs q, int splits, hipStream_t stream) {
     ConvArgs &p = q.c;
     constexpr int NP = MODE == 2 ? 2 : (MODE == 1 ? 3 : 1), ROWB = MODE == 0 ? 128 : 64;
     size_t lds = 2 * (size_t)(NP * (BM + BN) * ROWB);
-    const size_t epi = (size_t)4 * 32 * LDS_LD * sizeof(float);
+    const size_t epi = (size_t)NW * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
     const bool vec = vec_epilogue_ok(p);
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_one<BM, BN, MODE, true, true>(q, splits, lds, tiles, stream)
-                 : launch_one<BM, BN, MODE, true, false>(q, splits, lds, tiles, stream);
+        rc = vec ? launch_one<BM, BN, MODE, true, true, NW>(q, splits, lds, tiles, stream)
+                 : launch_one<BM, BN, MODE, true, false, NW>(q, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_one<BM, BN, MODE, false, true>(q, splits, lds, tiles, stream)
-                 : launch_one<BM, BN, MODE, false, false>(q, splits, lds, tiles, stream);
+        rc = vec ? launch_one<BM, BN, MODE, false, true, NW>(q, splits, lds, tiles, stream)
+                 : launch_one<BM, BN, MODE, false, false, NW>(q, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
@@ -409,6 +431,12 @@ int launch_mode(const DcnArgs &q, int tile, int splits, hipStream_t stream) {
         case 3: return launch_tile<64, 64, MODE>(q, splits, stream);
         case 4: return launch_tile<64, 256, MODE>(q, splits, stream);      // the gather is shared by 256 output channels
         case 5: return launch_tile<128, 256, MODE>(q, splits, stream);
+    }
+    if constexpr (MODE == 2) {
+        switch (tile - kNumTiles) {
+            case 0: return launch_tile<64, 512, 2, 8>(q, splits, stream);
+            case 1: return launch_tile<64, 256, 2, 8>(q, splits, stream);
+        }
     }
     return PPY_ERR_BAD_ARG;
 }
@@ -434,11 +462,12 @@ bool dcn_geometry(int N, int H, int W, int C, int K, int stride, int pad, int *H
 }
 
 int resolve(int M, int K, int chunks, int cfg, int splitk, int *mode, int *tile, int *splits) {
-    if (cfg >= 3 * kNumTiles) return PPY_ERR_BAD_ARG;
+    if (cfg >= 3 * kNumTiles + kNumTiles8) return PPY_ERR_BAD_ARG;
     int ht, hs;
     pick(M, K, chunks, &ht, &hs);
-    *mode = cfg < 0 ? -1 : cfg / kNumTiles;
-    *tile = cfg < 0 ? ht : cfg % kNumTiles;
+    const bool w8 = cfg >= 3 * kNumTiles;                       // the eight-wave f16x2 tiles
+    *mode = cfg < 0 ? -1 : (w8 ? 2 : cfg / kNumTiles);
+    *tile = cfg < 0 ? ht : (w8 ? kNumTiles + cfg - 3 * kNumTiles : cfg % kNumTiles);
     int s = splitk <= 0 ? (cfg < 0 ? hs : 1) : splitk;
     if (s > chunks) s = chunks;
     *splits = ceil_div(chunks, ceil_div(chunks, s));      // no empty split
@@ -447,7 +476,7 @@ int resolve(int M, int K, int chunks, int cfg, int splitk, int *mode, int *tile,
 
 }  // namespace
 
-extern "C" int ppy_dcnv2_num_configs(void) { return 3 * kNumTiles; }
+extern "C" int ppy_dcnv2_num_configs(void) { return 3 * kNumTiles + kNumTiles8; }
 
 extern "C" size_t ppy_dcnv2_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int cfg, int splitk) {
     int Ho, Wo, mode, tile, s;

@@ -711,7 +711,7 @@ class HipExecutor(object):
         guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
         from ._lib import lib
         ncfg_conv = {'fp32': NUM_FP32_CFGS, 'bf16x3': NUM_FP32_CFGS + NUM_X3_CFGS}.get(self.math, lib().ppy_conv2d_num_configs())
-        ncfg_dcn = K.dcnv2_num_configs() // 3 * {'fp32': 1, 'bf16x3': 2}.get(self.math, 3)      # schemes up to this mode's
+        cfgs_dcn = K.dcnv2_configs(self.math)      # schemes up to this mode's (+ the eight-wave f16x2 tiles)
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
         self._unlink_splits()          # (layers are measured on plain fp32 tensors; the links are re-derived from the new choices)
@@ -719,7 +719,7 @@ class HipExecutor(object):
             big = 0
             for op in self.plan.ops:
                 if op['op'] in ('conv', 'dcn'):
-                    for c in range(ncfg_dcn if op['op'] == 'dcn' else ncfg_conv):
+                    for c in (cfgs_dcn if op['op'] == 'dcn' else range(ncfg_conv)):
                         for s in splits:
                             o = dict(op, cfg=c, splitk=s)
                             big = max(big, self._ws_need(o))
@@ -773,7 +773,7 @@ class HipExecutor(object):
                     return ms
 
                 cands = []
-                for c in range(ncfg_dcn if op['op'] == 'dcn' else ncfg_conv):
+                for c in (cfgs_dcn if op['op'] == 'dcn' else range(ncfg_conv)):
                     for s in splits:
                         if s > 1 and chunks // s < 4:
                             continue

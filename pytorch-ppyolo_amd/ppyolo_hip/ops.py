@@ -514,6 +514,20 @@ def dcnv2_num_configs():
     return int(lib().ppy_dcnv2_num_configs())
 
 
+DCN_TILES_4W = 6      # csrc/dcn_fused.hip: ids [0, 18) = scheme (fp32, bf16x3, f16x2) * 6 + four-wave tile; [18, ...) = eight-wave f16x2 tiles
+
+
+def dcnv2_scheme(cfg):
+    """'fp32' / 'bf16x3' / 'f16x2': the math scheme a fused-DCNv2 configuration id runs."""
+    return ('fp32', 'bf16x3', 'f16x2')[min(cfg // DCN_TILES_4W, 2)]
+
+
+def dcnv2_configs(math='f16x2'):
+    """The configuration ids a plan in math mode `math` may use (the schemes up to its own)."""
+    n = {'fp32': 1, 'bf16x3': 2}.get(math, 3) * DCN_TILES_4W
+    return list(range(n)) + (list(range(3 * DCN_TILES_4W, dcnv2_num_configs())) if math == 'f16x2' else [])
+
+
 def dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg=-1, splitk=0):
     return int(lib().ppy_dcnv2_workspace_bytes(N, H, W, C, K, stride, pad, cfg, splitk))
 

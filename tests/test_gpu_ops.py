@@ -292,7 +292,7 @@ def test_dcn_fused_matches_the_columns_path(shape):
     ref = torch.where(ref > 0, ref, 0.1 * ref).float().view(N, Ho, Wo, K)
     w3, wf, amax = ops.split_weights_bf16x3(w), ops.split_weights_f16x2(w, scale), ops.amax_slots(x)
     ncfg = ops.dcnv2_num_configs()
-    assert ncfg % 3 == 0 and ncfg >= 12
+    assert ncfg >= 3 * ops.DCN_TILES_4W + 2      # three schemes x six four-wave tiles, then the eight-wave f16x2 tiles
     worst = {}
     for cfg in list(range(ncfg)) + [-1]:
         for splitk in (1, 2, 3, 9) if cfg >= 0 else (0,):
@@ -305,7 +305,7 @@ def test_dcn_fused_matches_the_columns_path(shape):
             ops.dcnv2(ops.View(x), w, scale, shift, ops.View(om), ops.View(y), stride, 1, 'leaky', ws, cfg=cfg, splitk=splitk,
                       w_x3=w3, w_f16=wf, amax_in=amax, amax_out=amax_out)
             err = float((y - ref).abs().max() / ref.abs().max())
-            scheme = 'auto' if cfg < 0 else ('fp32', 'bf16x3', 'f16x2')[cfg // (ncfg // 3)]
+            scheme = 'auto' if cfg < 0 else ops.dcnv2_scheme(cfg)
             worst[scheme] = max(worst.get(scheme, 0.0), err)
             assert err <= 2e-6, (cfg, splitk, err)
             got = amax_out.view(N, -1).amax(dim=1)
