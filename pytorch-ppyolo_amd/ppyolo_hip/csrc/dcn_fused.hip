@@ -325,9 +325,12 @@ __global__ void __launch_bounds__(NW * 64) dcn_fused_kernel(const DcnArgs q) {
         }
     };
 
+    constexpr bool DEEP = NW == 8;      // eight-wave tiles: the corner loads run TWO chunks ahead (two register sets of 16 VGPRs)
     if (nchunks > 0) {
         issue_b(0, kc_begin, true);
         gather_issue(g0, kc_begin, true);
+        GSet g1;
+        if constexpr (DEEP) gather_issue(g1, kc_begin + 1, 1 < nchunks);
         if constexpr (MODE == 2) {      // behind the first requests, so that this latency hides behind theirs
             const int f = scale_exp(gn);
             gsa = __uint_as_float((unsigned)f << 23);
@@ -338,21 +341,45 @@ __global__ void __launch_bounds__(NW * 64) dcn_fused_kernel(const DcnArgs q) {
             }
         }
         gather_store(g0, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // iteration k: request the weights and the corners of chunk k+1; MFMAs of chunk k; blend + split + store chunk k+1.
-        // Requests past the end of the split are issued out of range (no traffic, no branches in the loop body).
-        for (int k = 0; k < nchunks; ++k) {
-            const int st = k & 1;
-            issue_b(st ^ 1, kc_begin + k + 1, k + 1 < nchunks);
-            gather_issue(g0, kc_begin + k + 1, k + 1 < nchunks);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(st);
-            gather_store(g0, st ^ 1);
-            // every LDS read of chunk k has returned, chunk k+1 is complete in the other stage (here and, after the
-            // barrier, in all waves)
+        if constexpr (DEEP) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * NV) : "memory");      // (the corners of chunk 1 may still be in flight)
+        } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();
+        if constexpr (!DEEP) {
+            // iteration k: request the weights and the corners of chunk k+1; MFMAs of chunk k; blend + split + store chunk k+1.
+            // Requests past the end of the split are issued out of range (no traffic, no branches in the loop body).
+            for (int k = 0; k < nchunks; ++k) {
+                const int st = k & 1;
+                issue_b(st ^ 1, kc_begin + k + 1, k + 1 < nchunks);
+                gather_issue(g0, kc_begin + k + 1, k + 1 < nchunks);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(st);
+                gather_store(g0, st ^ 1);
+                // every LDS read of chunk k has returned, chunk k+1 is complete in the other stage (here and, after the
+                // barrier, in all waves)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            // iteration k: weights of chunk k+1 (DMA), corners of chunk k+2 into the set that chunk k's blend freed; MFMAs of chunk k;
+            // blend + split + store chunk k+1 from the OTHER set (requested one iteration ago).  The counted wait leaves only
+            // the 4 * NV corner loads just issued in flight: the DMA of chunk k+1, issued before them, has landed.
+            auto body = [&](int k, GSet &issue_set, GSet &store_set) {
+                const int st = k & 1;
+                issue_b(st ^ 1, kc_begin + k + 1, k + 1 < nchunks);
+                gather_issue(issue_set, kc_begin + k + 2, k + 2 < nchunks);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(st);
+                gather_store(store_set, st ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * NV) : "memory");
+                __builtin_amdgcn_s_barrier();
+            };
+            for (int k = 0; k < nchunks; k += 2) {
+                body(k, g0, g1);
+                if (k + 1 < nchunks) body(k + 1, g1, g0);
+            }
         }
     }
     float rowscale[TM][4];
