@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(NW * 64) dcn_fused_kernel(const DcnArgs q) {
         }
     };
 
-    constexpr bool DEEP = NW == 8;      // eight-wave tiles: the corner loads run TWO chunks ahead (two register sets of 16 VGPRs)
+    constexpr bool DEEP = NW == 8 && NV == 1;      // eight gather threads per row: the corner loads run TWO chunks ahead (two register sets of 16 VGPRs)
     if (nchunks > 0) {
         issue_b(0, kc_begin, true);
         gather_issue(g0, kc_begin, true);
@@ -414,7 +414,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // through the CU (4 corner pixels per sample: 4x the bytes of a dense A tile) plus the weights every M-tile re-reads; 64 x 512
 // gathers every sample ONCE for all 512 output channels (0.09 B per MAC against 0.18 at 64 x 128), and with eight gather threads
 // per row a thread holds 4 corners x 16 B per chunk.  144 KB of LDS: one workgroup per CU, split-K fills the chip.
-constexpr DcnTile kTiles8[] = {{64, 512}, {64, 256}};
+constexpr DcnTile kTiles8[] = {{64, 512}, {64, 256}, {128, 512}};
 constexpr int kNumTiles8 = sizeof(kTiles8) / sizeof(kTiles8[0]);
 
 template <int BM, int BN, int MODE, bool SPLIT, bool VEC, int NW = 4>
@@ -463,6 +463,7 @@ int launch_mode(const DcnArgs &q, int tile, int splits, hipStream_t stream) {
         switch (tile - kNumTiles) {
             case 0: return launch_tile<64, 512, 2, 8>(q, splits, stream);
             case 1: return launch_tile<64, 256, 2, 8>(q, splits, stream);
+            case 2: return launch_tile<128, 512, 2, 8>(q, splits, stream);      // all 160 KB of LDS; the weights stream half as often
         }
     }
     return PPY_ERR_BAD_ARG;

@@ -11,7 +11,7 @@ from ppyolo_hip import ops
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 TILES = ['128x128', '64x128', '128x64', '64x64', '64x256', '128x256']
-TILES8 = ['64x512 (8 waves)', '64x256 (8 waves)']
+TILES8 = ['64x512 (8 waves)', '64x256 (8 waves)', '128x512 (8 waves)']
 for H, stride in ((38, 2), (19, 1)):
     C = K = 512
     g = torch.Generator().manual_seed(H)
