@@ -46,4 +46,4 @@ for (N, H, C, K) in ((8, 38, 256, 1024), (8, 76, 128, 512), (8, 19, 512, 2048)):
     mb = (N * H * H * (C + 2 * K) * 4) / 1e6
     print('expand %dx%d C%d -> K%d bs %d (%.0f MB): streaming cfgs %d / %d' % (H, H, C, K, N, mb, first, first + 1))
     for us, cfg in res[:6] + [t for t in res if t[1] in (first, first + 1)]:
-        print('   cfg %3d  %6.1f us  %.2f TB/s' % (cfg, us, mb / us / 1e6 * 1e6 / 1e6))
+        print('   cfg %3d  %6.1f us  %.2f TB/s' % (cfg, us, mb / us))
