@@ -135,3 +135,34 @@ def test_split_pairs_of_the_r50_plan():
     # chains: an op can be consumer and producer
     prods = {id(pr) for pr, _ in pairs}
     assert any(id(c) in prods for _, cs in pairs for c in cs)
+
+
+def test_dcn_configuration_ids_and_weight_prep_descriptor_layout():
+    """Host-side bookkeeping of round 3 that needs no device: (1) the fused-DCNv2 ids -- [0, 18) = scheme * 6 + four-wave tile, from
+    18 the eight-wave f16x2 tiles -- as ops.dcnv2_scheme / dcnv2_configs hand them to the plan and the tuner; every committed
+    'dcnf' table entry names an id of its own table's scheme.  (2) ops._WeightPrep mirrors PpyWeightPrep of include/ppyolo_hip.h
+    field for field (six pointers, six ints: 72 bytes) -- the table is copied to the device as raw bytes."""
+    import ctypes
+    import json
+    import os
+    import re
+    from ppyolo_hip import ops
+    n = ops.dcnv2_num_configs()
+    assert n > 3 * ops.DCN_TILES_4W
+    assert [ops.dcnv2_scheme(c) for c in (0, 5, 6, 11, 12, 17, 18, n - 1)] == ['fp32', 'fp32', 'bf16x3', 'bf16x3', 'f16x2', 'f16x2', 'f16x2', 'f16x2']
+    assert ops.dcnv2_configs('fp32') == list(range(6)) and ops.dcnv2_configs('bf16x3') == list(range(12))
+    assert ops.dcnv2_configs('f16x2') == list(range(18)) + list(range(18, n))
+    here = os.path.join(os.path.dirname(ops.__file__))
+    for mode, fname in (('fp32', 'tuned_gfx950.json'), ('bf16x3', 'tuned_gfx950_bf16x3.json'), ('f16x2', 'tuned_gfx950_f16x2.json')):
+        with open(os.path.join(here, fname)) as fh:
+            table = json.load(fh)
+        ids = [v[0] for k, v in table.items() if k.startswith('dcnf')]
+        assert ids and all(c in ops.dcnv2_configs(mode) for c in ids), (mode, ids)
+    # the descriptor: same fields, same order, same size as the C struct
+    fields = [f for f, _ in ops._WeightPrep._fields_]
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(here)), 'include', 'ppyolo_hip.h')).read()
+    body = hdr[hdr.index('typedef struct PpyWeightPrep {'):hdr.index('} PpyWeightPrep;')]
+    names = re.findall(r'[\s\*](\w+)(?=[,;])', body.split('{', 1)[1])
+    assert names == fields, (names, fields)
+    assert ctypes.sizeof(ops._WeightPrep) == 6 * 8 + 6 * 4
+    assert ops.PREP_SPLIT == int(re.search(r'#define PPY_PREP_SPLIT (\d+)', hdr).group(1))
