@@ -31,6 +31,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel PER DEVICE: remember, per kernel, on which device
 // ordinals it has been raised (one bit each; set atomically -- launches come from several lane threads).
+static constexpr int PPY_LDS_MAX = 160 * 1024;      // gfx950: 160 KB of LDS per CU, all of it available to one workgroup
 struct PpyLdsAttr {
     std::atomic<unsigned long long> done{0};
 };
@@ -38,8 +39,16 @@ static inline int ppy_lds_attr(PpyLdsAttr &st, const void *kernel, int bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return PPY_ERR_LAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
+    if (bytes > PPY_LDS_MAX) return PPY_ERR_LAUNCH;
     if (st.done.load(std::memory_order_acquire) & bit) return PPY_OK;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return PPY_ERR_LAUNCH;
+    // once per kernel and device, so the limit must not be the FIRST launch's size (a loss kernel that meets a 255- then a
+    // 258-channel head, an SPP backward that meets 10x10 then 19x19 maps): always the CU's whole LDS
+    // -- minus the kernel's static __shared__ (the sum is what the runtime checks)
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return PPY_ERR_LAUNCH;
+    const int room = PPY_LDS_MAX - (int)fa.sharedSizeBytes;
+    if (bytes > room) return PPY_ERR_LAUNCH;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) return PPY_ERR_LAUNCH;
     st.done.fetch_or(bit, std::memory_order_release);
     return PPY_OK;
 }

@@ -32,6 +32,7 @@ class PlanCache(object):
         self.generation = 0
         self._sig = None               # parameter signature the executors' folded weights were derived from
         self._tensors = None
+        self._dirty = False            # set by writers that bypass autograd's version counters (mark_dirty)
         # the check costs ~0.14 ms of host time per forward (468 tensors): a server whose weights are final may switch it off
         self.pinned = os.environ.get('PPYOLO_HIP_PIN_WEIGHTS', '0') == '1'
         self.use_graph = os.environ.get('PPYOLO_HIP_GRAPH', '1') != '0'
@@ -52,10 +53,14 @@ class PlanCache(object):
         if ts is None:          # (walking the module tree costs ~1 ms: once per clear(); rebinding `.data` keeps the Parameter objects)
             m = self._model
             ts = self._tensors = [t for t in list(m.parameters()) + list(m.buffers()) if t.device.type != 'meta']
-        a = 0
-        for t in ts:
-            a ^= t.data_ptr()
-        return (sum([t._version for t in ts]), a)
+        # order-sensitive (the caching allocator hands freed addresses to OTHER parameters across EMA.apply() / restore(), and a
+        # sum / XOR of the addresses is blind to such a permutation)
+        return hash(tuple([(t._version, t.data_ptr()) for t in ts]))
+
+    def mark_dirty(self):
+        """Explicit invalidation for writers the signature cannot see: the HIP training kernels update BatchNorm running
+        statistics through raw pointers (no autograd version bump), and TrainStep re-binds the num_batches_tracked buffers."""
+        self._dirty = True
 
     def check_current(self):
         """The executors hold COPIES of the folded / re-laid / split weights: drop them when the parameters they were derived
@@ -64,6 +69,11 @@ class PlanCache(object):
         native blob is such a copy too."""
         if self.pinned:
             return
+        if self._dirty:
+            self._dirty = False
+            self._tensors = None           # buffers may have been re-bound
+            if self._ex or self.blob is not None:
+                self.clear()
         sig = self._signature()
         if self._sig is not None and sig != self._sig and (self._ex or self.blob is not None):
             self.clear()

@@ -793,6 +793,7 @@ class TrainStep(object):
             raise PPYoloHipError('the training step needs ROCm device tensors; there is no CPU path')
         self.tape = []
         self.flops = 0
+        self._prep_done = False          # a step that raised after _prepare_weights() must not leave stale f16x2 planes behind
         if self._amax_arena is not None:
             self._amax_arena.zero_()
             self._amax_next = 0
@@ -807,6 +808,18 @@ class TrainStep(object):
     def head_loss_backward(self, feats, gt_box, targets, inject_douts=None):
         """Head forward on the given backbone features (list of Act, shallowest first), loss, backward, -> loss terms [6]."""
         cfg, hcfg = self.cfg, self.cfg.head
+        try:
+            return self._head_loss_backward(feats, gt_box, targets, inject_douts, cfg, hcfg)
+        finally:
+            self.tape = []
+            self._prep_done = False
+            # BatchNorm running statistics / counters were written through raw pointers (no autograd version bump) and the
+            # counters may have been re-bound: inference executors folded from the old values are stale
+            plans = getattr(self.model, '_plans', None)
+            if plans is not None:
+                plans.mark_dirty()
+
+    def _head_loss_backward(self, feats, gt_box, targets, inject_douts, cfg, hcfg):
         with torch.no_grad():
             self._prepare_weights()
             outs = self.head(feats)
@@ -831,8 +844,6 @@ class TrainStep(object):
             for fn in reversed(self.tape):
                 fn()
         self.outs = outs
-        self.tape = []
-        self._prep_done = False
         if self._prep is None and self.gflat is not None:
             self._build_prep()
         return loss6
@@ -963,6 +974,8 @@ class TrainStep(object):
         read from `flat`, a copy of the flat gradient buffer taken after an earlier one (then the results are views of it
         wherever no re-layout is needed)."""
         out = {}
+        if self.gflat is None:
+            raise PPYoloHipError('grads(): no step has run yet (the flat gradient buffer is allocated by the first one)')
         base = self.gflat.data_ptr()
         for k in self.train_keys:
             g = self.G[k]

@@ -143,3 +143,45 @@ def test_g9_decode_harness(golden, model_shapes):
         p = p.numpy()
         assert np.array_equal(p[:, 2:], g['b_boxes%d' % i]) and np.array_equal(p[:, 1], g['b_scores%d' % i])
         assert np.array_equal(p[:, 0].astype(np.int32), g['b_classes%d' % i])
+
+
+@pytest.mark.parametrize('tag,cfgc', [('r18vd_416', PPYOLO_r18vd_Config), ('r50vd_608', PPYOLO_2x_Config)])
+def test_g18_headline_sizes(golden, tag, cfgc, model_shapes):
+    """BASELINE.json configs[1] / configs[2] at their own sizes (batch 8): the oracle -- fp32 and float64 -- against rows AND
+    keep indices the reference itself produced there (tools/make_goldens.py g18: the reference's matrix_nms instrumented for
+    its indices).  Bit for bit at the fixture's thread count; the fixture also carries the reference's distance from ITSELF
+    under other summation orders (1 thread, ATen's native convolution, one image at a time), checked to be self-consistent."""
+    g = golden('g18_' + tag)
+    S, N = int(g['meta'][0]), int(g['meta'][1])
+    cfg = cfgc()
+    sd = synth.synth_state_dict(model_shapes(cfg), seed=0)
+    x = synth.synth_images(N, S)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        feats, outs = orc.backbone_and_head(sd, cfg, x)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        _, outs64 = orc.backbone_and_head(sd64, cfg, x.double())
+    finally:
+        torch.set_num_threads(threads)
+    for lv, o in enumerate(outs):
+        idx = T(g['out%d_idx' % lv])
+        assert tuple(o.shape) == tuple(g['out%d_shape' % lv])
+        assert torch.equal(o.reshape(-1)[idx], T(g['out%d_val' % lv])), 'head level %d' % lv
+        # (the reference's DCNv2 keeps fp32 pieces -- the sampling grid's arange -- inside its float64 run, the oracle's float64
+        # run is float64 throughout: 5e-8 apart at R50vd, bit-equal at r18vd; the fp32 runs are 3e-6 rms from either)
+        assert (outs64[lv].reshape(-1)[idx] - T(g['out%d_val64' % lv])).abs().max() <= 2e-7, 'head level %d (float64)' % lv
+    nms = dict(cfg.nms_cfg)
+    nms.pop('nms_type')
+    for k in ('a', 'b'):
+        for run, oo in (('t8', outs), ('f64', outs64)):
+            with torch.no_grad():
+                boxes, scores = orc.decode_all(oo, cfg.head, T(g['im_size_' + k]).to(oo[0].dtype))
+            for i in range(N):
+                rows, keep = orc.matrix_nms(boxes[i], scores[i], return_index=True, **nms)
+                ref = T(g['%s_%s_pred%d' % (run, k, i)])
+                assert torch.equal(rows, ref) if run == 't8' else (rows.shape == ref.shape and (rows - ref).abs().max() <= 1e-4), (k, run, i)
+                assert np.array_equal(np.asarray(keep), g['%s_%s_keep%d' % (run, k, i)]), (k, run, i)
+        sp = g['spread_' + k]                       # rows: runs; columns: unmatched, out of place, score, box px, box / side
+        assert sp.shape == (len(g['runs']), 5) and not sp[0].any() and sp[:, 0].max() == 0
+        assert sp[:, 2].max() <= 1e-6 and sp[:, 4].max() <= 2e-5      # the reference agrees with itself to ~1e-5 of a box side

@@ -776,8 +776,151 @@ def g17_paddle_names():
     save('g17_paddle_names', **out)
 
 
+_G18_IMS = {'a': [[480., 640.]] * 8,                                                     # BASELINE.md's im_size
+            'b': [[480., 640.], [375., 500.], [608., 608.], [1080., 1920.]] * 2}            # tests/test_gpu_model.py::_FULL_IMS
+# Evaluations of the SAME reference network that are all "the reference": the first is the primary fixture, the others measure
+# the reference against ITSELF.  On the build box MKLDNN picks the same blocking for 2..16 threads (bit-identical results, measured),
+# so the ensemble is: 8 threads; 1 thread; ATen's native convolution (torch.backends.mkldnn off); the images one at a time;
+# and the reference's own modules in float64 (= the exact answer).
+_G18_RUNS = ('t8', 't1', 'native', 'bs1', 'f64')
+
+
+class _RecordNms:
+    """The reference's matrix_nms (model/matrix_nms.py:102-151) hands back rows, not indices, and full-size batches contain
+    bit-identical boxes (dozens of boxes clipped to the whole image), so rows cannot be matched back by value.  This records
+    what the reference itself computes on the way -- the two torch.argsort results and the decayed scores _matrix_nms returns
+    -- from which the flat index (box * C + class) of every returned row follows by the reference's own indexing."""
+
+    def __enter__(self):
+        import model.matrix_nms as mm
+        self.mm, self.real_sort, self.real_inner = mm, torch.argsort, mm._matrix_nms
+        self.sorts, self.decayed = [], []
+
+        def argsort(*a, **k):
+            r = self.real_sort(*a, **k)
+            self.sorts.append(r)
+            return r
+
+        def inner(*a, **k):
+            r = self.real_inner(*a, **k)
+            self.decayed.append(r)
+            return r
+        torch.argsort, mm._matrix_nms = argsort, inner
+        return self
+
+    def __exit__(self, *exc):
+        torch.argsort, self.mm._matrix_nms = self.real_sort, self.real_inner
+
+    def keep_index(self, pred, boxes, scores, nms_cfg, C=80):
+        if pred[0, 0] < 0:
+            return np.zeros((0,), np.int64)
+        assert len(self.sorts) == 2 and len(self.decayed) == 1
+        cand = (scores > nms_cfg['score_threshold']).nonzero()                    # matrix_nms.py:110, :115
+        first = self.sorts[0][:nms_cfg['nms_top_k']] if nms_cfg['nms_top_k'] > 0 else self.sorts[0]
+        kept = cand[first][self.decayed[0] >= nms_cfg['post_threshold']]          # :131
+        rows = kept[self.sorts[1][:nms_cfg['keep_top_k']]]                        # :139-141
+        assert torch.equal(rows[:, 1].float(), pred[:, 0]) and torch.equal(boxes[rows[:, 0]], pred[:, 2:6])
+        return (rows[:, 0] * C + rows[:, 1]).numpy().astype(np.int64)
+
+
+def g18_headline_sizes():
+    """BASELINE.json configs[1] / configs[2] at their OWN sizes, by the reference itself (model/ppyolo.py:19-22 ->
+    model/head.py:424-469): r18vd-416 and R50vd-608, 8 images, with (a) BASELINE's im_size = (480, 640) and (b) the mixed
+    original sizes of the GPU tests.  Evaluated five ways (_G18_RUNS): the summation order of the reference's own CPU
+    convolutions changes with the thread count / backend / batch, which gives the distance of the reference from ITSELF
+    (two correct fp32 evaluations of one network), and its float64 run gives its distance from the exact answer.  Stored:
+    detections + keep indices of every run, the spread, and a strided sample of the raw head outputs (the full tensors are
+    62 MB) of the primary and the float64 run."""
+    import copy
+    from model.head import get_iou_aware_score as gi, yolo_box as yb
+    for tag, C, S in (('r18vd_416', PPYOLO_r18vd_Config, 416), ('r50vd_608', PPYOLO_2x_Config, 608)):
+        cfg = C()
+        m, _ = build_ref(cfg, 0)
+        m64 = copy.deepcopy(m).double()
+        x = synth.synth_images(8, S)
+        arrs = {'meta': np.array([S, 8, 0, 0]), 'runs': np.array(_G18_RUNS)}
+        for k, v in _G18_IMS.items():
+            arrs['im_size_' + k] = np.array(v, np.float32)
+        nms = {k_: v_ for k_, v_ in cfg.nms_cfg.items() if k_ != 'nms_type'}
+
+        def network(run):
+            mm, xx = (m64, x.double()) if run == 'f64' else (m, x)
+            with torch.no_grad():
+                if run == 'bs1':
+                    per = [mm.backbone(xx[i:i + 1]) for i in range(8)]
+                    feats = [torch.cat([p[l] for p in per]) for l in range(len(per[0]))]
+                    outs = [torch.cat(o) for o in zip(*[mm.head._get_outputs(p) for p in per])]
+                else:
+                    feats = mm.backbone(xx)
+                    outs = mm.head._get_outputs(feats)
+            return mm, feats, outs
+
+        heads = {}
+        for run in _G18_RUNS:
+            torch.set_num_threads(1 if run == 't1' else 8)          # in force for everything this run computes
+            torch.backends.mkldnn.enabled = run != 'native'
+            mm, feats, outs = network(run)
+            heads[run] = outs
+            with torch.no_grad():
+                for k, v in _G18_IMS.items():
+                    ims = torch.tensor(v, dtype=outs[0].dtype)
+                    if run == _G18_RUNS[0]:
+                        arrs['ncand_' + k] = np.array(_assert_tie_free(m, x, ims, cfg))
+                    bs, ss = [], []
+                    for i, o in enumerate(outs):
+                        if mm.head.iou_aware:
+                            o = gi(o, 3, 80, mm.head.iou_aware_factor)
+                        b_, s_ = yb(o, mm.head._anchors[mm.head.anchor_masks[i]], mm.head.downsample[i], 80, mm.head.scale_x_y,
+                                    ims, True, cfg.nms_cfg['score_threshold'])
+                        bs.append(b_)
+                        ss.append(s_)
+                    boxes, scores = torch.cat(bs, 1), torch.cat(ss, 1)
+                    whole = mm.head.get_prediction(feats, ims)                  # the reference's own path, untouched
+                    for i in range(8):
+                        with _RecordNms() as rec:
+                            p = matrix_nms(boxes[i], scores[i], **nms)
+                        assert torch.equal(p, whole[i]), (run, k, i, p.shape, whole[i].shape, (p - whole[i]).abs().max() if p.shape == whole[i].shape else None)
+                        assert len(torch.unique(p[:, 1])) == p.shape[0]
+                        arrs['%s_%s_pred%d' % (run, k, i)] = p
+                        arrs['%s_%s_keep%d' % (run, k, i)] = rec.keep_index(p, boxes[i], scores[i], nms)
+        torch.set_num_threads(8)
+        torch.backends.mkldnn.enabled = True
+        # strided samples of the raw head outputs (primary and float64) + the reference-vs-reference distance per level
+        r0 = _G18_RUNS[0]
+        for lv, o in enumerate(heads[r0]):
+            flat = o.reshape(-1)
+            idx = torch.arange(0, flat.numel(), max(1, flat.numel() // 8192))[:8192]
+            arrs['out%d_idx' % lv], arrs['out%d_val' % lv] = idx.numpy(), flat[idx]
+            arrs['out%d_val64' % lv] = heads['f64'][lv].reshape(-1)[idx]
+            arrs['out%d_shape' % lv] = np.array(o.shape)
+            arrs['out%d_rms' % lv] = np.array(float(o.double().pow(2).mean().sqrt()))
+            arrs['out%d_spread_max' % lv] = np.array([float((heads[r][lv].double() - o.double()).abs().max()) for r in _G18_RUNS])
+            arrs['out%d_spread_rms' % lv] = np.array([float((heads[r][lv].double() - o.double()).pow(2).mean().sqrt()) for r in _G18_RUNS])
+            print('   %s head level %d: reference runs %s vs %s: max %s rms %s' % (
+                tag, lv, _G18_RUNS, r0, ['%.2e' % v for v in arrs['out%d_spread_max' % lv]], ['%.2e' % v for v in arrs['out%d_spread_rms' % lv]]))
+        # the reference against itself on the detections: rows matched by keep index
+        for k in _G18_IMS:
+            sp = np.zeros((len(_G18_RUNS), 5))       # unmatched rows, rows out of place, max |score|, max |box| px, max |box| / side
+            for j, run in enumerate(_G18_RUNS):
+                for i in range(8):
+                    a, ka = arrs['%s_%s_pred%d' % (r0, k, i)], arrs['%s_%s_keep%d' % (r0, k, i)]
+                    b, kb = arrs['%s_%s_pred%d' % (run, k, i)], arrs['%s_%s_keep%d' % (run, k, i)]
+                    pos = {int(q): r for r, q in enumerate(kb)}
+                    ia = [r for r, q in enumerate(ka) if int(q) in pos]
+                    ib = [pos[int(ka[r])] for r in ia]
+                    A, B = a[ia].double(), b[ib].double()
+                    side = torch.maximum(A[:, 4] - A[:, 2], A[:, 5] - A[:, 3]).clamp_min(1.0)
+                    d = (A[:, 2:] - B[:, 2:]).abs().max(dim=1).values
+                    sp[j] = np.maximum(sp[j], [max(len(ka), len(kb)) - len(ia), sum(1 for p_, q_ in zip(ia, ib) if p_ != q_),
+                                               float((A[:, 1] - B[:, 1]).abs().max()), float(d.max()), float((d / side).max())])
+            arrs['spread_' + k] = sp
+            print('   %s im_size %s: reference runs %s vs %s: rows unmatched / out of place / score / box px / box of side\n%s'
+                  % (tag, k, _G18_RUNS, r0, sp))
+        save('g18_' + tag, **arrs)
+
+
 ALL = dict(g1=g1_conv_units, g2=g2_dcn, g3=g3_coord_spp, g4=g4_decode, g5=g5_matrix_nms, g67=g6_g7_models,
-           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward, g16=g16_train_step_backbone, g17=g17_paddle_names)
+           g8=g8_preprocess, g9=g9_decode_harness, g10=g10_coco_records, g11=g11_state_dict_layout, g12=g12_train_step, g13=g13_ema, g14=g14_train_loop, g15=g15_dcn_backward, g16=g16_train_step_backbone, g17=g17_paddle_names, g18=g18_headline_sizes)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
