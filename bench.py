@@ -65,6 +65,130 @@ def build_model(cfg_name, device):
     return m.to(device), sd, cfg
 
 
+def model_from_sd(cfg_name, sd, device):
+    import config as C
+    from model.ppyolo import PPYOLO
+    cfg = getattr(C, cfg_name)()
+    bb = C.select_backbone(cfg.backbone_type)(**cfg.backbone)
+    hd = C.select_head(cfg.head_type)(yolo_loss=None, nms_cfg=cfg.nms_cfg, **cfg.head)
+    m = PPYOLO(bb, hd)
+    m.load_state_dict(sd)
+    m.eval()
+    hd.set_dropblock(is_test=True)
+    return m.to(device)
+
+
+def worst_case_leg(wl, dev, x, ims, sd, cfg, depth, seconds, cpu_threads):
+    """Not `value`: the WHOLE step in SURVEY 8(d)'s second score regime -- the head as a default initialisation leaves it (output
+    logits ~ N(0, 0.1)), so every one of the 1 819 440 (box, class) pairs of an image passes the 0.01 threshold; the reference
+    sorts 1.8 M keys per image there (model/matrix_nms.py:120; BASELINE.md section 2: 1.32 img/s on 8 CPU threads).  Same
+    network, same images; only the three output convolutions are rescaled (bias 0, weights x a factor measured on one forward so
+    that the logits' std is 0.1).  The CPU oracle runs ONE batch with the same weights beside it."""
+    from collections import OrderedDict
+    sdw = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for k in sdw:
+        if k.startswith('head.yolo_output_convs.') and k.endswith('.conv.bias'):
+            sdw[k].zero_()
+    model = model_from_sd(wl['cfg'], sdw, dev)
+    ex = model._plans.executor(x)
+    ex.set_inputs(x, ims)
+    ex.run()
+    torch.cuda.synchronize()
+    for i, a in enumerate(ex.plan.head_outs):
+        sdw['head.yolo_output_convs.%d.conv.weight' % i] *= 0.1 / float(ex.view(a).dense().std())
+    del ex, model
+    model = model_from_sd(wl['cfg'], sdw, dev)
+    lanes = model.in_flight(depth).lanes(x)
+    for e, _ in lanes:
+        e.set_inputs(x, ims)
+
+    def go(n, d):
+        for i in range(n):
+            e, st = lanes[i % d]
+            with torch.cuda.stream(st):
+                e.run()
+        torch.cuda.synchronize()
+
+    def rate(d):
+        go(3 * d, d)
+        n = 8
+        while True:
+            t0 = time.perf_counter()
+            go(n, d)
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 1 << 14:
+                return x.shape[0] * n / dt, dt / n * 1e3
+            n *= 4
+    v2, ms2 = rate(depth)
+    v1, ms1 = rate(1) if depth > 1 else (v2, ms2)
+    cands = int(lanes[0][0].cand_count.float().mean().item())
+    out = dict(value=round(v2, 1), unit='images/s', ms_per_step=round(ms2, 3), one_batch_at_a_time=round(v1, 1),
+               candidates_per_image=cands,
+               regime='every (box, class) pair above the score threshold: output convolutions rescaled to logits ~ N(0, 0.1), bias 0 '
+                      '(the reference\'s default initialisation); same images, same network otherwise')
+    if cpu_threads:
+        from oracle import ppyolo_oracle as orc
+        torch.set_num_threads(cpu_threads)
+        xc, ic = x.cpu(), ims.cpu()
+        orc.ppyolo_forward(sdw, cfg, xc[:1], ic[:1])
+        t0 = time.perf_counter()
+        orc.ppyolo_forward(sdw, cfg, xc, ic)
+        dt = time.perf_counter() - t0
+        out['cpu_baseline'] = dict(value=round(x.shape[0] / dt, 3), unit='images/s', cores=cpu_threads, kind='port',
+                                   sample='1 batch of %d images in the same regime (the oracle sorts all 1.8 M candidates per image like the reference)' % x.shape[0])
+    return out
+
+
+def pmc_traffic_leg(argv_tail, nconv, timeout=300):
+    """HBM-side bytes of the convolution launches, MEASURED BY THIS RUN: bench.py re-executes itself twice under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (counters need their own passes and their own process: the guide's
+    HBM / rocprofv3 section) as a short eager one-lane child, and sums the counters of the convolution kernels per pass of the
+    plan (= per stem launch).  gfx950: FETCH_SIZE reports half of a 16 B/lane streaming read (same section), hence 2 x FETCH +
+    WRITE; both are KB.  Returns (bytes per conv launch, source dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused')
+    tot = {}
+    t0 = time.perf_counter()
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='ppy_pmc_')
+        cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-child'] + argv_tail
+        env = dict(os.environ, TMPDIR='/tmp')
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection*.csv'), recursive=True)
+            val, passes = 0.0, 0
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get('Counter_Name') != counter:
+                            continue
+                        k = r['Kernel_Name']
+                        if 'stem_conv' in k:
+                            passes += 1
+                        if any(n in k for n in main_k) or 'splitk_reduce' in k:
+                            val += float(r['Counter_Value'])
+            if not passes:
+                return None, 'no counter rows for %s' % counter
+            tot[counter] = val / passes
+        except Exception as exc:       # a profiler that is missing / hangs / fails must not take the benchmark line with it
+            return None, '%s pass failed: %s' % (counter, type(exc).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    byt = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
+    return round(byt / nconv), dict(measured_by='this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an eager one-lane child process',
+                                    hbm_bytes_per_step=round(byt), fetch_size_kb_per_step=round(tot['FETCH_SIZE'], 1),
+                                    write_size_kb_per_step=round(tot['WRITE_SIZE'], 1), gfx950_fetch_correction=2.0,
+                                    seconds=round(time.perf_counter() - t0, 1), stale=False)
+
+
 def _tuned_path(mode):
     from ppyolo_hip import engine
     return engine._TUNED_PATHS[mode]
@@ -618,6 +742,10 @@ def main():
                     '([world*batch, keep_top_k+1, 6]) to this .npy file (tests)')
     ap.add_argument('--train', action='store_true', help='BASELINE config 5: time the training step (ppyolo_hip/train.py) instead of '
                     'inference; prints its own JSON line')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
+                    '(then the committed summary under profiles/ is quoted, marked stale)')
+    ap.add_argument('--pmc-child', action='store_true', help='(internal) the short eager one-lane run the PMC passes profile')
+    ap.add_argument('--no-worst-case', action='store_true', help='skip the whole-step measurement in the all-pass score regime')
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state running before the timed K steps and '
                     'length of the `sustained` measurement (the board is power-managed: DESIGN.md 4.1)')
     a = ap.parse_args()
@@ -653,7 +781,7 @@ def main():
     from ppyolo_hip import synth
     x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank + a.seed_offset).to(dev)
     ims = synth.synth_im_size(a.batch).to(dev)
-    depth = max(1, a.in_flight)
+    depth = 1 if a.pmc_child else max(1, a.in_flight)
     lanes = model.in_flight(depth).lanes(x)            # [(executor, stream)]; depth 1 = the plain forward's executor
     ex = lanes[0][0]
     for k, (e, _) in enumerate(lanes):
@@ -679,6 +807,11 @@ def main():
                     op['cfg'], op['splitk'] = src['cfg'], src['splitk']
             e._size_workspace()
             e._link_splits()
+    if a.pmc_child:          # profiled by pmc_traffic_leg: a few more eager passes of the plan, nothing else
+        for _ in range(3):
+            ex.run()
+        torch.cuda.synchronize()
+        return
     gats = [pd.DetectionGatherer(a.batch, ex.out_dets.shape[1], dev, world) for _ in lanes]
     for e, _ in lanes:
         e.use_graph = not a.no_graph
@@ -796,16 +929,21 @@ def main():
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
         # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
         traffic, traffic_src = None, None
-        if a.workload == 'r50vd_608' and a.batch == 8:
+        if world == 1 and not a.no_pmc:
+            traffic, traffic_src = pmc_traffic_leg(['--workload', a.workload, '--batch', str(a.batch)], nconv)
+            if traffic is None:
+                pmc_failed = traffic_src
+                traffic_src = None
+        if traffic is None and a.workload == 'r50vd_608' and a.batch == 8:
             import glob
             files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')) if '_train_' not in os.path.basename(f))
             if files:
                 with open(files[-1]) as fh:
                     rec = json.load(fh)
                 traffic = round(rec['hbm_bytes_per_step'] / nconv)
-                traffic_src = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured', 'round 1'),
-                                   note='NOT measured by this run: rocprofv3 PMC passes need their own processes '
-                                        '(tools/prof_run.sh -> tools/pmc_traffic.py); committed summary of the named date')
+                traffic_src = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured', 'round 1'), stale=True,
+                                   note='NOT measured by this run (%s): committed rocprofv3 PMC summary of the named date '
+                                        '(tools/prof_run.sh -> tools/pmc_traffic.py)' % ('--no-pmc' if a.no_pmc else locals().get('pmc_failed', 'N > 1')))
         roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
                     traffic_unit='bytes per launch (mean over the conv launches of a step; PMC 2*FETCH_SIZE+WRITE_SIZE)',
@@ -822,6 +960,16 @@ def main():
                     achieved_vs_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
                     whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4))
+        if one_at_a_time is not None:
+            ms_one = a.batch / one_at_a_time * 1e3
+            roof['frac_one_lane'] = round(total_flops / (ms_one * 1e-3) / 1e12 / peak, 4)
+            roof['overlap'] = dict(ms_per_step_one_lane=round(ms_one, 3), ms_per_step_two_lanes=round(ms_per_step, 3),
+                                   hidden_fraction=round(1.0 - ms_per_step / ms_one, 4), conv_kernel_ms_per_step_solo=round(conv_ms, 3),
+                                   note='frac = conv FLOPs / SOLO conv kernel time (eager launches, HIP events); frac_one_lane / '
+                                        'whole_step_mfma_util = the same FLOPs / whole-step wall time with one / %d batches in flight; '
+                                        'hidden_fraction = share of a one-lane step the second lane hides.  Per-stream busy time and '
+                                        'the overlap of the two lanes from a rocprofv3 kernel trace of this loop: '
+                                        'profiles/r04_two_lane_timeline.txt (tools/two_lane_timeline.py)' % depth)
         out = dict(metric='images/sec PPYOLO R50-vd 608x608 bs=8' if a.workload == 'r50vd_608'
                    else 'images/sec %s bs=%d' % (a.workload, a.batch),
                    value=round(value, 2), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
@@ -858,6 +1006,12 @@ def main():
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:
             out['alt_math'] = alt_math_leg(wl, dev, x, ims, min(a.steps, 30), ex.math, depth)
+            if ex.math != 'fp32' and 'fp32' in out['alt_math']:
+                # `value` computes every product from 2-term fp16 splits (3 MFMA products, ~22-bit operands, fp32 accumulate);
+                # this is the same step with every convolution on the exact-fp32 MFMA, v_mfma_f32_32x32x2_f32
+                out['value_fp32_exact'] = out['alt_math']['fp32']
+                out['value_fp32_exact_note'] = ('same loop, every convolution on the exact-fp32 MFMA (PPYOLO_HIP_MATH=fp32): %.2f of the '
+                                                '157.3 TFLOP/s fp32-MFMA bound' % (out['alt_math']['fp32'] * total_flops / a.batch / 1e12 / FP32_MFMA_PEAK_TFLOPS))
         if world == 1 and not a.no_host_input:
             out['host_input'] = host_input_leg(ex, x, ims, min(a.steps, 30), lanes)
         if world == 1 and not a.no_host_input:
@@ -865,6 +1019,9 @@ def main():
                                                                  not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg, wl['size'], a.batch)
+        if world == 1 and not a.no_worst_case:
+            out['worst_case_regime'] = worst_case_leg(wl, dev, x, ims, sd, cfg, depth, min(a.min_seconds, 1.0) or 0.2,
+                                                      out['cpu_baseline']['cores'] if 'cpu_baseline' in out else 0)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

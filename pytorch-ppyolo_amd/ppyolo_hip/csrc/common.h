@@ -8,6 +8,7 @@
 #include "../../../include/ppyolo_hip.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define PPY_CHECK_ARG(cond) \

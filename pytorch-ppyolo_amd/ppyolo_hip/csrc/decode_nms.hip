@@ -608,6 +608,45 @@ __device__ __forceinline__ void rank_sort_desc(const unsigned long long *in, uns
     __syncthreads();
 }
 
+// MSB-first radix select over `count` keys of `total_bits` bits (key_of(c), c < count): the largest T such that at least `need`
+// keys are >= T, exact unless a digit's bin holds exactly the keys still needed (then the whole bin is taken: T = the bin's
+// lower edge, same set).  All NT threads of the workgroup call it; hist = [1 << RBITS], scratch = [32], sel = [3] in LDS.
+template <typename KeyFn>
+__device__ __forceinline__ unsigned long long radix_select_threshold(KeyFn key_of, int count, int need, int total_bits,
+                                                                       unsigned int *hist, int *scratch, int *sel) {
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0ull;
+    int shift = total_bits;
+    while (shift > 0) {
+        const int bits = shift < RBITS ? shift : RBITS;
+        const int hi_shift = shift;
+        shift -= bits;
+        for (int i = tid; i < (1 << RBITS); i += NT) hist[i] = 0u;
+        __syncthreads();
+        for (int c = tid; c < count; c += NT) {
+            const unsigned long long k = key_of(c);
+            if ((hi_shift >= 64 ? 0ull : (k >> hi_shift)) == prefix)
+                atomicAdd(&hist[(unsigned)((k >> shift) & ((1ull << bits) - 1ull))], 1u);
+        }
+        __syncthreads();
+        const int h0 = (int)hist[2 * tid], h1 = (int)hist[2 * tid + 1];
+        const int incl = block_suffix_sum(h0 + h1, scratch);
+        const int after = incl - (h0 + h1);   // candidates in bins above this thread's pair
+        if (after < need && need <= after + h1) {
+            sel[0] = 2 * tid + 1; sel[1] = after; sel[2] = h1;
+        } else if (after + h1 < need && need <= after + h1 + h0) {
+            sel[0] = 2 * tid; sel[1] = after + h1; sel[2] = h0;
+        }
+        __syncthreads();
+        prefix = (prefix << bits) | (unsigned long long)sel[0];
+        need -= sel[1];
+        const bool whole_bin = (sel[2] == need);
+        __syncthreads();
+        if (whole_bin) break;
+    }
+    return prefix << shift;
+}
+
 __device__ __forceinline__ float nanmin_(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
 
 struct NmsArgs {
@@ -616,7 +655,7 @@ struct NmsArgs {
     const int *cand_count;
     float *out_dets;
     int *out_count, *out_keep;
-    int M_total, C, cand_cap, top_k, keep_k, gaussian, idx_bits;
+    int M_total, C, cand_cap, top_k, keep_k, gaussian, idx_bits, N;
     float post_thr, sigma;
     char *ws;                  // per-image intermediates between the four kernels (NmsWs below)
 };
@@ -638,17 +677,151 @@ struct NmsWs {                 // one per image
     int K, pad[15];
 };
 
+// Large candidate lists (round 4).  A list of more than CCAP entries does not fit the select kernel's LDS cache, and walking
+// it from global memory in ONE workgroup per image took 2.9 ms per step in the all-pass regime (1.8 M candidates per image,
+// six walks of dependent loads on 8 of 256 CUs).  Now two chip-wide steps cut such a list down to a few thousand entries first:
+//   S  nms_sample_kernel  (1 workgroup / image)   NMS_SAMPLE keys from evenly spaced strata (a hashed position in each), the
+//      r-th largest of them by the LDS radix select = a score-key threshold t with ~4 x nms_top_k entries expected above it
+//   C  nms_collect_kernel (NMS_CG workgroups / image)   one streaming pass over the keys: every entry with key >= t (ALL ties
+//      included) goes to a compact list; the exact number of such entries is counted on the way
+// and the select kernel runs on the compact list iff it is certain to hold the whole top-k: count(key >= t) >= nms_top_k, no
+// overflow.  Otherwise (probability ~1e-9 for random order; heavy ties) it walks the original list as before -- the result is
+// the same either way: the top-k by (score desc, index asc) of a superset of the top-k.
+constexpr int NMS_SAMPLE = CCAP;          // sampled keys (staged in the same LDS cache)
+constexpr int NMS_CG = 64;                // workgroups per image of the collect pass
+constexpr int NMS_CCAP2 = 32768;          // compact list capacity per image (entries)
+constexpr int NMS_CL = 4096;              // survivors one collect workgroup can hold
+struct NmsBig {                            // one per image, behind the NmsWs array
+    uint32_t thr_key;
+    int ccount;                            // entries with key >= thr_key (exact), -1: the list is small, nothing to do
+    int bad;                               // a collect workgroup overflowed: the compact list is incomplete
+    int pad[13];
+};
+__device__ __forceinline__ NmsBig *nms_big(const NmsArgs &p, int n) {
+    return reinterpret_cast<NmsBig *>(p.ws + (size_t)p.N * sizeof(NmsWs)) + n;
+}
+__device__ __forceinline__ uint32_t *nms_compact(const NmsArgs &p, int n) {      // [NMS_CCAP2] keys, then [NMS_CCAP2] indices
+    return reinterpret_cast<uint32_t *>(p.ws + (size_t)p.N * (sizeof(NmsWs) + sizeof(NmsBig))) + (size_t)n * 2 * NMS_CCAP2;
+}
+
+__global__ void __launch_bounds__(NT) nms_sample_kernel(const NmsArgs p) {
+    __shared__ unsigned int hist[1 << RBITS];
+    __shared__ int scratch[32];
+    __shared__ int s_sel[3];
+    extern __shared__ unsigned long long scache[];      // [NMS_SAMPLE] (dynamic)
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int count = min(p.cand_count[n], p.cand_cap);
+    NmsBig *hdr = nms_big(p, n);
+    if (count <= CCAP) {
+        if (tid == 0) { hdr->ccount = -1; hdr->bad = 0; }
+        return;
+    }
+    const uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
+    // stratum i = [i count / S, (i + 1) count / S): one key from a hashed position inside it (a fixed stride would resonate
+    // with the 240 (anchor, class) pairs per cell of the decode's append order)
+    for (int base = 0; base < NMS_SAMPLE; base += NT * 8) {
+        uint32_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned i = (unsigned)(base + u * NT + tid);
+            const long long lo = (long long)i * count / NMS_SAMPLE, hi = (long long)(i + 1) * count / NMS_SAMPLE;
+            const unsigned h = (i * 2654435761u) ^ ((i * 2246822519u) >> 15);
+            kk[u] = ckey[lo + (long long)(h % (unsigned)(hi - lo))];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) scache[base + u * NT + tid] = (unsigned long long)kk[u];
+    }
+    __syncthreads();
+    // the r-th largest sample sits at rank ~ r count / S of the whole list: aim at 4 x top_k, never fewer than 16 samples
+    long long r = (4ll * p.top_k * NMS_SAMPLE + count - 1) / count;
+    r = r < 16 ? 16 : (r > NMS_SAMPLE / 2 ? NMS_SAMPLE / 2 : r);
+    auto key_of = [&](int c) -> unsigned long long { return scache[c]; };
+    const unsigned long long T = radix_select_threshold(key_of, NMS_SAMPLE, (int)r, 32, hist, scratch, s_sel);
+    if (tid == 0) { hdr->thr_key = (uint32_t)T; hdr->ccount = 0; hdr->bad = 0; }
+}
+
+__global__ void __launch_bounds__(512) nms_collect_kernel(const NmsArgs p) {
+    __shared__ int l_pos[NMS_CL];
+    __shared__ int l_n, l_base;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int count = min(p.cand_count[n], p.cand_cap);
+    if (count <= CCAP) return;
+    NmsBig *hdr = nms_big(p, n);
+    const uint32_t t = hdr->thr_key;
+    const uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
+    const uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
+    if (tid == 0) l_n = 0;
+    __syncthreads();
+    auto take = [&](uint32_t k, int c) {
+        if (k >= t) {
+            const int q = atomicAdd(&l_n, 1);
+            if (q < NMS_CL) l_pos[q] = c;
+        }
+    };
+    // this workgroup's slice, in units of four keys (16-byte loads when the list is aligned; four of them in flight per thread)
+    const int quads = (count + 3) >> 2;
+    const int per = (quads + NMS_CG - 1) / NMS_CG;
+    const int q0 = blockIdx.x * per, q1 = min(q0 + per, quads);
+    if ((reinterpret_cast<uintptr_t>(ckey) & 15) == 0) {
+        constexpr int U = 4;
+        for (int qb = q0; qb < q1; qb += 512 * U) {
+            uintx4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = qb + u * 512 + tid;
+                v[u] = uintx4{0u, 0u, 0u, 0u};
+                if (q < q1) v[u] = *reinterpret_cast<const uintx4 *>(ckey + 4 * (long long)q);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = qb + u * 512 + tid;
+                if (q < q1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * q + e < count) take(v[u][e], 4 * q + e);
+                }
+            }
+        }
+    } else {
+        for (int c = 4 * q0 + tid; c < min(4 * q1, count); c += 512) take(ckey[c], c);
+    }
+    __syncthreads();
+    const int total = l_n, nl = min(total, NMS_CL);
+    if (tid == 0) {
+        l_base = total > 0 ? atomicAdd(&hdr->ccount, total) : 0;
+        if (total > NMS_CL) atomicExch(&hdr->bad, 1);
+    }
+    __syncthreads();
+    uint32_t *k2 = nms_compact(p, n), *i2 = k2 + NMS_CCAP2;
+    for (int i = tid; i < nl; i += 512) {
+        const int g = l_base + i, c = l_pos[i];
+        if (g < NMS_CCAP2) {
+            k2[g] = ckey[c];
+            i2[g] = cidx[c];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT) nms_select_kernel(const NmsArgs p) {
     __shared__ unsigned long long skey[KMAX], skey2[KMAX];
     __shared__ unsigned int hist[1 << RBITS];
     int *srank = reinterpret_cast<int *>(hist);                 // the histogram is dead once the threshold is known
     __shared__ int scratch[32];
-    __shared__ int s_bin, s_above, s_binc, s_cnt;
+    __shared__ int s_sel[3], s_cnt;
 
     const int n = blockIdx.x, tid = threadIdx.x;
     const uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
     const uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
-    const int count = min(p.cand_count[n], p.cand_cap);
+    int count = min(p.cand_count[n], p.cand_cap);
+    if (count > CCAP) {          // a large list: the compact one instead, iff it holds every entry >= its threshold and >= top_k of them
+        const NmsBig *hdr = nms_big(p, n);
+        const int cc = hdr->ccount;
+        if (hdr->bad == 0 && cc >= p.top_k && cc <= NMS_CCAP2) {
+            ckey = nms_compact(p, n);
+            cidx = ckey + NMS_CCAP2;
+            count = cc;
+        }
+    }
     const int ib = p.idx_bits;
     const unsigned long long idx_mask = (1ull << ib) - 1ull;
     float *dets = p.out_dets + (long long)n * p.keep_k * 6;
@@ -692,38 +865,7 @@ __global__ void __launch_bounds__(NT) nms_select_kernel(const NmsArgs p) {
     // ---- 1. top-k threshold by MSB-first radix select (reference :120-125) ----
     const int K = min(p.top_k, count);
     unsigned long long T = 0ull;
-    if (count > p.top_k) {
-        unsigned long long prefix = 0ull;
-        int shift = 32 + ib, need = K;
-        while (shift > 0) {
-            const int bits = shift < RBITS ? shift : RBITS;
-            const int hi_shift = shift;
-            shift -= bits;
-            for (int i = tid; i < (1 << RBITS); i += NT) hist[i] = 0u;
-            __syncthreads();
-            for (int c = tid; c < count; c += NT) {
-                const unsigned long long k = comp_of(c);
-                if ((hi_shift >= 64 ? 0ull : (k >> hi_shift)) == prefix)
-                    atomicAdd(&hist[(unsigned)((k >> shift) & ((1ull << bits) - 1ull))], 1u);
-            }
-            __syncthreads();
-            const int h0 = (int)hist[2 * tid], h1 = (int)hist[2 * tid + 1];
-            const int incl = block_suffix_sum(h0 + h1, scratch);
-            const int after = incl - (h0 + h1);   // candidates in bins above this thread's pair
-            if (after < need && need <= after + h1) {
-                s_bin = 2 * tid + 1; s_above = after; s_binc = h1;
-            } else if (after + h1 < need && need <= after + h1 + h0) {
-                s_bin = 2 * tid; s_above = after + h1; s_binc = h0;
-            }
-            __syncthreads();
-            prefix = (prefix << bits) | (unsigned long long)s_bin;
-            need -= s_above;
-            const bool whole_bin = (s_binc == need);
-            __syncthreads();
-            if (whole_bin) break;
-        }
-        T = prefix << shift;
-    }
+    if (count > p.top_k) T = radix_select_threshold(comp_of, count, K, 32 + ib, hist, scratch, s_sel);
     // ---- 2. collect the K survivors, sort them (score desc, index asc) ----
     if (tid == 0) s_cnt = 0;
     for (int i = tid; i < KMAX; i += NT) skey[i] = 0ull;
@@ -1023,7 +1165,9 @@ extern "C" int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, 
     return ppy_launch_status();
 }
 
-extern "C" size_t ppy_matrix_nms_workspace_bytes(int N) { return N > 0 ? (size_t)N * sizeof(NmsWs) : 0; }
+extern "C" size_t ppy_matrix_nms_workspace_bytes(int N) {
+    return N > 0 ? (size_t)N * (sizeof(NmsWs) + sizeof(NmsBig) + (size_t)2 * NMS_CCAP2 * sizeof(uint32_t)) : 0;
+}
 
 extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_classes, const uint32_t *cand_key,
                                   const uint32_t *cand_idx, const int *cand_count, int cand_cap, int N,
@@ -1034,7 +1178,7 @@ extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_class
     PPY_CHECK_ARG(boxes && cand_key && cand_idx && cand_count && out_dets && out_count && out_keep_idx);
     PPY_CHECK_ARG(N > 0 && M_total > 0 && num_classes > 0 && cand_cap > 0);
     PPY_CHECK_ARG(((uintptr_t)boxes & 15) == 0);
-    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < (size_t)N * sizeof(NmsWs)) return PPY_ERR_WORKSPACE;
+    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < ppy_matrix_nms_workspace_bytes(N)) return PPY_ERR_WORKSPACE;
     if (nms_top_k < 1 || nms_top_k > KMAX || keep_top_k < 1 || keep_top_k > nms_top_k) return PPY_ERR_UNSUPPORTED;
     const long long span = (long long)M_total * num_classes;
     PPY_CHECK_ARG(span < (1ll << 31));
@@ -1046,9 +1190,16 @@ extern "C" int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_class
     p.M_total = M_total; p.C = num_classes; p.cand_cap = cand_cap; p.top_k = nms_top_k; p.keep_k = keep_top_k;
     p.gaussian = use_gaussian ? 1 : 0; p.idx_bits = ib; p.post_thr = post_threshold; p.sigma = gaussian_sigma;
     p.ws = (char *)ws;
-    static PpyLdsAttr attr;
+    p.N = N;
+    static PpyLdsAttr attr, attr_s;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(nms_select_kernel), CCAP * 8) != PPY_OK) return PPY_ERR_LAUNCH;
+    if (ppy_lds_attr(attr_s, reinterpret_cast<const void *>(nms_sample_kernel), NMS_SAMPLE * 8) != PPY_OK) return PPY_ERR_LAUNCH;
     hipStream_t st = (hipStream_t)stream;
+    // a list can only be large if the caller's capacity is: the two chip-wide steps are not even launched otherwise
+    if (cand_cap > CCAP) {
+        hipLaunchKernelGGL(nms_sample_kernel, dim3(N), dim3(NT), NMS_SAMPLE * 8, st, p);
+        hipLaunchKernelGGL(nms_collect_kernel, dim3(NMS_CG, N), dim3(512), 0, st, p);
+    }
     hipLaunchKernelGGL(nms_select_kernel, dim3(N), dim3(NT), CCAP * 8, st, p);
     hipLaunchKernelGGL(nms_colmax_kernel, dim3(NMS_G, N), dim3(NT), 0, st, p);
     hipLaunchKernelGGL(nms_decay_kernel, dim3(NMS_G, N), dim3(NT), 0, st, p);

@@ -573,6 +573,83 @@ def test_matrix_nms_full_size_every_pair_a_candidate():
         assert np.array_equal(keep[n, :k].numpy().astype(np.int64), f)
 
 
+def _nms_big_header(ws, N):
+    """(ccount, bad) per image of the large-list header behind the NmsWs array (csrc/decode_nms.hip: NmsBig)."""
+    from ppyolo_hip._lib import lib
+    one = int(lib().ppy_matrix_nms_workspace_bytes(1))
+    per_ws = one - 64 - 2 * 32768 * 4
+    raw = ws.view(torch.int32).cpu()
+    hdr = raw[N * per_ws // 4:N * per_ws // 4 + 16 * N].view(N, 16)
+    return hdr[:, 1].tolist(), hdr[:, 2].tolist()
+
+
+@pytest.mark.parametrize('case', ['mid', 'mixed', 'ties', 'few_above'])
+def test_matrix_nms_large_lists_take_the_compact_route(case):
+    """Round 4: a candidate list that does not fit the select kernel's LDS cache (> 8192 entries) is cut down chip-wide first
+    (nms_sample_kernel -> a score threshold from 8192 sampled keys; nms_collect_kernel -> every entry at or above it, counted
+    exactly) and the select runs on that compact list iff it must contain the whole top-k.  Rows and keep indices equal the
+    oracle's on: a mid-size list, a batch mixing small / large / empty lists, massive exact ties (the compact list overflows ->
+    the original list is walked as before), and a list whose scores above the sampled threshold are fewer than nms_top_k."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(77)
+    C = 80
+    cfg = (0.05, 0.01, 500, 100, False, 2.0)
+
+    def boxes_of(M):
+        b = torch.rand(M, 4, generator=g) * 500
+        b[:, 2:] = b[:, :2] + 5 + torch.rand(M, 2, generator=g) * 120
+        return b
+    if case == 'mid':            # 3 images x ~20 k / 100 k / 9 k candidates, distinct scores
+        Ms, fracs = [1500, 1500, 1500], [0.17, 0.85, 0.076]
+    elif case == 'mixed':        # small (LDS-cached), large, empty
+        Ms, fracs = [1500, 1500, 1500], [0.02, 0.9, 0.0]
+    elif case == 'ties':
+        Ms, fracs = [1500, 1500], [0.9, 0.9]
+    else:
+        Ms, fracs = [1500], [0.9]
+    N, M = len(Ms), Ms[0]
+    boxes = torch.stack([boxes_of(M) for _ in range(N)])
+    scores = torch.zeros(N, M * C)
+    for n in range(N):
+        k = int(M * C * fracs[n])
+        if case == 'ties':       # 15 distinct values: every sampled threshold ties with thousands of entries
+            vals = torch.randint(1, 16, (k,), generator=g).float() / 20.0 + 0.1
+        elif case == 'few_above':  # 300 scores near 0.9, everything else exactly 0.06: fewer than top_k above any useful threshold
+            vals = torch.full((k,), 0.06)
+            vals[:300] = 0.9 + torch.randperm(300, generator=g).float() * 1e-4
+        else:
+            vals = (torch.randperm(k, generator=g).float() + 1.0) / (k + 2) * 0.9 + 0.06
+        scores[n, torch.randperm(M * C, generator=g)[:k]] = vals
+    scores = scores.reshape(N, M, C)
+    ck, ci, cc = _cand_bufs(N, M * C)
+    ops.nms_candidates(scores.cuda(), cfg[0], ck, ci, cc)
+    dets = torch.zeros(N, 100, 6).cuda()
+    cnt = torch.zeros(N, dtype=torch.int32).cuda()
+    keep = torch.zeros(N, 100, dtype=torch.int32).cuda()
+    ws = ops.matrix_nms_workspace(N, 'cuda')
+    ops.matrix_nms(boxes.cuda(), C, ck, ci, cc, cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], dets, cnt, keep, ws=ws)
+    torch.cuda.synchronize()
+    ccount, bad = _nms_big_header(ws, N)
+    counts = cc.cpu().tolist()
+    for n in range(N):
+        ref, f = orc.matrix_nms(boxes[n], scores[n], *cfg, return_index=True)
+        k = int(cnt[n])
+        if ref[0, 0] < 0:
+            assert k == 0
+            continue
+        assert k == ref.shape[0], (case, n)
+        assert torch.equal(dets[n, :k].cpu(), ref), (case, n)
+        assert np.array_equal(keep[n, :k].cpu().numpy().astype(np.int64), f), (case, n)
+        if counts[n] <= 8192:
+            assert ccount[n] == -1, 'a small list must not be touched'
+        elif case in ('mid', 'mixed'):
+            assert bad[n] == 0 and 500 <= ccount[n] <= 8192, 'compact route not taken: %d of %d entries' % (ccount[n], counts[n])
+        elif case == 'ties':       # the threshold is one of 15 values: thousands of entries tie with it, all of them collected
+            assert ccount[n] >= 0.9 * 1500 * 80 / 15 * 0.8
+    if case == 'few_above':
+        assert ccount[0] >= 500      # the threshold falls into the tie: all of it is counted, the list overflows or is complete
+
+
 def test_matrix_nms_ties_use_index_order():
     """Exact score ties (the reference's argsort is unstable there): this build's documented
     total order (score desc, candidate index asc) == the oracle's."""
