@@ -23,10 +23,17 @@ class PPYOLO(torch.nn.Module):
             # and backward all ran as HIP kernels by the time this returns; backward() hands the finished gradients to autograd
             from ppyolo_hip.train import loss_dict
             return loss_dict(self, x, gt_box, targets)
+        ex = self._run(x, im_size)
+        return self._plans.unpack(ex)
+
+    def _run(self, x, im_size):
+        """One forward on the current stream -> the object holding out_dets / out_count / out_keep."""
+        if self._plans.split_forward and x.shape[0] >= 4 and x.shape[0] % 2 == 0:
+            return self._plans.run_split(x, im_size)
         ex = self._plans.executor(x)
         ex.set_inputs(x, im_size)
         ex.run()
-        return self._plans.unpack(ex)
+        return ex
 
     def add_param_group(self, param_groups, base_lr, base_wd):      # reference model/ppyolo.py:27-29
         self.backbone.add_param_group(param_groups, base_lr, base_wd)
@@ -36,9 +43,7 @@ class PPYOLO(torch.nn.Module):
         """Device-resident result without the host sync `forward` needs to build its
         variable-length list: (dets [N,keep_top_k,6] padded with -1, count [N] int32,
         keep_idx [N,keep_top_k] int32 = box*num_classes + class)."""
-        ex = self._plans.executor(x)
-        ex.set_inputs(x, im_size)
-        ex.run()
+        ex = self._run(x, im_size)
         return ex.out_dets, ex.out_count, ex.out_keep
 
     def in_flight(self, depth=2):

@@ -36,10 +36,14 @@ class PlanCache(object):
         # the check costs ~0.14 ms of host time per forward (468 tensors): a server whose weights are final may switch it off
         self.pinned = os.environ.get('PPYOLO_HIP_PIN_WEIGHTS', '0') == '1'
         self.use_graph = os.environ.get('PPYOLO_HIP_GRAPH', '1') != '0'
+        # plain forward() of an even batch >= 4 as two half-batch lanes on two streams (round 4 experiment, see run_split)
+        self.split_forward = os.environ.get('PPYOLO_HIP_FORWARD_SPLIT', '0') == '1'
+        self._split = {}
         self.autotune = os.environ.get('PPYOLO_HIP_AUTOTUNE', '0') == '1'
 
     def clear(self):
         self._ex = {}
+        self._split = {}
         self.blob = None
         self._sig = None
         self._tensors = None
@@ -112,6 +116,43 @@ class PlanCache(object):
                     ex.autotune()
             self._ex[key] = ex
         return ex
+
+    def run_split(self, x, im_size):
+        """`forward` of one batch as TWO half-batch lanes (own executor, hipGraph and stream each) joined on the caller's
+        stream: the second half's wide layers fill the CUs the first half's narrow tail leaves idle -- what InFlight does
+        across batches, inside one call.  -> an object with out_dets / out_count / out_keep of the whole batch (the two
+        executors write their halves of ONE set of result tensors)."""
+        N = x.shape[0]
+        h = N // 2
+        key = (tuple(x.shape), str(x.device))
+        sp = self._split.get(key)
+        self.check_current()
+        if sp is None or sp.generation != self.generation:
+            class _Split(object):
+                pass
+            sp = _Split()
+            sp.generation = self.generation
+            exs = [self.executor(x[:h], lane=('split', k), multi_stream=False) for k in range(2)]
+            kk = exs[0].out_dets.shape[1]
+            sp.out_dets = torch.zeros((N, kk, 6), dtype=torch.float32, device=x.device)
+            sp.out_count = torch.zeros((N,), dtype=torch.int32, device=x.device)
+            sp.out_keep = torch.zeros((N, kk), dtype=torch.int32, device=x.device)
+            for k, ex in enumerate(exs):      # (before the first run: the graphs capture these addresses)
+                ex.out_dets, ex.out_count, ex.out_keep = sp.out_dets[k * h:(k + 1) * h], sp.out_count[k * h:(k + 1) * h], sp.out_keep[k * h:(k + 1) * h]
+                ex.invalidate_graph()
+            sp.lanes = [(ex, torch.cuda.Stream(device=x.device)) for ex in exs]
+            self._split[key] = sp
+        cur = torch.cuda.current_stream(x.device)
+        for k, (ex, st) in enumerate(sp.lanes):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ex.set_inputs(x[k * h:(k + 1) * h], im_size[k * h:(k + 1) * h])
+                ex.run()
+        for _, st in sp.lanes:
+            cur.wait_stream(st)
+        x.record_stream(sp.lanes[0][1])
+        x.record_stream(sp.lanes[1][1])
+        return sp
 
     @staticmethod
     def unpack(ex):

@@ -27,6 +27,7 @@ def close(a, b, rel=2e-5, what=''):
     scale = max(1.0, b.abs().max().item())
     err = (a - b).abs().max().item()
     assert err <= rel * scale, '%s: max abs err %.3e (scale %.3e)' % (what, err, scale)
+    return err / scale
 
 
 def nhwc(x):
@@ -339,7 +340,8 @@ def test_dcn_gather_and_full_layer(golden):
             u.conv.dcn_weight.copy_(T(g[p + 'w_dcn']))
         y = u.eval().cuda()(x.cuda())
         # offsets are recomputed on the GPU (fp32 reordering ~1e-6 px) -> samples move ~1e-5
-        close(y, T(g[p + 'y']), rel=2e-4, what='dcn layer %d' % i)
+        e = close(y, T(g[p + 'y']), rel=2e-4, what='dcn layer %d' % i)
+        print('dcn layer %d: max error / max|y| %.3e' % (i, e))
 
 
 # ------------------------------------------------------------------------------------------
