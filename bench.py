@@ -902,6 +902,11 @@ def main():
         allr = torch.zeros(world * 2, dtype=torch.float64, device=dev)
         torch.distributed.all_gather_into_tensor(allr, own)
         allr = allr.view(world, 2).cpu()
+        if torch.distributed.get_backend() == 'nccl':      # what the collective library says it is (RCCL reports an NCCL-style version)
+            try:
+                ranks['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:
+                ranks['rccl_version'] = 'unavailable (%s)' % type(exc).__name__
         ranks.update(world_size=torch.distributed.get_world_size(), backend=torch.distributed.get_backend(),
                      per_rank_images_per_s=[round(float(v), 1) for v in allr[:, 0]],
                      devices=['cuda:%d' % int(v) for v in allr[:, 1]])

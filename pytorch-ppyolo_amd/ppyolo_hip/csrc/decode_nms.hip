@@ -465,18 +465,26 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
         // 4 cell + anchor.
         if (dense) {
             const float *grow = p.head + ((long long)n * cells_img + cell_base) * p.head_ld;
+            constexpr int NCK = (NCH + 63) / 64;
+            auto load_row = [&](int cc, float (&dst)[NCK]) {
+                const float *rw = grow + (long long)cc * p.head_ld;
+#pragma unroll
+                for (int j = 0; j < NCK; ++j) dst[j] = (cc < ncl && 64 * j + lane < NCH) ? rw[64 * j + lane] : 0.0f;
+            };
             auto sweep = [&](auto write, int base) -> int {
+                float cur[NCK], nxt[NCK];
+                load_row(0, cur);
                 for (int cc = 0; cc < ncl; ++cc) {
+                    load_row(cc + 1, nxt);          // (the next cell's row is in flight while this one is scored)
                     float cfa[A], bda[A];
 #pragma unroll
                     for (int q = 0; q < A; ++q) {
                         cfa[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(conf), 4 * cc + q));
                         bda[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 4 * cc + q));
                     }
-                    const float *rw = grow + (long long)cc * p.head_ld;
                     const int boxc = p.box_offset + (cell_base + cc) * A;
 #pragma unroll
-                    for (int j = 0; j < (NCH + 63) / 64; ++j) {
+                    for (int j = 0; j < NCK; ++j) {
                         const int ch = 64 * j + lane;
                         const int t = ch - OFF0;
                         int a = 0;
@@ -484,7 +492,7 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
                         for (int q = 1; q < A; ++q) a += (t >= q * PER) ? 1 : 0;
                         const int k = t - a * PER - 5;
                         const bool cls = ch < NCH && t >= 0 && k >= 0;
-                        const float lg = cls ? rw[ch] : 0.0f;
+                        const float lg = cur[j];
                         float b = bda[0], cf = cfa[0];
 #pragma unroll
                         for (int q = 1; q < A; ++q) {
@@ -505,6 +513,8 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
                         }
                         base += __popcll(bal);
                     }
+#pragma unroll
+                    for (int j = 0; j < NCK; ++j) cur[j] = nxt[j];
                 }
                 return base;
             };

@@ -110,3 +110,53 @@ def test_train_step_two_ranks_average_their_gradients(tmp_path):
     rel = np.abs(got - want).max() / np.abs(want).max()
     assert rel <= 5e-2, rel
     assert np.abs(singles[0] - singles[1]).max() / np.abs(want).max() > 0.05     # the two batches do produce different gradients
+
+
+def _two_devices():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _two_devices(), reason='needs >= 2 visible ROCm devices (RCCL refuses two ranks on one GPU); the 1-GPU boxes run the gloo twin above')
+def test_two_ranks_over_rccl_equal_two_single_runs(tmp_path):
+    """The same comparison over the REAL backend -- one rank per GPU, `nccl` = RCCL over xGMI: the all-gathered detection
+    records of `python bench.py --gpus 2` equal two single-rank runs bit for bit, the line names the backend and RCCL's
+    version, and every rank ran on its own device.  Auto-skips on a 1-GPU box, so a driver whose box has more devices
+    exercises RCCL through `pytest -m gpu` as well."""
+    common = ['--workload', 'r18vd_320', '--steps', '3', '--warmup', '1', '--min-seconds', '0', '--no-cpu-baseline',
+              '--no-alt-math', '--no-host-input', '--no-pmc', '--no-worst-case']
+    two = str(tmp_path / 'two.npy')
+    r = _run(['--gpus', '2', '--dump-dets', two] + common, env={'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks']['backend'] == 'nccl' and line['ranks']['world_size'] == 2
+    assert sorted(line['ranks']['devices']) == ['cuda:0', 'cuda:1'] and line['ranks'].get('rccl_version')
+    singles = []
+    for off in (0, 1):
+        f = str(tmp_path / ('one%d.npy' % off))
+        r1 = _run(['--gpus', '1', '--seed-offset', str(off), '--dump-dets', f] + common)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        singles.append(np.load(f))
+    assert np.array_equal(np.load(two), np.concatenate(singles, 0)), 'records gathered over RCCL differ from the single-rank runs'
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _two_devices(), reason='needs >= 2 visible ROCm devices')
+def test_train_step_two_ranks_over_rccl(tmp_path):
+    """Config 5 over RCCL: the gradient all-reduce (one collective behind the backward by default) leaves
+    every rank with the mean of the two ranks' gradients."""
+    common = ['--train', '--workload', 'r18vd_320', '--batch', '4', '--steps', '1', '--warmup', '1', '--min-seconds', '0']
+    two = str(tmp_path / 'g2.npy')
+    r = _run(['--gpus', '2', '--dump-dets', two] + common, env={'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and np.isfinite(line['loss_last'])
+    singles = []
+    for off in (0, 1):
+        f = str(tmp_path / ('g1_%d.npy' % off))
+        r1 = _run(['--gpus', '1', '--seed-offset', str(off), '--dump-dets', f] + common)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        singles.append(np.load(f))
+    got, want = np.load(two), 0.5 * (singles[0] + singles[1])
+    assert np.abs(got - want).max() / np.abs(want).max() <= 5e-2
