@@ -791,8 +791,8 @@ def main():
         e.run()
     torch.cuda.synchronize()
     if a.autotune:
-        ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')),
-                    match=a.tune_match.split(',') if a.tune_match else None)
+        for alt in (a.tune_match.split('|') if a.tune_match else [None]):      # "a,b|c,d": layers matching (a and b) or (c and d)
+            ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
         if a.co_tune and depth > 1:
             lanes[1][0].use_graph = True
             changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)

@@ -117,11 +117,11 @@ class Conv2dUnit(torch.nn.Module):
             assert (self.conv.in_channels, self.filter_size, self.stride) == (3, 3, 2) and not self.use_dcn
             return b.stem(self.conv.weight, scale, shift, self.act_name)
         if self.use_dcn:
-            assert res is None and out is None and not ups and not coord
+            assert res is None and not ups and not coord
             co = self.conv.conv_offset
             one = None if skel else torch.ones(27, dtype=torch.float32, device=b.device)
             om = b.conv(x, co.weight, one, None if skel else co.bias.detach().float().clone(), stride=self.stride, act=None)
-            return b.dcn(x, om, self.conv.dcn_weight, scale, shift, self.stride, self.act_name)
+            return b.dcn(x, om, self.conv.dcn_weight, scale, shift, self.stride, self.act_name, out=out)
         return b.conv(x, self.conv.weight, scale, shift, stride=self.stride, act=act, res=res, out=out,
                       ups=ups, coord=coord)
 

@@ -8,6 +8,8 @@ emission time: the residual `x + shortcut` and the final ReLU ride in the epilog
 branch's last conv; the vd shortcut's AvgPool2d(2,2) feeds the 1x1 projection conv.
 Training-only helpers (freeze / add_param_group) are out of scope.
 """
+import os
+
 import torch
 
 from model.custom_layers import Conv2dUnit, get_norm
@@ -49,7 +51,28 @@ class ConvBlock(_Units, torch.nn.Module):
         self.conv4 = Conv2dUnit(in_c, f3, 1, stride=stride if is_first else 1, act=None,
                                 name=block_name + '_branch1', **kw)
 
+    # Round 4: the projection shortcut folded into conv3.  relu(bn3(W3 z) + bn4(W4 s)) is ONE 1x1 convolution over the channel
+    # concatenation [z | s] with the weights [diag(scale3) W3 | diag(scale4) W4], shift3 + shift4 and a ReLU: conv2 writes z into
+    # the first channels of a wide buffer, the vd average pool (or, in stage 2, the stem's max pool) writes s behind it, and the
+    # shortcut tensor -- written by one launch and read back by the next as the residual, 2 x 189 MB at 152 x 152 -- never
+    # exists.  One launch less per stage; the reduction of conv3 grows from f2 to f2 + in_c channels, same FLOPs in total.
+    @staticmethod
+    def _fold():
+        return os.environ.get('PPYOLO_HIP_FOLD_SHORTCUT', '1') == '1'
+
+    def wide_input(self, b, N, H, W):
+        """Stage 2 (no pooling in front of the projection): the block's INPUT is the shortcut operand, so its producer writes it
+        straight into the wide buffer -> the slice to hand to that producer (None when the fold is off)."""
+        if not (self._fold() and self.is_first):
+            return None
+        f2, cs = self.conv2.filters, self.conv4.conv.in_channels
+        self._wide = b.new_buf(N, H, W, f2 + cs)
+        from ppyolo_hip.engine import A
+        return A(self._wide, f2, cs, N, H, W)
+
     def emit(self, b, x, out=None):
+        if self._fold():
+            return self._emit_folded(b, x, out)
         with b.side():              # projection shortcut: independent of conv1 -> conv2
             s = x if self.is_first else b.avgpool(x)
             s = self.conv4.emit(b, s)
@@ -57,6 +80,33 @@ class ConvBlock(_Units, torch.nn.Module):
         y = self.conv2.emit(b, y)
         y = self.conv3.emit(b, y, res=s, out=out, post_act='relu')      # relu(bn(conv) + shortcut)
         return y
+
+    def _emit_folded(self, b, x, out):
+        from ppyolo_hip.engine import A
+        f2, cs, f3 = self.conv2.filters, self.conv4.conv.in_channels, self.conv3.filters
+        Ho, Wo = (x.H, x.W) if self.is_first else (x.H // 2, x.W // 2)
+        wide = getattr(self, '_wide', None)
+        if self.is_first and wide is not None and x.buf == wide:      # x already sits in its slice (wide_input)
+            self._wide = None
+        else:
+            wide = b.new_buf(x.N, Ho, Wo, f2 + cs)
+            s_slot = A(wide, f2, cs, x.N, Ho, Wo)
+            if self.is_first:
+                raise AssertionError('stage-2 ConvBlock: hand wide_input() to the producer of x first')
+            b.avgpool(x, out=s_slot)
+        y = self.conv1.emit(b, x)
+        self.conv2.emit(b, y, out=A(wide, 0, f2, x.N, Ho, Wo))
+        skel = getattr(b, 'skeleton', False)
+        if skel:
+            w = torch.empty((f3, f2 + cs, 1, 1), dtype=torch.float32, device='meta')
+            one = shift = None
+        else:
+            s3, b3 = self.conv3.folded(b.device)
+            s4, b4 = self.conv4.folded(b.device)
+            w = torch.cat([self.conv3.conv.weight.detach().float() * s3.view(-1, 1, 1, 1),
+                           self.conv4.conv.weight.detach().float() * s4.view(-1, 1, 1, 1)], dim=1)
+            one, shift = torch.ones_like(s3), b3 + b4
+        return b.conv(A(wide, 0, f2 + cs, x.N, Ho, Wo), w, one, shift, stride=1, act='relu', out=out)
 
 
 class IdentityBlock(_Units, torch.nn.Module):
@@ -82,7 +132,9 @@ class _Backbone(torch.nn.Module):
         x = self.stage1_conv1_1.emit(b, None)
         x = self.stage1_conv1_2.emit(b, x)
         x = self.stage1_conv1_3.emit(b, x)
-        return b.maxpool(x)
+        first = self._stage_blocks(2)[0]
+        slot = first.wide_input(b, x.N, (x.H + 1) // 2, (x.W + 1) // 2) if hasattr(first, 'wide_input') else None
+        return b.maxpool(x, out=slot)
 
     def emit(self, b, out_slots=None):
         """out_slots: {stage: callable(builder, N, H, W) -> A}: feature maps the head wants

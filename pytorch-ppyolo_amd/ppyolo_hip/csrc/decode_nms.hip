@@ -315,6 +315,7 @@ __device__ __forceinline__ float quad_bcast(float v) {      // value of lane (la
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xf, 0xf, false));
 }
 
+static_assert(3 * DS_WAVES * DS_LW * 4 + 64 <= PPY_LDS_MAX / 2, "the wave-private lists of TWO workgroups must fit one CU's LDS");
 template <int A, int C, bool IOU>
 __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(const DecodeStream m) {
     constexpr int PER = 5 + C, OFF0 = IOU ? A : 0, NCH = A * PER + OFF0, N4ROW = (NCH + 3) / 4, NJ = (N4ROW + 3) / 4;
@@ -1124,7 +1125,16 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
     // the streaming kernel: compiled for the two head layouts of the configurations (3 anchors, 80 classes, with / without the
     // IoU-aware channels); rows 16-byte aligned with a pixel stride that is a multiple of 4 floats (what the plan produces:
     // 258 channels in rows of 260); anything else takes the staged kernel
-    bool stream_ok = getenv("PPY_DECODE_STAGED") == nullptr && A == 3 && num_classes == 80;
+    // experiment switches, read ONCE (not per launch): PPY_DECODE_STAGED = the staged kernel; PPY_DECODE_PER_WAVE = groups a wave takes
+    // in turn.  The ablation switch PPY_DECODE_ABL (deliberately wrong results) exists in -DPPY_DECODE_ABLATE builds only.
+    static const bool env_staged = getenv("PPY_DECODE_STAGED") != nullptr;
+    static const int env_per_wave = getenv("PPY_DECODE_PER_WAVE") ? atoi(getenv("PPY_DECODE_PER_WAVE")) : 0;
+#ifdef PPY_DECODE_ABLATE
+    static const int env_abl = getenv("PPY_DECODE_ABL") ? atoi(getenv("PPY_DECODE_ABL")) : 0;
+#else
+    static const int env_abl = 0;
+#endif
+    bool stream_ok = !env_staged && A == 3 && num_classes == 80;
     for (int l = 0; l < nlevels && stream_ok; ++l)
         stream_ok = (head_ld[l] & 3) == 0 && head_ld[l] >= (A * (5 + num_classes) + (iou_aware ? A : 0) + 3) / 4 * 4 &&
                     (((uintptr_t)head_out[l]) & 15) == 0;      // (whole 16-byte groups of a row are read, pad channels included)
@@ -1136,10 +1146,17 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
         // ONE group per wave while the whole launch fits on the chip at once (R50vd-608, 8 images: 3790 groups = 948 workgroups on
         // 1024 slots of 4 waves): a wave is a latency chain load -> decode_pair -> sweep -> flush of ~8 us, and waves that take
         // several groups in turn run those chains back to back (36 us measured with ~2 groups per wave, ~2048 waves)
-        const long long wave_slots = 256LL * 16;                  // waves resident at once (two workgroups of eight per CU)
+        static const int n_cu = [] {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            return cus;
+        }();
+        const long long wave_slots = (long long)n_cu * 2 * DS_WAVES;      // waves resident at once (two workgroups of eight per CU)
         long long per_wave = (groups_total * N + wave_slots - 1) / wave_slots;       // groups a wave takes in turn
-        if (const char *e = getenv("PPY_DECODE_PER_WAVE")) per_wave = atoi(e) > 0 ? atoi(e) : per_wave;      // (experiments)
-        ds.abl = getenv("PPY_DECODE_ABL") ? atoi(getenv("PPY_DECODE_ABL")) : 0;
+        if (env_per_wave > 0) per_wave = env_per_wave;
+        ds.abl = env_abl;
         unsigned nblocks = 0;
         for (int l = 0; l < nlevels; ++l) {
             const long long gl = (S[l] * S[l] + DS_GC - 1) / DS_GC;

@@ -231,14 +231,16 @@ class Builder(object):
         out = self.conv(g, w32, one, zero, stride=stride, act=None, setup=True)
         return out          # A of shape [1,Ho,Wo,K]; bound to its tensor by the executor
 
-    def maxpool(self, x):
+    def maxpool(self, x, out=None):
         Ho, Wo = K.conv_out_hw(x.H, x.W, 3, 3, 2, 1)
-        y = self.new_act(x.N, Ho, Wo, x.C)
+        y = self.new_act(x.N, Ho, Wo, x.C) if out is None else out
+        assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, x.C)
         self._emit(dict(op='maxpool', x=x, y=y))
         return y
 
-    def avgpool(self, x):
-        y = self.new_act(x.N, x.H // 2, x.W // 2, x.C)
+    def avgpool(self, x, out=None):
+        y = self.new_act(x.N, x.H // 2, x.W // 2, x.C) if out is None else out
+        assert (y.N, y.H, y.W, y.C) == (x.N, x.H // 2, x.W // 2, x.C)
         self._emit(dict(op='avgpool', x=x, y=y))
         return y
 
@@ -249,13 +251,14 @@ class Builder(object):
         self._emit(dict(op='spp', x=x_slot0, y5=ys[0], y9=ys[1], y13=ys[2]))
         return A(x_slot0.buf, x_slot0.coff, 4 * C, x_slot0.N, x_slot0.H, x_slot0.W)
 
-    def dcn(self, x, om, weight, scale, shift, stride, act):
+    def dcn(self, x, om, weight, scale, shift, stride, act, out=None):
         Kout = weight.shape[0]
         w_krsc = (_meta(Kout, weight.shape[2], weight.shape[3], weight.shape[1]) if self.skeleton
                   else weight.detach().float().permute(0, 2, 3, 1).contiguous())
         Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
         assert (om.H, om.W, om.C) == (Ho, Wo, 27)
-        y = self.new_act(x.N, Ho, Wo, Kout)
+        y = self.new_act(x.N, Ho, Wo, Kout) if out is None else out
+        assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Kout)
         self._emit(dict(op='dcn', x=x, om=om, y=y, w=w_krsc, scale=scale, shift=shift, stride=stride, pad=1, act=act,
                         cfg=-1, splitk=0))
         return y

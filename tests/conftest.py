@@ -90,6 +90,20 @@ def model_shapes():
     return _shapes
 
 
+@pytest.fixture(autouse=True)
+def _release_gpu_objects_between_tests():
+    """Executors of a finished test (captured hipGraphs, their memory pools, side streams) are destroyed HERE, with the device
+    idle -- not whenever the cyclic garbage collector happens to run inside a later test's launch loop (round 4: the collector
+    fired in the middle of an autotune sweep and the runtime aborted in a graph destructor; the same test passes alone)."""
+    yield
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
+
+
 @pytest.fixture(scope='session', autouse=True)
 def _drain_gpu_at_exit():
     """Captured hipGraphs and their memory pools are released while the HIP runtime is still alive (an interpreter

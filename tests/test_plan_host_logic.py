@@ -47,7 +47,11 @@ def test_plan_end_to_end_matches_golden(golden, tag, cfgc):
         assert p.shape == ref.shape
         assert torch.equal(p[:, 0], ref[:, 0])                         # labels, in order
         assert (p[:, 1] - ref[:, 1]).abs().max() <= 1e-4               # scores
-        assert (p[:, 2:] - ref[:, 2:]).abs().max() <= 1e-3             # boxes (pixels)
+        # boxes: 1e-3 px, or 2e-5 of the box side for large boxes -- the plan folds BatchNorm scales into the weights of the four
+        # projection-shortcut layers (model/resnet_vd.py), i.e. it rounds in another order than the reference's eager ops, and a
+        # box edge moves by (logit noise) x (box side) / 2: what the reference does against itself (tests/golden/g18_*: 1e-5)
+        side = torch.maximum(ref[:, 4] - ref[:, 2], ref[:, 5] - ref[:, 3]).clamp_min(1.0)
+        assert bool(((p[:, 2:] - ref[:, 2:]).abs().max(dim=1).values <= torch.clamp(2e-5 * side, min=1e-3)).all())
 
 
 def test_plan_structure_r50():
@@ -55,7 +59,8 @@ def test_plan_structure_r50():
     model, _ = build_model(cfg)
     plan = build_plan(model, 2, 160, 160, 'cpu')
     kinds = [o['op'] for o in plan.ops]
-    assert kinds.count('conv') == 78 and kinds.count('dcn') == 3 and kinds.count('spp') == 1
+    # (74 = 78 - the four projection-shortcut launches, folded into their block's conv3: ConvBlock._emit_folded)
+    assert kinds.count('conv') == 74 and kinds.count('dcn') == 3 and kinds.count('spp') == 1
     assert kinds.count('stem') == 1 and kinds.count('maxpool') == 1 and kinds.count('avgpool') == 3
     assert len(plan.setup_ops) == 12                # one CoordConv bias map per coord conv
     # every conv reads a 32-channel-aligned, 16-byte aligned slice
@@ -128,7 +133,8 @@ def test_split_pairs_of_the_r50_plan():
     n3 = sum(1 for o in plan.ops if o['op'] == 'conv' and shape(o)[1] == 3)
     # all 3x3 launches but the three conv_offset (their input is shared with the DCNv2 launch) and the stem's second layer (its
     # input comes from the stem kernel, which is no 'conv' op)
-    assert n3 == 27 and len(cons3) == 23 and len(pairs) == 45
+    # (42 = 45 - the conv2 -> conv3 links of the first blocks of stages 2-4: their buffer now has a second writer, the shortcut operand)
+    assert n3 == 27 and len(cons3) == 23 and len(pairs) == 42
     assert all(shape(c)[1] == 3 for _, cs in only3 for c in cs) and sum(len(cs) for _, cs in only3) <= len(cons3)
     two = [(pr, cs) for pr, cs in pairs if len(cs) == 2]
     assert len(two) == 2 and all(sorted(shape(c)[1] for c in cs) == [1, 3] for _, cs in two)      # the routes of levels 0 and 1
