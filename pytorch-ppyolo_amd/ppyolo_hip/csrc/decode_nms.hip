@@ -1074,6 +1074,16 @@ static int decode_pack(DecodeArgs &p, const float *head_out, int head_ld, int N,
     return PPY_OK;
 }
 
+// Test / experiment hook (tests/test_gpu_ops.py compares the two decode kernels in one process; tools/decode_bench.py): staged /
+// per_wave = -1 keeps the environment's choice, >= 0 overrides it; abl (results deliberately wrong: 1 = no flush atomic, 2 = no
+// pair phase, 4 = no sweep) only acts in a -DPPY_DECODE_ABLATE build.
+static std::atomic<int> g_dec_staged{-1}, g_dec_per_wave{-1}, g_dec_abl{0};
+extern "C" void ppy_debug_decode_mode(int staged, int per_wave, int abl) {
+    g_dec_staged.store(staged);
+    g_dec_per_wave.store(per_wave);
+    g_dec_abl.store(abl);
+}
+
 template <typename Kern>
 static int decode_attr(PpyLdsAttr &st, Kern k) {
     return ppy_lds_attr(st, reinterpret_cast<const void *>(k), 96 * 1024);
@@ -1127,12 +1137,15 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
     // 258 channels in rows of 260); anything else takes the staged kernel
     // experiment switches, read ONCE (not per launch): PPY_DECODE_STAGED = the staged kernel; PPY_DECODE_PER_WAVE = groups a wave takes
     // in turn.  The ablation switch PPY_DECODE_ABL (deliberately wrong results) exists in -DPPY_DECODE_ABLATE builds only.
-    static const bool env_staged = getenv("PPY_DECODE_STAGED") != nullptr;
-    static const int env_per_wave = getenv("PPY_DECODE_PER_WAVE") ? atoi(getenv("PPY_DECODE_PER_WAVE")) : 0;
+    static const bool env_staged0 = getenv("PPY_DECODE_STAGED") != nullptr;
+    static const int env_per_wave0 = getenv("PPY_DECODE_PER_WAVE") ? atoi(getenv("PPY_DECODE_PER_WAVE")) : 0;
+    const int m_staged = g_dec_staged.load(), m_per_wave = g_dec_per_wave.load();       // ppy_debug_decode_mode overrides the environment
+    const bool env_staged = m_staged >= 0 ? m_staged != 0 : env_staged0;
+    const int env_per_wave = m_per_wave >= 0 ? m_per_wave : env_per_wave0;
 #ifdef PPY_DECODE_ABLATE
-    static const int env_abl = getenv("PPY_DECODE_ABL") ? atoi(getenv("PPY_DECODE_ABL")) : 0;
+    const int env_abl = g_dec_abl.load();
 #else
-    static const int env_abl = 0;
+    const int env_abl = 0;
 #endif
     bool stream_ok = !env_staged && A == 3 && num_classes == 80;
     for (int l = 0; l < nlevels && stream_ok; ++l)

@@ -397,13 +397,13 @@ def _decode_levels(outs, anchors_px, strides, iou_aware, im_size, thr, staged):
         M += o.shape[2] * o.shape[3] * 3
     boxes = torch.zeros(N, M, 4).cuda()
     ck, ci, cc = _cand_bufs(N, M * 80)
-    if staged:
-        os.environ['PPY_DECODE_STAGED'] = '1'
+    from ppyolo_hip._lib import lib
+    lib().ppy_debug_decode_mode(1 if staged else 0, -1, 0)          # (the library reads its environment switches once per process)
     try:
         ops.yolo_decode_levels(views, anchors_px, strides, 80, 1.05, iou_aware, 0.4, True, im_size.cuda(), boxes, thr, ck, ci, cc)
         torch.cuda.synchronize()
     finally:
-        os.environ.pop('PPY_DECODE_STAGED', None)
+        lib().ppy_debug_decode_mode(-1, -1, 0)
     cands = []
     for n in range(N):
         k = int(cc[n])

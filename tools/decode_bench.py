@@ -29,9 +29,12 @@ def main():
                              d['num_classes'], d['scale_x_y'], d['iou_aware'], d['iou_aware_factor'], d['clip_bbox'],
                              ex.im_size, ex.boxes, n['score_threshold'], ex.cand_key, ex.cand_idx, ex.cand_count)
 
+    from ppyolo_hip._lib import lib
+
     def t(label, **env):
-        for k, v in env.items():
-            os.environ[k] = str(v)
+        # (the library reads its environment once: the switches go through its debug hook; PPY_DECODE_ABL only acts in a build
+        # with PPY_EXTRA_HIPCC_FLAGS=-DPPY_DECODE_ABLATE)
+        lib().ppy_debug_decode_mode(int(env.get('PPY_DECODE_STAGED', 0)), int(env.get('PPY_DECODE_PER_WAVE', -1)), int(env.get('PPY_DECODE_ABL', 0)))
         try:
             ex.cand_count.zero_()
             decode()
@@ -49,8 +52,7 @@ def main():
                 best = v if best is None else min(best, v)
             print('%-60s %7.1f us' % (label, best * 1e3), flush=True)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            lib().ppy_debug_decode_mode(-1, -1, 0)
     t('staged kernel (rounds 1-2)', PPY_DECODE_STAGED=1)
     for pw in (1, 2, 3, 4, 6, 8):
         t('stream, %d group(s) per wave' % pw, PPY_DECODE_PER_WAVE=pw)
