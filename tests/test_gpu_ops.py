@@ -340,7 +340,7 @@ def test_dcn_gather_and_full_layer(golden):
             u.conv.dcn_weight.copy_(T(g[p + 'w_dcn']))
         y = u.eval().cuda()(x.cuda())
         # offsets are recomputed on the GPU (fp32 reordering ~1e-6 px) -> samples move ~1e-5
-        e = close(y, T(g[p + 'y']), rel=2e-4, what='dcn layer %d' % i)
+        e = close(y, T(g[p + 'y']), rel=2e-5, what='dcn layer %d' % i)      # measured on MI355X: 2.8e-6 .. 4.8e-6
         print('dcn layer %d: max error / max|y| %.3e' % (i, e))
 
 
