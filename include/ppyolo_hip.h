@@ -428,7 +428,13 @@ int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_out, const 
  * out_keep_idx [N][keep_top_k] = box*C + class of every kept row (-1 padding).
  * Limits: 1 <= nms_top_k <= 1024, keep_top_k <= nms_top_k.
  * ws: ppy_matrix_nms_workspace_bytes(N) bytes of scratch, 16-byte aligned (the sorted top-k boxes and the
- * per-column compensate / decay values travel between the four kernels of one call through it). */
+ * per-column compensate / decay values travel between the kernels of one call through it; round 4: + 264 KB per image
+ * for the compact list of the large-list route).
+ * Lists of more than 8192 candidates (only possible when cand_cap > 8192; up to 1.8 M per image when every (box,
+ * class) pair passes the threshold) are first cut down chip-wide -- a threshold from 8192 sampled keys, then one
+ * streaming pass that moves every entry at or above it to a compact list and counts them -- and the top-k select
+ * runs on the compact list iff that list is certain to contain the whole top-k; otherwise it walks the original
+ * list.  The result is the same either way (csrc/decode_nms.hip: nms_sample_kernel, nms_collect_kernel). */
 size_t ppy_matrix_nms_workspace_bytes(int N);
 int ppy_matrix_nms_f32(const float *boxes, int M_total, int num_classes, const uint32_t *cand_key,
                        const uint32_t *cand_idx, const int *cand_count, int cand_cap, int N,

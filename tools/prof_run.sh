@@ -8,7 +8,7 @@ SCR=/tmp/prof_$TAG
 rm -rf $SCR; mkdir -p $OUT $SCR
 export TMPDIR=/tmp
 STEPS=5
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-math --no-host-input --no-graph --in-flight 1 --min-seconds 0 $*"   # (one lane: the per-kernel durations bench.py reports are solo durations)
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-math --no-host-input --no-pmc --no-worst-case --no-graph --in-flight 1 --min-seconds 0 $*"   # (one lane: the per-kernel durations bench.py reports are solo durations)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 run_pmc() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $SCR/$name -o pmc -- $BENCH > $OUT/$name.log 2>&1; }
