@@ -324,6 +324,14 @@ int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_kcrs, const 
                                 const float *shift, float *y, int y_ld, int N, int H, int W,
                                 int K, int act, float *amax_out /* NULL or N * PPY_AMAX_FLOATS_PER_IMAGE floats */, void *stream);
 
+/* The same operator on the bf16 MFMA (round 4): the 27-deep reduction as two k-steps of v_mfma_f32_32x32x16_bf16 on
+ * exactly-split operands (3 bf16 terms per fp32 value, 6 partial products, fp32 accumulate -- no scaling, so any input
+ * range).  K == 32 only (PPY_ERR_UNSUPPORTED otherwise).  Agrees with the fma chain of the entry above to fp32
+ * rounding, not bit for bit; PPYOLO_HIP_MATH=fp32 keeps the entry above. */
+int ppy_stem_conv3x3s2_nchw_x3_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
+                                   const float *shift, float *y, int y_ld, int N, int H, int W,
+                                   int K, int act, float *amax_out, void *stream);
+
 /* Image pre-processing in front of the path, reference Decode.process_image
  * (model/decode_np.py:125-140): BGR->RGB (swap_rb), cv2.resize(fx = S/w, fy = S/h, INTER_CUBIC) on uint8
  * (tools/transform.py:996-1003; OpenCV's 11-bit fixed-point bicubic, A = -0.75, replicated border), then the numpy

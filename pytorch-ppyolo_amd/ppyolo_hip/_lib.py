@@ -83,6 +83,8 @@ _PROTOS = {
                                      c_size_t, c_void_p]),
     'ppy_stem_conv3x3s2_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ppy_stem_conv3x3s2_nchw_x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ppy_preprocess_u8_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),
     'ppy_maxpool3x3s2_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

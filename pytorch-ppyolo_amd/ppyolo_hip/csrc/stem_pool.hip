@@ -127,6 +127,121 @@ __global__ void __launch_bounds__(256) stem_conv_row_kernel(const float *__restr
     if (amax_out) amax_track(amx, n, amax_out, blockIdx.x * 4 + wv);      // tracked per-image max|y| (f16x2 consumers)
 }
 
+// Round 4: the same operator on the matrix pipe.  The row kernel above spends 83 us on 1.28 GFLOP and 130 MB -- 12 160 small
+// workgroups, each two barriers and 216 dependent fma per thread deep.  Here the 27-deep reduction (padded to 32) is TWO k-steps of
+// v_mfma_f32_32x32x16_bf16 on exactly-split operands (three bf16 terms per fp32 value, six partial products, fp32 accumulate:
+// conv_x3.hip's bf16x3 scheme -- no scaling, no range question for an arbitrary input image), a persistent workgroup of four
+// waves walks over tiles of 2 output rows x 64 pixels, wave w owning 32 pixels of a row: the five input rows of a tile are copied
+// to LDS as whole lines (even / odd columns apart, as above), a lane gathers its pixel's 8 taps per k-group from there, and the
+// accumulator layout (lane = channel, 16 pixel rows per lane) stores 128 contiguous bytes per half-wave: whole lines, no LDS
+// transposition.  Weights: 32 x 27 -> three bf16 planes of B fragments in 24 VGPRs, built once per workgroup.
+// Error: the bf16x3 split is exact, the six products drop a 2^-24 tail like the fp32 fma chain (tests/test_gpu_ops.py).
+constexpr int SM_TR = 2, SM_TC = 64;
+__global__ void __launch_bounds__(256) stem_conv_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             float *y, int y_ld, int N, int H, int W, int Ho, int Wo, int act,
+                                                             float *amax_out, int tiles_x, int tiles_y) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float floatx2_t;
+    typedef __attribute__((ext_vector_type(16))) float floatx16_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned uint4_t;
+    constexpr int NR = 2 * SM_TR + 1, LD = SM_TC + 2;
+    __shared__ float s_in[3][NR][2][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 5, fr = lane & 31;
+    auto pk = [](float a, float b) -> unsigned {
+        const floatx2_t v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    };
+    // 8 consecutive-k values -> three bf16x8 operands (exact: the third term holds what two roundings left)
+    auto split8 = [&](const float (&v)[8], uint4_t (&out)[3]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = v[2 * q], b = v[2 * q + 1];
+            const unsigned P0 = pk(a, b);
+            const float ra = a - __uint_as_float(P0 << 16), rb = b - __uint_as_float(P0 & 0xffff0000u);
+            const unsigned P1 = pk(ra, rb);
+            const float sa = ra - __uint_as_float(P1 << 16), sb = rb - __uint_as_float(P1 & 0xffff0000u);
+            out[0][q] = P0;
+            out[1][q] = P1;
+            out[2][q] = pk(sa, sb);
+        }
+    };
+    // B fragments: column = channel fr, k = 16 ks + 8 g + i  (k = 9 c + 3 r + s; k >= 27: zero)
+    uint4_t bfr[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 16 * ks + 8 * g + i;
+            v[i] = k < 27 ? w[fr * 27 + k] : 0.f;
+        }
+        split8(v, bfr[ks]);
+    }
+    const float sc = scale[fr], sh = shift[fr];
+    const int row = wv >> 1, px = (wv & 1) * 32 + fr;        // this lane's pixel of the tile (A fragment row fr)
+    const long long ntiles = (long long)N * tiles_y * tiles_x;
+    int run_n = -1;
+    float run_mx = 0.f;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), n = (int)(t / ((long long)tiles_x * tiles_y));
+        const int ho0 = ty * SM_TR, wo0 = tx * SM_TC;
+        __syncthreads();                                     // (the previous tile's gathers are done)
+        for (int i = tid; i < 3 * NR * (2 * SM_TC + 1); i += 256) {
+            const int j = i % (2 * SM_TC + 1), cr = i / (2 * SM_TC + 1);
+            const int c = cr / NR, r = cr - NR * c;
+            const int hi = 2 * ho0 - 1 + r, wi = 2 * wo0 - 1 + j;
+            float v = 0.f;
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)n * 3 + c) * H + hi) * W + wi];
+            s_in[c][r][(j & 1) ^ 1][j >> 1] = v;             // j even: odd input column (taps s = 0 / s = 2 of the pixel before)
+        }
+        __syncthreads();
+        floatx16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * ks + 8 * g + i;
+                const int c = k / 9, r = (k - 9 * c) / 3, sx = k - 9 * c - 3 * r;
+                v[i] = k < 27 ? s_in[c][2 * row + r][sx == 1 ? 0 : 1][px + (sx == 2 ? 1 : 0)] : 0.f;
+            }
+            uint4_t a[3];
+            split8(v, a);
+            // partial products, smallest first (conv_x3.hip): (a2,b0) (a1,b1) (a0,b2) (a1,b0) (a0,b1) (a0,b0)
+            constexpr int ta[6] = {2, 1, 0, 1, 0, 0}, tb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ta[q]]), __builtin_bit_cast(bf16x8_t, bfr[ks][tb[q]]),
+                                                              acc, 0, 0, 0);
+        }
+        // accumulator element e of this lane: pixel (e & 3) + 8 (e >> 2) + 4 g of the wave's 32, channel fr
+        if (n != run_n) {
+            if (amax_out && run_n >= 0) amax_track(run_mx, run_n, amax_out, (int)blockIdx.x * 4 + wv);
+            run_n = n;
+            run_mx = 0.f;
+        }
+        // (stores straight from the accumulator layout: a half-wave writes one whole 128-byte pixel per instruction; going through
+        // an LDS patch for 16-byte stores measured the same 50-52 us and costs 18 KB of LDS, i.e. two workgroups per CU)
+        const int ho = ho0 + row;
+        float *yrow = y + (((long long)n * Ho + ho) * Wo) * y_ld + fr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int wo = wo0 + (wv & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+            const float o = ppy_apply_act(fmaf(acc[e], sc, sh), act);
+            if (ho < Ho && wo < Wo) {
+                yrow[(long long)wo * y_ld] = o;
+                run_mx = fmaxf(run_mx, fabsf(o));
+            }
+        }
+    }
+    if (amax_out && run_n >= 0) amax_track(run_mx, run_n, amax_out, (int)blockIdx.x * 4 + wv);
+}
+
 // ---------------------------------------------------------------------------------------
 // MaxPool2d(3, 2, 1): implicit -inf padding == skip out-of-range taps.
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x, int x_ld,
@@ -268,6 +383,24 @@ extern "C" int ppy_stem_conv3x3s2_nchw_f32(const float *x_nchw, const float *w_k
     dim3 grid((unsigned)((total + 255) / 256), K / 16);
     hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, w_kcrs, scale,
                        shift, y, y_ld, N, H, W, Ho, Wo, K, act, amax_out);
+    return ppy_launch_status();
+}
+
+// The stem on the bf16 MFMA (stem_conv_mfma_kernel; K = 32 only -- both backbones').  Same arguments as
+// ppy_stem_conv3x3s2_nchw_f32; results agree with its fp32 fma chain to fp32 rounding, not bit for bit.
+extern "C" int ppy_stem_conv3x3s2_nchw_x3_f32(const float *x_nchw, const float *w_kcrs, const float *scale,
+                                              const float *shift, float *y, int y_ld, int N, int H, int W,
+                                              int K, int act, float *amax_out, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x_nchw && w_kcrs && scale && shift && y);
+    PPY_CHECK_ARG(N > 0 && H > 0 && W > 0 && y_ld >= K && y_ld % 4 == 0 && ((uintptr_t)y & 15) == 0);
+    if (K != 32) return PPY_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int tiles_x = (Wo + SM_TC - 1) / SM_TC, tiles_y = (Ho + SM_TR - 1) / SM_TR;
+    const long long ntiles = (long long)N * tiles_x * tiles_y;
+    const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);      // eight workgroups of four waves per CU
+    hipLaunchKernelGGL(stem_conv_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_kcrs, scale, shift, y, y_ld,
+                       N, H, W, Ho, Wo, act, amax_out, tiles_x, tiles_y);
     return ppy_launch_status();
 }
 

@@ -620,8 +620,10 @@ class HipExecutor(object):
             if op.get('pool') is not None:
                 K.avgpool2x2(self.view(op['y']), self.view(op['pool']))
         elif t == 'stem':
+            # (16-bit modes: the stem on the bf16 MFMA too; PPYOLO_HIP_STEM_MFMA=0 or the exact-fp32 mode: the fp32 fma chain)
             K.stem_conv(self.x_in, op['w'], op['scale'], op['shift'], self.view(op['y']), op['act'],
-                        self._amax(op.get('amax_out_id')))
+                        self._amax(op.get('amax_out_id')),
+                        mfma=self.math != 'fp32' and op['w'].shape[0] == 32 and os.environ.get('PPYOLO_HIP_STEM_MFMA', '1') == '1')
         elif t == 'maxpool':
             K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
         elif t == 'avgpool':

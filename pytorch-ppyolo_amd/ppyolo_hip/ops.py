@@ -457,13 +457,14 @@ def yolov3_loss(head_out, target, gt_box, anchors_px, num_classes, downsample, s
     return ws
 
 
-def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None):
+def stem_conv(x_nchw, w_kcrs, scale, shift, y, act='relu', amax_out=None, mfma=False):
+    """mfma: the bf16x3 MFMA form (K == 32; csrc/stem_pool.hip stem_conv_mfma_kernel) instead of the fp32 fma chain."""
     _dev(x_nchw, w_kcrs, scale, shift, y.t)
     N, C, H, W = x_nchw.shape
     assert C == 3 and x_nchw.is_contiguous() and w_kcrs.is_contiguous() and tuple(w_kcrs.shape[1:]) == (3, 3, 3)
-    check(lib().ppy_stem_conv3x3s2_nchw_f32(x_nchw.data_ptr(), w_kcrs.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                            y.ptr, y.ld, N, H, W, w_kcrs.shape[0], ACT[act], _p(amax_out), _stream()),
-          'ppy_stem_conv3x3s2_nchw_f32')
+    fn = lib().ppy_stem_conv3x3s2_nchw_x3_f32 if mfma else lib().ppy_stem_conv3x3s2_nchw_f32
+    check(fn(x_nchw.data_ptr(), w_kcrs.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.ptr, y.ld, N, H, W, w_kcrs.shape[0],
+             ACT[act], _p(amax_out), _stream()), 'ppy_stem_conv3x3s2_nchw%s_f32' % ('_x3' if mfma else ''))
 
 
 def preprocess_images(images_u8, target_size, lut, out, swap_rb=True):

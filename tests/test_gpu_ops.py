@@ -234,6 +234,39 @@ def test_stem_conv(golden):
     close(nchw(y), ref, what='stem')
 
 
+def test_stem_on_the_mfma_matches_fp64_as_well_as_the_fma_chain():
+    """Round 4: the stem on the bf16 MFMA (stem_conv_mfma_kernel: 27 -> 32 deep, two k-steps, exact 3-term bf16 split, six
+    products) against a float64 convolution, next to the fp32 fma chain of the row kernel: no further from exact than that
+    chain (x 1.5 + rounding of the result), incl. odd sizes, partial 2 x 64 tiles, the border taps, a padded pixel stride, an
+    image 1000 x larger than its neighbour (no scaling in this scheme), and the tracked per-image maxima."""
+    from ppyolo_hip import ops
+    gen = torch.Generator().manual_seed(13)
+    for (N, H, W, ld) in [(2, 37, 150, 32), (1, 64, 259, 40), (3, 9, 130, 32), (2, 608, 608, 32), (1, 15, 18, 32)]:
+        x = torch.randn(N, 3, H, W, generator=gen)
+        x[0] *= 1000.0
+        w = torch.randn(32, 3, 3, 3, generator=gen) * 0.2
+        sc, sh = torch.rand(32, generator=gen) + 0.5, torch.randn(32, generator=gen)
+        ref = F.relu(F.conv2d(x.double(), w.double(), None, 2, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        err = {}
+        for mfma in (False, True):
+            y = torch.full((N, Ho, Wo, ld), -3.0).cuda()
+            amax = ops.amax_slots(device='cuda', N=N)
+            ops.stem_conv(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), ops.View(y, 0, 32), 'relu', amax_out=amax, mfma=mfma)
+            torch.cuda.synchronize()
+            out = y.cpu()
+            assert bool((out[..., 32:] == -3.0).all()), 'wrote beyond its 32 channels'
+            got = out[..., :32].permute(0, 3, 1, 2).double()
+            # error per image relative to that image's magnitude (image 0 is 1000 x larger)
+            e = [float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-30)) for n in range(N)]
+            err[mfma] = e
+            mx = amax.view(N, -1).amax(dim=1).cpu()
+            assert torch.equal(mx, out[..., :32].abs().amax(dim=(1, 2, 3))), 'tracked maxima'
+        for n in range(N):
+            assert err[True][n] <= 1.5 * err[False][n] + 1.2e-7, ((N, H, W), n, err)
+    print('stem: max error / max|y| per image, fma chain %s, bf16x3 MFMA %s' % (['%.1e' % v for v in err[False]], ['%.1e' % v for v in err[True]]))
+
+
 def test_stem_row_kernel_is_bit_identical_to_the_pixel_kernel():
     """Round 3: the stem as row segments through LDS (csrc/stem_pool.hip, stem_conv_row_kernel) keeps the fma chain of the
     thread-per-pixel form (PPY_STEM_OLD=1 selects it per call): same bits, incl. several / partial 64-pixel segments, odd
