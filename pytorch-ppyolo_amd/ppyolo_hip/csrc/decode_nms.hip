@@ -320,8 +320,7 @@ template <int A, int C, bool IOU>
 __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(const DecodeStream m) {
     constexpr int PER = 5 + C, OFF0 = IOU ? A : 0, NCH = A * PER + OFF0, N4ROW = (NCH + 3) / 4, NJ = (N4ROW + 3) / 4;
     static_assert(A >= 1 && A <= 4, "one pair lane per anchor inside a quad");
-    __shared__ float l_lg[DS_WAVES][DS_LW], l_cf[DS_WAVES][DS_LW];
-    __shared__ uint32_t l_ix[DS_WAVES][DS_LW];
+    __shared__ float l_all[DS_WAVES][3 * DS_LW];      // per wave: logits, confidences, indices of the list -- or the dense regime's key cache
     int bx = blockIdx.x, l = 0;
     while (l + 1 < m.nlevels && bx >= m.nb[l]) {
         bx -= m.nb[l];
@@ -336,8 +335,8 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
     const float im_h = p.im_size[n * 2 + 0], im_w = p.im_size[n * 2 + 1];
     uint32_t *ckey = p.cand_key + (long long)n * p.cand_cap;
     uint32_t *cidx = p.cand_idx + (long long)n * p.cand_cap;
-    float *wlg = l_lg[wave], *wcf = l_cf[wave];
-    uint32_t *wix = l_ix[wave];
+    float *wlg = l_all[wave], *wcf = wlg + DS_LW;
+    uint32_t *wix = reinterpret_cast<uint32_t *>(wlg + 2 * DS_LW);
     int l_n = 0;                           // wave-uniform
     const int c = lane >> 2, r = lane & 3;
 
@@ -385,12 +384,17 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
         write_list(__shfl(base, 0));
     };
 
-    for (int g = bx * DS_WAVES + wave; g < ngroups; g += nbx * DS_WAVES) {
+    // (the trip count is the same for all waves of a workgroup -- a wave without a group of its own runs the iteration empty --
+    // because the dense regime below reserves list space per WORKGROUP, behind barriers)
+    __shared__ int w_cnt[2][DS_WAVES], w_base[2];
+    for (int g0 = bx * DS_WAVES; g0 < ngroups; g0 += nbx * DS_WAVES) {
+        const int g = g0 + wave;
+        const bool have = g < ngroups;
         if (l_n > DS_LW / 2) flush_now();          // (several groups per wave, all of them busy: keep half of the list for this one)
         const int l_start = l_n;
         bool dense = false;
         const int cell_base = g * DS_GC;
-        const int ncl = min(DS_GC, cells_img - cell_base);
+        const int ncl = have ? min(DS_GC, cells_img - cell_base) : 0;
         const bool cell_ok = c < ncl;
         const float *row = p.head + ((long long)n * cells_img + cell_base + c) * p.head_ld;
         floatx4 v[NJ];
@@ -458,32 +462,43 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
         }
         // Dense regime (worst case: every pair of every cell passes, 3840 candidates per group).  Filling and flushing the 768-entry
         // list cost one returning atomic on the image's counter per 768 candidates -- 2370 per image, ~75 ns of serialised time
-        // each: 180 of the launch's 267 us (round 3).  Here: count the group's exact survivors, reserve ONCE (474 atomics per
-        // image), evaluate again and store straight to the list, consecutive lanes to consecutive slots.  A compact loop that
-        // re-reads the group's rows (16 KB, L2-hot) a cell at a time, 64 channels per step -- from the registers of the sweep
-        // above the same thing is 2 x 272 unrolled bodies whose invariants (anchor / class per element) spill.  Both sweeps run the
-        // same instructions on the same values, so they agree on every candidate; conf / bound of (cell, anchor) sit in lane
-        // 4 cell + anchor.
-        if (dense) {
-            const float *grow = p.head + ((long long)n * cells_img + cell_base) * p.head_ld;
-            constexpr int NCK = (NCH + 63) / 64;
-            auto load_row = [&](int cc, float (&dst)[NCK]) {
-                const float *rw = grow + (long long)cc * p.head_ld;
+        // each: 180 of the launch's 263 us (round 3); one per group (474) or per half group (948) still queued 36 / 71 us behind
+        // one address.  Now a group that overflows the list leaves it: in two halves of eight cells, a compact loop re-reads the
+        // rows (8 KB, L2-hot, the next cell's row in flight) 64 channels per step, scores every pair ONCE and parks the key (0 =
+        // not a candidate) in the wave's list storage -- 8 x 258 words of its 2304 --, counts the half's survivors, the
+        // WORKGROUP reserves for its eight waves with ONE atomic (118 per image), and a second pass over the parked keys stores
+        // them, consecutive lanes to consecutive slots.  (From the registers of the sweep above the same thing is 272 unrolled
+        // bodies whose per-element invariants spill.)  conf / bound of (cell, anchor) sit in lane 4 cell + anchor.
+        if (__syncthreads_or(dense ? 1 : 0)) {
+            if (dense && l_start > 0) {        // the pending entries of earlier groups own the storage: out with them first
+                l_n = l_start;
+                flush_now();
+            }
+            if (dense) l_n = 0;
+            uint32_t *park = reinterpret_cast<uint32_t *>(wlg);
+            constexpr int NCK = (NCH + 63) / 64, HALF = DS_GC / 2;
+            static_assert(HALF * NCH <= 3 * DS_LW, "the parked keys of half a group fit the wave's list storage");
+#pragma unroll 1
+            for (int c0 = 0; c0 < DS_GC; c0 += HALF) {
+                const int hb = (c0 / HALF) & 1;
+                const int c1 = dense ? min(c0 + HALF, ncl) : c0;          // (a wave that is not dense: nothing to do, but it meets the barriers)
+                const float *grow = p.head + ((long long)n * cells_img + cell_base) * p.head_ld;
+                auto load_row = [&](int cc, float (&dst)[NCK]) {
+                    const float *rw = grow + (long long)cc * p.head_ld;
 #pragma unroll
-                for (int j = 0; j < NCK; ++j) dst[j] = (cc < ncl && 64 * j + lane < NCH) ? rw[64 * j + lane] : 0.0f;
-            };
-            auto sweep = [&](auto write, int base) -> int {
+                    for (int j = 0; j < NCK; ++j) dst[j] = (cc < c1 && 64 * j + lane < NCH) ? rw[64 * j + lane] : 0.0f;
+                };
                 float cur[NCK], nxt[NCK];
-                load_row(0, cur);
-                for (int cc = 0; cc < ncl; ++cc) {
-                    load_row(cc + 1, nxt);          // (the next cell's row is in flight while this one is scored)
+                load_row(c0, cur);
+                int cnt = 0;
+                for (int cc = c0; cc < c1; ++cc) {
+                    load_row(cc + 1, nxt);
                     float cfa[A], bda[A];
 #pragma unroll
                     for (int q = 0; q < A; ++q) {
                         cfa[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(conf), 4 * cc + q));
                         bda[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bound), 4 * cc + q));
                     }
-                    const int boxc = p.box_offset + (cell_base + cc) * A;
 #pragma unroll
                     for (int j = 0; j < NCK; ++j) {
                         const int ch = 64 * j + lane;
@@ -493,36 +508,59 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
                         for (int q = 1; q < A; ++q) a += (t >= q * PER) ? 1 : 0;
                         const int k = t - a * PER - 5;
                         const bool cls = ch < NCH && t >= 0 && k >= 0;
-                        const float lg = cur[j];
                         float b = bda[0], cf = cfa[0];
 #pragma unroll
                         for (int q = 1; q < A; ++q) {
                             b = a >= q ? bda[q] : b;
                             cf = a >= q ? cfa[q] : cf;
                         }
-                        const bool pass = cls && lg > b;
-                        if (__ballot(pass) == 0ull) continue;
-                        const float sc = cf * sigmoidf_(lg);
-                        const bool ok = pass && sc > p.thr;
-                        const unsigned long long bal = __ballot(ok);
-                        if (decltype(write)::value && ok) {
-                            const int gpos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                            if (gpos < p.cand_cap) {
-                                ckey[gpos] = score_to_key(sc);
-                                cidx[gpos] = (uint32_t)((boxc + a) * C + k);
-                            }
+                        const bool pass = cls && cur[j] > b;
+                        uint32_t key = 0u;
+                        if (__ballot(pass) != 0ull) {
+                            const float sc = cf * sigmoidf_(cur[j]);
+                            const bool ok = pass && sc > p.thr;
+                            key = ok ? score_to_key(sc) : 0u;          // (a score above a threshold >= 0 is positive: its key has the top bit set)
+                            cnt += __popcll(__ballot(ok));
                         }
-                        base += __popcll(bal);
+                        if (ch < NCH) park[(cc - c0) * NCH + ch] = key;
                     }
 #pragma unroll
                     for (int j = 0; j < NCK; ++j) cur[j] = nxt[j];
                 }
-                return base;
-            };
-            const int cnt = sweep(std::false_type{}, 0);
-            int base = 0;
-            if (lane == 0 && cnt > 0 && !(m.abl & 1)) base = atomicAdd(p.cand_count + n, cnt);
-            sweep(std::true_type{}, __shfl(base, 0));
+                if (lane == 0) w_cnt[hb][wave] = cnt;
+                __syncthreads();
+                if (tid == 0) {
+                    int sum = 0;
+#pragma unroll
+                    for (int w = 0; w < DS_WAVES; ++w) sum += w_cnt[hb][w];
+                    w_base[hb] = (sum > 0 && !(m.abl & 1)) ? atomicAdd(p.cand_count + n, sum) : 0;
+                }
+                __syncthreads();
+                int base = w_base[hb];
+                for (int w = 0; w < wave; ++w) base += w_cnt[hb][w];
+                for (int cc = c0; cc < c1; ++cc) {
+                    const int boxc = p.box_offset + (cell_base + cc) * A;
+#pragma unroll
+                    for (int j = 0; j < NCK; ++j) {
+                        const int ch = 64 * j + lane;
+                        const uint32_t key = ch < NCH ? park[(cc - c0) * NCH + ch] : 0u;
+                        const unsigned long long bal = __ballot(key != 0u);
+                        if (key != 0u) {
+                            const int t = ch - OFF0;
+                            int a = 0;
+#pragma unroll
+                            for (int q = 1; q < A; ++q) a += (t >= q * PER) ? 1 : 0;
+                            const int gpos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                            if (gpos < p.cand_cap) {
+                                ckey[gpos] = key;
+                                cidx[gpos] = (uint32_t)((boxc + a) * C + (t - a * PER - 5));
+                            }
+                        }
+                        base += __popcll(bal);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     {   // one reservation for the whole workgroup
