@@ -405,379 +405,6 @@ int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStrea
     return PPY_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Round 4: PING-PONG tiles for the 1x1 "expand" layers (reference model/resnet_vd.py:55-91, conv3 + shortcut + ReLU of stages 3-5).
-// On every other tile of this library a launch of such a layer is two chip-wide phases -- ~17 us in which all workgroups multiply
-// (a reduction of only 4-16 chunks: HBM idles) and ~17 us in which they all read the shortcut and store (5.6 TB/s: the matrix
-// pipe idles); four tile shapes end at the same 40.6 us (profiles/r04_expand_stagger.txt).  Here ONE persistent workgroup per
-// CU keeps both phases in flight: twelve waves = four producers (all LDS-DMA pieces, as above) + TWO consumer groups of 2 x 2
-// waves that take the workgroup's 128 x 128 tiles in turn -- while group A multiplies tile i, group B sends tile i-1 through its
-// epilogue (own LDS patches, so the stages keep streaming), then they swap.  The producers run through the chunks of
-// consecutive tiles without a gap, so a tile's first chunks land during the previous tile's last MFMAs.  Synchronisation is the
-// workgroup barrier of the kernel above, one per chunk: s_barrier counts arrivals, so the group that is busy with an epilogue
-// simply arrives NC times per period, between the four 32 x 32 pieces of its sub-tile.  Every wave of a workgroup executes
-// 2 + tiles x NC barriers.  Same operand layouts, same products in the same order, same epilogue arithmetic as the f16x2 tiles:
-// bit-identical results.
-template <bool GP>
-__global__ void __launch_bounds__(768) conv1x1_pp_kernel(const ConvArgs p, const int tiles_n, const int ntiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 128, BN = 128, NS = 3, NP = 2, NWP = 4, TM = 2, TN = 2, WM = 64, WN = 64;
-    constexpr int A_PASS = BM / (8 * NWP), B_ROWS = NP * BN, B_PASS = B_ROWS / (16 * NWP), G = A_PASS + B_PASS;
-    constexpr int A_BYTES = BM * 128, B_BYTES = B_ROWS * 64, STAGE = A_BYTES + B_BYTES;
-    static_assert((NS - 1) * G <= 63, "6-bit vmcnt");
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    extern __shared__ __attribute__((aligned(16))) char smem_ws[];
-    char *smem = smem_ws;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NC = p.chunks_total;                                       // 32-channel chunks of the reduction (R = S = 1)
-    const int nt = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // this workgroup's tiles: b, b + grid, ...
-    const int hw = p.Ho * p.Wo;
-
-    if (wave >= 8) {
-        // ================= producers: the chunks of all tiles, back to back through the NS stages =================
-        const int pw = wave - 8;
-        const unsigned OOB = 0xFFFFFFF0u;
-        unsigned a_off[A_PASS], b_off[B_PASS];
-        const long long plane_bytes = (long long)p.K * p.Kred * 2;
-        auto setup_tile = [&](int q) {
-            const int id = (int)blockIdx.x + q * (int)gridDim.x;
-            const int tm = id / tiles_n, tn = id - tm * tiles_n;
-#pragma unroll
-            for (int d = 0; d < A_PASS; ++d) {
-                const int row = (d * NWP + pw) * 8 + (lane >> 3);
-                const int scol = (lane & 7) ^ ((row >> 1) & 7);
-                const int mr = tm * BM + row;
-                a_off[d] = mr < p.M ? (unsigned)((long long)mr * p.x_ld * 4 + scol * 16) : OOB;
-            }
-#pragma unroll
-            for (int j = 0; j < B_PASS; ++j) {
-                const int rb = (j * NWP + pw) * 16 + (lane >> 2);
-                const int plane = rb / BN, nrow = rb - plane * BN;
-                const int scol = (lane & 3) ^ ((rb >> 2) & 3);
-                const int k = min(tn * BN + nrow, p.K - 1);              // rows >= K are masked at store
-                b_off[j] = (unsigned)(plane * plane_bytes + (long long)k * 64 + scol * 16);
-            }
-        };
-        const char *xb = reinterpret_cast<const char *>(p.x);
-        const char *wb = reinterpret_cast<const char *>(p.wf16);
-        int qi = 0, ki = 0;                                              // the next chunk to request: tile qi, chunk ki
-        auto issue_next = [&](int stage) {
-            const bool have = qi < nt;
-            if (have && ki == 0) setup_tile(qi);
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? (long long)ki * 128 : 0)), 0, 0xFFFFFF00u, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? (long long)ki * p.K * 64 : 0)), 0, 0xFFFFFF00u, 0x00020000);
-            const unsigned lds = (unsigned)(stage * STAGE + pw * 1024);
-#pragma unroll
-            for (int d = 0; d < A_PASS; ++d)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, have ? a_off[d] : OOB, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < B_PASS; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + lds + A_BYTES + j * NWP * 1024), 16, have ? b_off[j] : OOB, 0, 0, 0);
-            if (have && ++ki == NC) {
-                ki = 0;
-                ++qi;
-            }
-        };
-#pragma unroll
-        for (int sidx = 0; sidx < NS; ++sidx) issue_next(sidx);
-        wait_vmcnt<(NS - 1) * G>();                      // chunk 0 has landed
-        __builtin_amdgcn_s_barrier();
-        int st = 0;
-        const int J = nt * NC;
-        for (int j = 0; j < J; ++j) {
-            wait_vmcnt<(NS - 2) * G>();                  // chunk j+1 has landed (this wave's pieces; the barrier makes it all of them)
-            __builtin_amdgcn_s_barrier();                // ... and its consumers have read all of chunk j
-            issue_next(st);
-            st = st + 1 == NS ? 0 : st + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        return;
-    }
-
-    // ================= consumers: group (wave >> 2) takes the tiles q with q & 1 == group =================
-    const int grp = wave >> 2, cw = wave & 3, wm = cw >> 1, wn = cw & 1;
-    float *sE = reinterpret_cast<float *>(smem + NS * STAGE) + wave * (32 * LDS_LD);
-    const int frow = lane & 31, fkh = lane >> 5;
-    const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 2) & 3;
-    int a_foff[2][2], b_foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if constexpr (GP) {
-            a_foff[s][0] = frow * 128 + (((2 * s + fkh) ^ a_sw) << 4);
-            a_foff[s][1] = frow * 128 + (((4 + 2 * s + fkh) ^ a_sw) << 4);
-        } else {
-            a_foff[s][0] = frow * 128 + (((4 * s + 2 * fkh) ^ a_sw) << 4);
-            a_foff[s][1] = frow * 128 + (((4 * s + 2 * fkh + 1) ^ a_sw) << 4);
-        }
-        b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
-    }
-    struct Frag {
-        uintx4 a[TM][NP];
-        uintx4 b[NP][TN];
-    };
-    constexpr int NM = 3 * TM * TN, NRA = 2 * TM, NRB = NP * TN, NR = NRA + NRB;
-    constexpr int NSL = GP ? 0 : 3 * 4 * TM;
-    constexpr int RPS = (NR + NM - 1) / NM;
-    constexpr int LEAD0 = (NRA + RPS - 1) / RPS + 1;
-    constexpr int LEAD = LEAD0 < NM ? LEAD0 : NM - 1;
-    constexpr int PER = (NSL + (NM - LEAD) - 1) / (NM - LEAD);
-    floatx16 acc[TM][TN];
-    float sa[TM], inv_sa[TM];
-    // one k-step (conv_igemm_ws_kernel's step()): NM slots { one MFMA of step g ; LDS reads for step g+1 ; pieces of its split }
-    auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag, const bool fetch) {
-        constexpr int s = decltype(s_tag)::value;
-        constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0};
-        const char *a_ptr = smem + stage * STAGE + wm * WM * 128;
-        const char *b_ptr = smem + stage * STAGE + A_BYTES + wn * WN * 64;
-        floatx4 raw[TM][2];
-        float ra[TM][4], rb[TM][4];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            {
-                const int t = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][ta[t]]),
-                                                                  __builtin_bit_cast(f16x8, cur.b[tb[t]][j]), acc[i][j], 0, 0, 0);
-            }
-            if (fetch) {
-#pragma unroll
-                for (int u = 0; u < RPS; ++u) {
-                    const int r = m * RPS + u;
-                    if (r >= NR) {
-                    } else if (r < NRA) {
-                        if constexpr (GP)
-                            nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
-                        else
-                            raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
-                    } else {
-                        const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
-                        nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
-                    }
-                }
-                if (m >= LEAD) {
-#pragma unroll
-                    for (int u = 0; u < PER; ++u) {
-                        const int sl = (m - LEAD) * PER + u;
-                        if (sl < NSL) {
-                            const int stg = sl / (4 * TM), pr = sl % (4 * TM), i = pr / 4, q4 = pr % 4;
-                            const float xa = raw[i][q4 >> 1][(q4 & 1) * 2], xb = raw[i][q4 >> 1][(q4 & 1) * 2 + 1];
-                            if (stg == 0) {
-                                nxt.a[i][0][q4] = cvt_pk_f16(xa * sa[i], xb * sa[i]);
-                            } else if (stg == 1) {
-                                const unsigned P = nxt.a[i][0][q4];
-                                ra[i][q4] = fmaf(xa, sa[i], -f16_lo(P));
-                                rb[i][q4] = fmaf(xb, sa[i], -f16_hi(P));
-                            } else {
-                                nxt.a[i][1][q4] = cvt_pk_f16(ra[i][q4], rb[i][q4]);
-                            }
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
-    };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
-
-    // the epilogue of a finished tile (tile_epilogue's vector path: scale, shift, shortcut, activation, tracked maxima), in four
-    // 32 x 32 pieces; `sync`: this group is the passive one of a period and arrives at the period's NC barriers on the way
-    auto epilogue = [&](const int m0, const int n0, const float (&rowscale)[TM][4], const bool sync) {
-        const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-        const int mw0 = min(m0 + wm * WM, p.M - 1), mw1 = min(m0 + wm * WM + WM - 1, p.M - 1);
-        const int n_lo = mw0 / hw, n_hi = mw1 / hw;
-        const int bnd = (n_lo + 1) * hw;
-        float amx = 0.0f, amx_hi = 0.0f;
-        floatx4 rv[TM][TN][4];
-        if (p.res) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int col = n0 + wn * WN + j * 32 + ec4;
-                        const int m = m0 + wm * WM + i * 32 + erow + 8 * t;
-                        rv[i][j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
-                        if (col < p.K && m < p.M) rv[i][j][t] = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
-                    }
-        }
-        int piece = 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + ec4;
-            const bool colok = col < p.K;
-            floatx4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (colok) {
-                sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
-                sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mbase = m0 + wm * WM + i * 32 + erow;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    sE[row * LDS_LD + (lane & 31)] = acc[i][j][e];
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = mbase + 8 * t;
-                    floatx4 v = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * t) * LDS_LD + ec4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] *= rowscale[i][t];
-                    if (colok && m < p.M) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            float o = fmaf(v[u], sc[u], sh[u]);
-                            if (p.res) o += rv[i][j][t][u];
-                            v[u] = ppy_apply_act(o, p.act);
-                        }
-                        const float rmx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                        amx = fmaxf(amx, m < bnd ? rmx : 0.0f);
-                        amx_hi = fmaxf(amx_hi, m < bnd ? 0.0f : rmx);
-                        *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (sync) {          // this piece's share of the period's NC arrivals
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const int nb = NC * (piece + 1) / 4 - NC * piece / 4;
-                    for (int b = 0; b < nb; ++b) __builtin_amdgcn_s_barrier();
-                }
-                ++piece;
-            }
-        }
-        if (p.amax_out) amax_track2(amx, amx_hi, n_lo, n_hi, p.amax_out, blockIdx.x * 8 + wave);
-    };
-
-    bool pend = false;
-    int pend_m0 = 0, pend_n0 = 0;
-    float pend_scale[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pend_scale[i][t] = 0.f;
-    __builtin_amdgcn_s_barrier();            // chunk 0 is in the LDS
-    int st = 0;
-    for (int q = 0; q < nt; ++q) {
-        if ((q & 1) != grp) {
-            // ---- passive period: the tile finished one period ago goes out; NC arrivals either way ----
-            if (pend) {
-                epilogue(pend_m0, pend_n0, pend_scale, true);
-                pend = false;
-            } else {
-                for (int b = 0; b < NC; ++b) __builtin_amdgcn_s_barrier();
-            }
-            st = (st + NC) % NS;
-            continue;
-        }
-        const int id = (int)blockIdx.x + q * (int)gridDim.x;
-        const int tm_ = id / tiles_n, tn_ = id - tm_ * tiles_n;
-        const int m0 = tm_ * BM, n0 = tn_ * BN;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {        // per-image activation scale (conv_x3.hip)
-            const int mrow = min(m0 + wm * WM + i * 32 + (lane & 31), p.M - 1);
-            if constexpr (GP) {
-                sa[i] = p.xscale[mrow / hw];
-                inv_sa[i] = pow2_inverse(sa[i]);
-            } else {
-                const float mx = amax_read(p.amax_in, mrow / hw);
-                const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-                int f = 267 - e;
-                f = f < 103 ? 103 : (f > 167 ? 167 : f);
-                sa[i] = __uint_as_float((unsigned)f << 23);
-                inv_sa[i] = __uint_as_float((unsigned)(254 - f) << 23);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        Frag f0, f1;
-        {   // operands of (chunk 0, k-step 0) of this tile: landed since the last barrier
-            const char *a_ptr = smem + st * STAGE + wm * WM * 128;
-            const char *b_ptr = smem + st * STAGE + A_BYTES + wn * WN * 64;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (GP) {
-                    f0.a[i][0] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
-                    f0.a[i][1] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
-                } else {
-                    const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
-                    const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const float xa = q4 < 2 ? lo[2 * q4] : hi[2 * q4 - 4], xb = q4 < 2 ? lo[2 * q4 + 1] : hi[2 * q4 - 3];
-                        const unsigned P0 = cvt_pk_f16(xa * sa[i], xb * sa[i]);
-                        f0.a[i][0][q4] = P0;
-                        f0.a[i][1][q4] = cvt_pk_f16(fmaf(xa, sa[i], -f16_lo(P0)), fmaf(xb, sa[i], -f16_hi(P0)));
-                    }
-                }
-            }
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
-        }
-        for (int k = 0; k < NC; ++k) {
-            step(f0, f1, st, S1(), true);                        // k-step 0 of chunk k  ||  fetch + split k-step 1
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of chunk k has returned
-            __builtin_amdgcn_s_barrier();
-            st = st + 1 == NS ? 0 : st + 1;
-            step(f1, f0, st, S0(), k + 1 < NC);                  // k-step 1 of chunk k  ||  k-step 0 of chunk k+1 (not across a tile: the next tile is the other group's)
-        }
-        pend = true;
-        pend_m0 = m0;
-        pend_n0 = n0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) pend_scale[i][t] = __shfl(inv_sa[i], (lane >> 3) + 8 * t);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (pend) epilogue(pend_m0, pend_n0, pend_scale, false);
-#endif
-}
-
-int launch_pp(ConvArgs p, int splits, hipStream_t stream) {
-    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad != 0 || p.ups || p.posb || p.yscale || p.bn_part || splits > 1) return PPY_ERR_BAD_ARG;
-    if (!vec_epilogue_ok(p) || ((uintptr_t)p.x & 15) != 0 || p.x_ld % 4 != 0) return PPY_ERR_BAD_ARG;
-    const long long xbytes = (long long)p.M * p.x_ld * 4, wbytes = (long long)p.K * p.Kred * 2 * 2;
-    if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL) return PPY_ERR_UNSUPPORTED;
-    p.nstages = 3;
-    p.chunks_total = p.C / 32;
-    p.chunks_per_split = p.chunks_total;
-    const int tiles_n = ceil_div(p.K, 128), ntiles = ceil_div(p.M, 128) * tiles_n;
-    int n_cu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n_cu = prop.multiProcessorCount;
-    }
-    const int grid = ntiles < n_cu ? ntiles : n_cu;              // one persistent workgroup (twelve waves, 132 KB of LDS) per CU
-    const size_t lds = (size_t)3 * (128 * 128 + 256 * 64) + (size_t)8 * 32 * LDS_LD * sizeof(float);
-    static PpyLdsAttr attr_gp, attr_plain;
-    if (p.xscale) {
-        if (ppy_lds_attr(attr_gp, reinterpret_cast<const void *>(conv1x1_pp_kernel<true>), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv1x1_pp_kernel<true>, dim3(grid), dim3(768), lds, stream, p, tiles_n, ntiles);
-    } else {
-        if (ppy_lds_attr(attr_plain, reinterpret_cast<const void *>(conv1x1_pp_kernel<false>), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv1x1_pp_kernel<false>, dim3(grid), dim3(768), lds, stream, p, tiles_n, ntiles);
-    }
-    return ppy_launch_status();
-}
-
 template <int BM, int BN, int NS, bool PRE = false>
 int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
@@ -823,7 +450,7 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 // split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4; eight consumer waves (4 x 2)
 // + four producers on a 256x128 tile: 7 = two stages, 8 = three
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 10; }      // (9 = the ping-pong tiles for 1x1 layers, conv1x1_pp_kernel)
+int ppy_ws_num_configs() { return 9; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -840,7 +467,6 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 6: return launch_ws<128, 64, 4, true>(q, s, st);
         case 7: return launch_ws<256, 128, 2>(q, s, st);
         case 8: return launch_ws<256, 128, 3>(q, s, st);
-        case 9: return launch_pp(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

@@ -469,8 +469,7 @@ class HipExecutor(object):
         if f0 <= cfg < f0 + 27 or f0 + 45 <= cfg < f0 + 54:          # 9 tiles x {2, 3, 4} stages; the 96 / 192-row tiles
             return True
         w0 = K.ws_first_cfg()
-        # (9 = the ping-pong tiles for 1x1 layers: they read pre-split tensors but always write fp32)
-        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8))
+        return cfg - w0 in ((0, 1, 2, 3, 7, 8) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8))
 
     def _split_pairs(self):
         """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (split_pairs below)."""
