@@ -139,7 +139,7 @@ def worst_case_leg(wl, dev, x, ims, sd, cfg, depth, seconds, cpu_threads):
     return out
 
 
-def pmc_traffic_leg(argv_tail, nconv, timeout=300):
+def pmc_traffic_leg(argv_tail, nconv, timeout=120):
     """HBM-side bytes of the convolution launches, MEASURED BY THIS RUN: bench.py re-executes itself twice under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (counters need their own passes and their own process: the guide's
     HBM / rocprofv3 section) as a short eager one-lane child, and sums the counters of the convolution kernels per pass of the
