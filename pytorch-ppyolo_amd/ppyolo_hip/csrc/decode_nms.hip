@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(512) nms_collect_kernel(const NmsArgs p) {
     const int quads = (count + 3) >> 2;
     const int per = (quads + NMS_CG - 1) / NMS_CG;
     const int q0 = blockIdx.x * per, q1 = min(q0 + per, quads);
-    if ((reinterpret_cast<uintptr_t>(ckey) & 15) == 0) {
+    if ((reinterpret_cast<uintptr_t>(ckey) & 15) == 0 && (p.cand_cap & 3) == 0) {      // (whole quads inside this image's list)
         constexpr int U = 4;
         for (int qb = q0; qb < q1; qb += 512 * U) {
             uintx4 v[U];

@@ -632,3 +632,26 @@ def test_vd_shortcut_pool_is_written_by_its_producer(monkeypatch):
         got = model(x, ims)
         for a, b in zip(got, base):
             assert torch.equal(a, b), force
+
+
+def test_shortcut_fold_same_detections(monkeypatch):
+    """Round 4 (model/resnet_vd.py ConvBlock._emit_folded): the projection shortcut of every stage's first block evaluated inside
+    that block's conv3 -- one 1x1 convolution over [z | s] -- against the plan with the shortcut as its own launch + residual:
+    four launches fewer, same detections and keep indices, head outputs equal to fp32 noise."""
+    from ppyolo_hip.runtime import build_plan
+    cfg = PPYOLO_2x_Config()
+    x, ims = synth.synth_images(2, 320).cuda(), synth.synth_im_size(2).cuda()
+    got = {}
+    for fold in ('0', '1'):
+        monkeypatch.setenv('PPYOLO_HIP_FOLD_SHORTCUT', fold)
+        model, _ = build_model(cfg, 0, 'cuda')
+        dets, cnt, keep = model.forward_padded(x, ims)
+        torch.cuda.synchronize()
+        ex = model._plans.executor(x)
+        got[fold] = (dets.clone(), cnt.clone(), keep.clone(), [ex.view(a).dense().clone() for a in ex.plan.head_outs],
+                     sum(1 for o in ex.plan.ops if o['op'] == 'conv'))
+    assert got['0'][4] - got['1'][4] == 4
+    assert torch.equal(got['0'][1], got['1'][1]) and torch.equal(got['0'][2], got['1'][2]), 'detections / keep indices differ'
+    assert (got['0'][0][:, :, 1] - got['1'][0][:, :, 1]).abs().max() <= 2e-6
+    for a, b in zip(got['0'][3], got['1'][3]):
+        assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))

@@ -291,3 +291,32 @@ def test_two_training_forwards_before_one_backward_keep_their_own_gradients():
         assert torch.equal(q.grad, want), k
         worst = max(worst, float((single[0][k] - single[1][k]).abs().max()))
     assert worst > 0          # the two batches do have different gradients
+
+
+def test_validation_forward_without_optimizer_step_invalidates_the_plans():
+    """A training-mode forward that is NOT followed by optimizer.step() -- a validation-loss forward, the first micro-batches of a
+    gradient accumulation -- still moves the BatchNorm running statistics, written by the HIP kernels through raw pointers (no
+    autograd version bump), and may re-bind the num_batches_tracked buffers.  The inference plans folded from the old statistics
+    must be dropped (PlanCache.mark_dirty, round 4): the next eval equals a freshly built model on the same state_dict."""
+    from conftest import build_model
+    S, N = 128, 2
+    cfg, m, gt, targets = _r18_loop_pieces(S, N)
+    xe = synth.synth_images(N, S, seed=99).cuda()
+    ims = synth.synth_im_size(N).cuda()
+
+    def head_outputs(mod):
+        ex = mod._plans.executor(xe)
+        return [ex.view(a).dense().clone() for a in ex.plan.head_outs]
+    m.eval()
+    before = [p.clone() for p in m(xe, ims)] + head_outputs(m)          # builds (and caches) the inference executor
+    m.train()
+    for it in range(2):                                                   # loss forwards only: no backward(), no step()
+        m(synth.synth_images(N, S, seed=500 + it).cuda(), None, False, gt, None, None, targets)
+    m.eval()
+    after = [p.clone() for p in m(xe, ims)] + head_outputs(m)
+    fresh, _ = build_model(cfg, 0, 'cuda')
+    fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    want = [p for p in fresh(xe, ims)] + head_outputs(fresh)
+    for a, b in zip(after, want):
+        assert torch.equal(a, b), 'the evaluation ran plans folded from stale BatchNorm statistics'
+    assert any(not torch.equal(a, b) for a, b in zip(before[N:], after[N:])), 'the statistics did move'
