@@ -934,11 +934,11 @@ def main():
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
         # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
         traffic, traffic_src = None, None
+        why_stale = '--no-pmc' if a.no_pmc else 'N > 1'
         if world == 1 and not a.no_pmc:
             traffic, traffic_src = pmc_traffic_leg(['--workload', a.workload, '--batch', str(a.batch)], nconv)
             if traffic is None:
-                pmc_failed = traffic_src
-                traffic_src = None
+                why_stale, traffic_src = traffic_src, None
         if traffic is None and a.workload == 'r50vd_608' and a.batch == 8:
             import glob
             files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')) if '_train_' not in os.path.basename(f))
@@ -948,7 +948,7 @@ def main():
                 traffic = round(rec['hbm_bytes_per_step'] / nconv)
                 traffic_src = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured', 'round 1'), stale=True,
                                    note='NOT measured by this run (%s): committed rocprofv3 PMC summary of the named date '
-                                        '(tools/prof_run.sh -> tools/pmc_traffic.py)' % ('--no-pmc' if a.no_pmc else locals().get('pmc_failed', 'N > 1')))
+                                        '(tools/prof_run.sh -> tools/pmc_traffic.py)' % why_stale)
         roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
                     traffic_unit='bytes per launch (mean over the conv launches of a step; PMC 2*FETCH_SIZE+WRITE_SIZE)',

@@ -66,9 +66,10 @@ class ConvBlock(_Units, torch.nn.Module):
         if not (self._fold() and self.is_first):
             return None
         f2, cs = self.conv2.filters, self.conv4.conv.in_channels
-        self._wide = b.new_buf(N, H, W, f2 + cs)
+        wide = b.new_buf(N, H, W, f2 + cs)
+        b.wide_of_block[id(self)] = wide          # (kept on the builder: a plan under construction, not module state)
         from ppyolo_hip.engine import A
-        return A(self._wide, f2, cs, N, H, W)
+        return A(wide, f2, cs, N, H, W)
 
     def emit(self, b, x, out=None):
         if self._fold():
@@ -85,9 +86,9 @@ class ConvBlock(_Units, torch.nn.Module):
         from ppyolo_hip.engine import A
         f2, cs, f3 = self.conv2.filters, self.conv4.conv.in_channels, self.conv3.filters
         Ho, Wo = (x.H, x.W) if self.is_first else (x.H // 2, x.W // 2)
-        wide = getattr(self, '_wide', None)
+        wide = b.wide_of_block.pop(id(self), None)
         if self.is_first and wide is not None and x.buf == wide:      # x already sits in its slice (wide_input)
-            self._wide = None
+            pass
         else:
             wide = b.new_buf(x.N, Ho, Wo, f2 + cs)
             s_slot = A(wide, f2, cs, x.N, Ho, Wo)

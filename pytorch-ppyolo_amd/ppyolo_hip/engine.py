@@ -121,6 +121,7 @@ class Builder(object):
         self.skeleton = skeleton
         self._coord_cache = {}
         self._stream = 0
+        self.wide_of_block = {}      # ConvBlock (by id) -> wide buffer its input was placed into (model/resnet_vd.py, shortcut fold)
 
     # ---- buffers -------------------------------------------------------------------------
     def new_buf(self, N, H, W, ld):
