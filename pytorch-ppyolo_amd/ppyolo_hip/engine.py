@@ -520,6 +520,21 @@ class HipExecutor(object):
                 n += 1
         return n
 
+    def presplit_headroom(self):
+        """Diagnostic (host sync; after a run): for every pre-split link and image, (key of the producer, log2 of the SCALED
+        maximum s_image * max|y|).  The scale comes from a static bound of |y| (above), so the scaled maximum sits below 2^14 by
+        however pessimistic that bound is for the data at hand; both fp16 terms stay normal numbers for values down to
+        2^-(24 - (14 - log2)) of the maximum.  tests/test_gpu_model.py holds the R50vd plan to >= 2^4 on its synthetic inputs."""
+        out = []
+        for op in self.plan.ops:
+            ys = op.get('y_split')
+            if ys is None or op.get('amax_out_id') is None:
+                continue
+            mx = self._amax(op['amax_out_id']).view(self.plan.N, -1).amax(dim=1)
+            scaled = (mx * ys[0]).cpu()
+            out.append((tune_key(op), [float(torch.log2(v)) if v > 0 else float('-inf') for v in scaled]))
+        return out
+
     def _amax(self, idx):
         return None if idx is None else self.amax[idx * self._amax_block:(idx + 1) * self._amax_block]
 

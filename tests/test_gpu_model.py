@@ -655,3 +655,21 @@ def test_shortcut_fold_same_detections(monkeypatch):
     assert (got['0'][0][:, :, 1] - got['1'][0][:, :, 1]).abs().max() <= 2e-6
     for a, b in zip(got['0'][3], got['1'][3]):
         assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_presplit_scales_leave_headroom_on_the_full_size_plan():
+    """The pre-split links take their per-image scale from a STATIC bound of |y| (engine._link_splits): however pessimistic the
+    bound is for the data at hand, that many of the 14 bits above the fp16 terms' floor are given away.  On the R50vd-608 plan
+    and its synthetic batch the scaled maximum of every linked tensor and image stays within [2^4, 2^14): at least 14 of the 24
+    significand bits of the maximum survive in two normal fp16 terms, and the absolute floor 2^-25 / s is <= 2^-29 of the
+    tensor's maximum (HipExecutor.presplit_headroom; the advisor's round-3 finding, measured instead of assumed)."""
+    model, _ = build_model(PPYOLO_2x_Config(), 0, 'cuda')
+    x, ims = synth.synth_images(8, 608).cuda(), torch.tensor(_FULL_IMS).cuda()
+    model.forward_padded(x, ims)
+    torch.cuda.synchronize()
+    rows = model._plans.executor(x).presplit_headroom()
+    assert len(rows) >= 35
+    lo = min(min(v) for _, v in rows)
+    hi = max(max(v) for _, v in rows)
+    print('pre-split links: %d, log2 of the scaled per-image maximum between %.1f and %.1f' % (len(rows), lo, hi))
+    assert 4.0 <= lo and hi < 14.0, [(k, v) for k, v in rows if min(v) < 4.0 or max(v) >= 14.0]
