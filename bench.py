@@ -182,8 +182,36 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
             return None, '%s pass failed: %s' % (counter, type(exc).__name__)
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    # third pass: the matrix pipe's own busy count (BASELINE.json's metric names "conv MFMA util %"): SQ_VALU_MFMA_BUSY_CYCLES is 32
+    # per 32x32x16 wave-instruction over all SIMDs, GRBM_GUI_ACTIVE the active cycles summed over the 8 XCDs -- at the clock the
+    # board actually ran.  Optional: a failure here leaves the traffic figures standing.
+    mfma = None
+    d = tempfile.mkdtemp(prefix='ppy_pmc_')
+    try:
+        cmd = [exe, '--kernel-trace', '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-child'] + argv_tail
+        subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout, check=True)
+        busy = active = 0.0
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection*.csv'), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = r['Kernel_Name']
+                    if any(n in k for n in main_k):
+                        if r.get('Counter_Name') == 'SQ_VALU_MFMA_BUSY_CYCLES':
+                            busy += float(r['Counter_Value'])
+                        elif r.get('Counter_Name') == 'GRBM_GUI_ACTIVE':
+                            active += float(r['Counter_Value'])
+        if busy > 0 and active > 0:
+            mfma = dict(frac=round(busy / (active / 8.0 * 1024.0), 4), unit='share of the matrix pipe\'s cycles with an MFMA in flight, all conv / DCN launches, time-weighted',
+                        note='SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), rocprofv3 --pmc pass of this run; 3 MFMA products per fp32 '
+                             'multiply-add in the f16x2 scheme, i.e. a third of the busy cycles is useful fp32 work')
+    except Exception:
+        mfma = None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     byt = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
-    return round(byt / nconv), dict(measured_by='this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an eager one-lane child process',
+    return round(byt / nconv), dict(mfma_busy_pmc=mfma, measured_by='this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an eager one-lane child process',
                                     hbm_bytes_per_step=round(byt), fetch_size_kb_per_step=round(tot['FETCH_SIZE'], 1),
                                     write_size_kb_per_step=round(tot['WRITE_SIZE'], 1), gfx950_fetch_correction=2.0,
                                     seconds=round(time.perf_counter() - t0, 1), stale=False)
@@ -949,8 +977,9 @@ def main():
                 traffic_src = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured', 'round 1'), stale=True,
                                    note='NOT measured by this run (%s): committed rocprofv3 PMC summary of the named date '
                                         '(tools/prof_run.sh -> tools/pmc_traffic.py)' % why_stale)
+        mfma_pmc = traffic_src.pop('mfma_busy_pmc', None) if traffic_src else None
         roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
-                    frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                    frac=round(achieved / peak, 4), mfma_busy_pmc=mfma_pmc, traffic=traffic, traffic_source=traffic_src,
                     traffic_unit='bytes per launch (mean over the conv launches of a step; PMC 2*FETCH_SIZE+WRITE_SIZE)',
                     kernel='conv_igemm_x3_kernel<*> (fp32-in/fp32-out implicit GEMM on the 16-bit MFMA: f16x2 = 3 x '
                            'v_mfma_f32_32x32x16_f16 per product after a 2-term fp16 split, bf16x3 = 6 x ..._bf16 after a 3-term '
