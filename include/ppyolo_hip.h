@@ -140,10 +140,6 @@ int ppy_conv2d_patch_first_config(void);
 /* First cfg id of the f16x2 tiles with specialised waves (csrc/conv_ws.hip: four waves deliver operands, four multiply; any
  * geometry the f16x2 tiles take, split-K included; bit-identical results). */
 int ppy_conv2d_ws_first_config(void);
-/* Cfg id of the kernel for convolutions with K <= 32 output channels and C % 32 == 0 (csrc/conv_narrow.hip, one id, f16x2
- * operands: eight waves share the reduction of one 32-pixel tile -- the DCNv2 offset convolutions, reference
- * model/custom_layers.py:551-564).  No shortcut input, no split-K; anything else under this id is PPY_ERR_BAD_ARG. */
-int ppy_conv2d_narrow_first_config(void);
 /* Writes the tile configuration / split the heuristic would pick. */
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);

@@ -526,9 +526,7 @@ void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
 static int stream_first() { return kNumCfgs + ppy_x3_num_configs(); }
 static int patch_first() { return stream_first() + ppy_stream_num_configs(); }
 static int ws_first() { return patch_first() + ppy_patch_num_configs(); }
-static int narrow_first() { return ws_first() + ppy_ws_num_configs(); }      // conv_narrow.hip (round 4)
-extern "C" int ppy_conv2d_num_configs(void) { return narrow_first() + ppy_narrow_num_configs(); }
-extern "C" int ppy_conv2d_narrow_first_config(void) { return narrow_first(); }
+extern "C" int ppy_conv2d_num_configs(void) { return ws_first() + ppy_ws_num_configs(); }
 extern "C" int ppy_conv2d_ws_first_config(void) { return ws_first(); }
 extern "C" int ppy_conv2d_stream_first_config(void) { return stream_first(); }
 extern "C" int ppy_conv2d_patch_first_config(void) { return patch_first(); }
@@ -660,8 +658,7 @@ static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
     // (statistics from the epilogue exist in the f16x2 kernels only: conv_x3.hip's tiles, conv_stream.hip, conv_patch.hip, conv_ws.hip)
     if (p.bn_part && c < kNumCfgs + ppy_x3_f16_base()) return PPY_ERR_UNSUPPORTED;
     // pre-split tensors exist on the f16x2 tiles (conv_x3.hip, conv_ws.hip) only: anything else would misread the bytes
-    if ((p.xscale || p.yscale) && (c < kNumCfgs + ppy_x3_f16_base() || (c >= stream_first() && c < ws_first()) || c >= narrow_first())) return PPY_ERR_BAD_ARG;
-    if (c >= narrow_first()) return ppy_narrow_dispatch(p, c - narrow_first(), s, st);
+    if ((p.xscale || p.yscale) && (c < kNumCfgs + ppy_x3_f16_base() || (c >= stream_first() && c < ws_first()))) return PPY_ERR_BAD_ARG;
     if (c >= ws_first()) return ppy_ws_dispatch(p, c - ws_first(), s, st);
     if (c >= patch_first()) return s == 1 ? ppy_patch_dispatch(p, c - patch_first(), st) : PPY_ERR_BAD_ARG;
     if (c >= stream_first()) return s == 1 ? ppy_stream_dispatch(p, c - stream_first(), nullptr, 0, st) : PPY_ERR_BAD_ARG;

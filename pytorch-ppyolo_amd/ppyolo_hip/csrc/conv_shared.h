@@ -70,9 +70,6 @@ int ppy_patch_dispatch(const ConvArgs &p, int local_cfg, hipStream_t stream);
 // conv_ws.hip: the f16x2 tiles with specialised waves (four deliver operands, four multiply)
 int ppy_ws_num_configs();
 int ppy_ws_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
-// conv_narrow.hip: K <= 32 output channels, eight waves share the reduction of one 32-pixel tile (the DCNv2 offset convolutions)
-int ppy_narrow_num_configs();
-int ppy_narrow_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
 
 namespace {
 

@@ -158,12 +158,7 @@ def ws_first_cfg():
 
 
 def ws_num_cfgs():
-    return lib().ppy_conv2d_narrow_first_config() - lib().ppy_conv2d_ws_first_config()
-
-
-def narrow_cfg():
-    """Conv cfg id of the kernel for K <= 32 output channels (csrc/conv_narrow.hip: the DCNv2 offset convolutions)."""
-    return lib().ppy_conv2d_narrow_first_config()
+    return lib().ppy_conv2d_num_configs() - lib().ppy_conv2d_ws_first_config()
 
 
 def patch_first_cfg():
