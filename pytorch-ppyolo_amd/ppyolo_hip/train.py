@@ -130,6 +130,14 @@ class TrainStep(object):
         self._coord_bufs = {}
         self._prep, self._prep_done = None, False      # ops.WeightPrepTable of the trainable convolutions (built after the first step)
         self.ws = torch.empty(96 << 20, dtype=torch.float32, device=dev)     # conv split-K / dgrad / wgrad / reductions
+        # The weight gradient of a head convolution has no consumer before the optimizer: it runs on a SECOND stream beside the data
+        # gradient chain (its own workspace; the operands are kept alive until the join at the end of the backward).  Same kernels,
+        # same results bit for bit; PPYOLO_HIP_TRAIN_WGRAD_STREAM=0 puts it back in line.
+        self._wgrad_side = os.environ.get('PPYOLO_HIP_TRAIN_WGRAD_STREAM', '1') == '1'
+        self._wstream = torch.cuda.Stream(device=dev) if self._wgrad_side else None
+        self._ws_side = None
+        self._wkeep = []
+        self._wpending = False
         self.steps_done = 0
         self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
         self.weight_decay = cfg.optimizerBuilder['regularizer']['factor']
@@ -490,6 +498,27 @@ class TrainStep(object):
         K.zero_insert(d_raw.view(), up.view(), stride)
         K.conv2d_dgrad(up.view(), krsc, dxin.view(), 1, pad, self.ws, amax_dy=amax)       # (zeros do not raise the maximum)
 
+    def _wgrad(self, xin, d_raw, dw, stride, pad, amax_x, amax_dy):
+        """Weight gradient of a convolution; with the side stream, issued there behind everything queued so far."""
+        if not self._wgrad_side:
+            K.conv2d_wgrad(xin.view(), d_raw.view(), dw, stride, pad, self.ws, amax_x, amax_dy)
+            return
+        if self._ws_side is None:
+            self._ws_side = torch.empty_like(self.ws)
+        main = torch.cuda.current_stream(self.dev)
+        self._wstream.wait_stream(main)
+        with torch.cuda.stream(self._wstream):
+            K.conv2d_wgrad(xin.view(), d_raw.view(), dw, stride, pad, self._ws_side, amax_x, amax_dy)
+        self._wkeep.append((xin.t, d_raw.t))          # (the allocator must not hand these out again before the join)
+        self._wpending = True
+
+    def _join_wgrad(self):
+        """The current stream waits for the weight gradients issued on the side stream."""
+        if self._wpending:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wstream)
+            self._wpending = False
+        self._wkeep = []
+
     def _conv_unit_bwd(self, prefix, x, xin, raw, y, mean, invstd, act, stride, pad, ent, res=None):
         dy = y.g
         if dy is None:
@@ -513,8 +542,8 @@ class TrainStep(object):
             if f16 and d_raw.amax is None:
                 d_raw.amax = K.amax_slots(d_raw.t)      # (the loss gradient of an output convolution: three small tensors per step)
             K.channel_sum(dy.view(), self.G[prefix + '.conv.bias'], self.ws)
-        K.conv2d_wgrad(xin.view(), d_raw.view(), self.G[prefix + '.conv.weight'], stride, pad, self.ws,
-                       xin.amax if f16 and d_raw.amax is not None else None, d_raw.amax if f16 else None)
+        self._wgrad(xin, d_raw, self.G[prefix + '.conv.weight'], stride, pad,
+                    xin.amax if f16 and d_raw.amax is not None else None, d_raw.amax if f16 else None)
         unit = 2 * raw.N * raw.H * raw.W * raw.C * ent['krsc'].shape[1] * ent['krsc'].shape[2] * ent['Cin']
         self.flops += unit
         if x.req:
@@ -813,6 +842,7 @@ class TrainStep(object):
         finally:
             self.tape = []
             self._prep_done = False
+            self._join_wgrad()           # (also after an exception: nothing of this step stays queued behind freed operands)
             # BatchNorm running statistics / counters were written through raw pointers (no autograd version bump) and the
             # counters may have been re-bound: inference executors folded from the old values are stale
             plans = getattr(self.model, '_plans', None)
@@ -843,6 +873,7 @@ class TrainStep(object):
                 out.g = dout
             for fn in reversed(self.tape):
                 fn()
+            self._join_wgrad()
         self.outs = outs
         if self._prep is None and self.gflat is not None:
             self._build_prep()
@@ -923,6 +954,8 @@ class TrainStep(object):
         left.discard(prefix)
         if not left:
             del self._pending[b]
+            if self._wpending:           # the bucket's weight gradients may still be running on the side stream
+                torch.cuda.current_stream(self.dev).wait_stream(self._wstream)
             for a, e in self._buckets[b]['ranges']:
                 self._works.append(torch.distributed.all_reduce(self.gflat[a:e], async_op=True))
             self._reduced.append(b)

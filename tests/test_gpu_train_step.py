@@ -179,6 +179,33 @@ def test_sgd_step_changes_the_model_and_loss_goes_down():
     assert len(out) == N
 
 
+def test_weight_gradients_on_the_side_stream_change_nothing(monkeypatch):
+    """The head's weight gradients run on a second stream beside the data-gradient chain (train.py:_wgrad): same kernels on the
+    same operands, so gradients, parameters and loss after two steps are EQUAL to the in-line form's, bit for bit -- a missing
+    wait (an operand overwritten early, the optimizer reading an unfinished gradient) would show here."""
+    from ppyolo_hip.train import TrainStep
+    cfg = PPYOLO_r18vd_Config()
+    N, S = 4, 256
+    x = synth.synth_images(N, S, seed=11).cuda()
+    gt, targets = synth_targets(cfg, N, S, 5)
+    gt, targets = gt.cuda(), [t.cuda() for t in targets]
+    got = {}
+    for side in ('0', '1', '1'):
+        monkeypatch.setenv('PPYOLO_HIP_TRAIN_WGRAD_STREAM', side)
+        model, _ = build_model(cfg, 0, 'cuda')
+        ts = TrainStep(model, cfg)
+        assert ts._wgrad_side == (side == '1')
+        losses = [ts.step(x, gt, targets, 0.002).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        res = (torch.stack(losses).cpu(), ts.gflat.clone().cpu(), ts.pflat.clone().cpu())
+        if side in got:
+            for a, b in zip(got[side], res):
+                assert torch.equal(a, b), 'the step is not repeatable with the side stream'
+        got[side] = res
+    for a, b in zip(got['0'], got['1']):
+        assert torch.equal(a, b)
+
+
 def test_sgd_groups_and_ema_semantics():
     """optimizer.step() + ema.update() of reference train.py:442-444: weight decay on convolution weights only
     (custom_layers.py:167-215), momentum buffers start as the first gradient, EMA decay warms up as (1+t)/(10+t)."""
