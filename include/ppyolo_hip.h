@@ -158,6 +158,17 @@ int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f16x2, const 
                            const float *residual, int res_ld, float *y, int y_ld, float *pooled, int pooled_ld, int N, int H,
                            int W, int C, int K, int act, int variant, const float *amax_in, float *amax_out, void *stream);
 
+/* The last stem convolution (reference model/resnet_vd.py:110 conv1_3: 3x3, stride 1, pad 1, C = 32 -> K = 64, BatchNorm affine, ReLU)
+ * AND the MaxPool2d(kernel_size=3, stride=2, padding=1) that follows it (model/resnet_vd.py:103, 136) in one launch: only the pooled
+ * tensor [N][(H-1)/2+1][(W-1)/2+1][pooled_ld] is written; bit-identical to ppy_conv2d_bn_act_f32 on the patch kernel followed by
+ * ppy_maxpool3x3s2_f32 (same products in the same order per pixel, exact maxima; padding positions never win, as with -inf padding).
+ * f16x2 operands (w_f16x2 / scale_f16x2 from ppy_conv2d_split_weights_f16x2, amax_in the tracked maxima of x); amax_out (or NULL)
+ * records max|.| of the pooled tensor per image (= that of the unpooled one: every pixel lies in a window).
+ * PPY_ERR_BAD_ARG for any other geometry (C != 32, K != 64): there is no silent fall-back. */
+int ppy_conv3x3_maxpool_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *shift,
+                            float *pooled, int pooled_ld, int N, int H, int W, int C, int K, int act, const float *amax_in,
+                            float *amax_out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Backward of the convolution -- training step, SURVEY 8f rank 2 / BASELINE config 5: what torch autograd computes for
  * the F.conv2d inside Conv2dUnit.forward (reference model/custom_layers.py:243-253) when train.py:441 calls

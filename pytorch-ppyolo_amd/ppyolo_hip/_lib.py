@@ -41,6 +41,7 @@ _PROTOS = {
     'ppy_bn_train_stats_merge_f32': (c_int, [c_void_p, c_size_t, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ppy_conv1x1_expand_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]
                                + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
+    'ppy_conv3x3_maxpool_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p]),
     'ppy_conv2d_num_configs': (c_int, []),
     'ppy_conv2d_stream_first_config': (c_int, []),
     'ppy_conv2d_patch_first_config': (c_int, []),

@@ -726,6 +726,28 @@ extern "C" int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f1
 }
 
 
+extern "C" int ppy_conv3x3_maxpool_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *shift,
+                                       float *pooled, int pooled_ld, int N, int H, int W, int C, int K, int act, const float *amax_in,
+                                       float *amax_out, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && w_f16x2 && scale_f16x2 && shift && pooled && amax_in);
+    Geometry g;
+    if (!conv_geometry(N, H, W, C, K, 3, 3, 1, 1, &g)) return PPY_ERR_BAD_ARG;
+    PPY_CHECK_ARG(x_ld >= C && pooled_ld >= K);
+    PPY_CHECK_ARG(act == PPY_ACT_NONE || act == PPY_ACT_RELU || act == PPY_ACT_LEAKY);
+    ConvArgs p;
+    p.x = x; p.w = nullptr; p.w3 = nullptr; p.wf16 = (const unsigned short *)w_f16x2;
+    p.scale_f16 = scale_f16x2; p.posb_f16 = nullptr; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale_f16x2; p.shift = shift;
+    p.res = nullptr; p.posb = nullptr; p.y = pooled; p.part = nullptr;
+    p.x_ld = x_ld; p.res_ld = 0; p.y_ld = pooled_ld;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = H; p.Wo = W; p.K = K; p.R = 3; p.S = 3;
+    p.stride = 1; p.pad = 1; p.act = act; p.ups = 0;
+    p.M = g.M; p.Kred = 9 * C; p.cchunks = C / BK; p.chunks_total = g.chunks; p.chunks_per_split = g.chunks;
+    p.nstages = 2;
+    p.trace = nullptr;
+    return ppy_patch_maxpool_dispatch(p, (H - 1) / 2 + 1, (W - 1) / 2 + 1, (hipStream_t)stream);
+}
+
 // Training-mode forward of Conv2dUnit's convolution (reference model/custom_layers.py:243-253: conv (+ bias) in front of a
 // BatchNorm2d on batch statistics): y = conv(x, w) + bias on an f16x2 kernel (cfg: any f16x2 id -- tiles, streaming 1x1, stem
 // patch, specialised waves; one split), AND the first pass of the BatchNorm from the same epilogue -- (n, mean, M2) of every channel per wave row-tile in

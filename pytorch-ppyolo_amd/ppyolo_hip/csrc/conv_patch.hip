@@ -14,6 +14,14 @@
 //   * wave w owns output row w of the tile (32 consecutive pixels = one MFMA row tile, K / 32 column tiles): 54 MFMAs per
 //     column tile with two 16-byte LDS reads per operand pair, then the vector epilogue of conv_shared.h's layout (rows of
 //     4 KB / 8 KB contiguous output per wave).
+//
+// MPOOL (round 4): the last stem layer with the MaxPool2d(3, 2, 1) behind it (reference model/resnet_vd.py:103, 136) in ONE launch:
+// the full-resolution tensor (189 MB at 8 x 304 x 304 x 64) is never written or read back.  A tile then is the window of 3 x 15
+// POOLED pixels: conv rows 6 by - 1 .. 6 by + 5 (waves 0..6; wave 7 only stages) and columns 30 bx - 1 .. 30 bx + 30 -- neighbouring
+// tiles recompute one row / two columns (1.24 x the MFMA work).  Every wave finishes its row as before (scale, shift, activation),
+// pools it along x through its transposition patch, leaves the 15 x K result in the (now idle) operand planes, and after one
+// barrier the workgroup takes the maximum over the three rows of each pooled row and stores 3 x 15 x K values.  Same products in the
+// same order per pixel and max() is exact: bit-identical to the two launches.
 #include "conv_shared.h"
 #pragma clang fp contract(off)
 
@@ -29,13 +37,18 @@ constexpr int PT_TH = 8, PT_TW = 32, PT_PW = PT_TW + 2, PT_NPIX = (PT_TH + 2) * 
 constexpr int PT_PLANE = PT_NPIX * 64;                                                       // one fp16 plane of the patch: 64 B per pixel
 constexpr int PT_UNITS = PT_NPIX * 8, PT_NST = (PT_UNITS + 511) / 512;                        // 16-byte staging loads, per thread
 
+constexpr int PM_ROWS = 3, PM_COLS = 15;      // MPOOL: pooled pixels per tile
+
 struct PatchArgs {
     ConvArgs c;
     int tiles_x, tiles_y, ntiles;
+    int Hp, Wp;       // MPOOL: pooled map (c.y / c.y_ld then describe the POOLED tensor [N][Hp][Wp][y_ld])
 };
 
-template <int TN, bool BNS = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
+template <int TN, bool BNS = false, bool MPOOL = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
 __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q) {
+    static_assert(!(BNS && MPOOL), "statistics of a tensor that is not stored");
+    static_assert(PT_TH * PM_COLS * 32 * TN * 4 <= 2 * PT_PLANE, "the x-pooled rows fit the operand planes");
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
     constexpr int K = 32 * TN, WBYTES = 9 * 2 * K * 64;
@@ -85,8 +98,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
     auto tile_of = [&](int t, int &n, int &y0, int &x0) {
         n = t / tiles_img;
         const int r = t - n * tiles_img, by = r / q.tiles_x;
-        y0 = by * PT_TH;
-        x0 = (r - by * q.tiles_x) * PT_TW;
+        y0 = MPOOL ? 2 * PM_ROWS * by - 1 : by * PT_TH;
+        x0 = MPOOL ? 2 * PM_COLS * (r - by * q.tiles_x) - 1 : (r - by * q.tiles_x) * PT_TW;
     };
     auto request = [&](int t, uintx4 (&stg)[PT_NST]) {
         int n, y0, x0;
@@ -166,7 +179,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const int tx = lane & 31, kh = lane >> 5;
-        if (live && PPY_PATCH_ABL != 1) {
+        if (live && PPY_PATCH_ABL != 1 && (!MPOOL || wave < 2 * PM_ROWS + 1)) {
             // 18 steps (tap, 16-deep half), software-pipelined by hand: the LDS reads of step g+1 are issued in front of the
             // MFMAs of step g and the order is fenced -- left alone, hipcc puts every step's reads directly in front of its
             // MFMAs behind an lgkmcnt(0), and the (dependent: one accumulator per column tile) MFMAs wait out the LDS latency
@@ -214,7 +227,75 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
         if (!live || PPY_PATCH_ABL == 3) return;
 
         const int y = y0 + wave;
-        const bool row_ok = y < p.H;
+        const bool row_ok = (unsigned)y < (unsigned)p.H;
+        if constexpr (MPOOL) {
+            float *xp = reinterpret_cast<float *>(smem_pt);            // [wave][pooled column][K]: the operand planes are idle now
+            constexpr int K4 = K / 4;
+            if (wave < 2 * PM_ROWS + 1) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        sE[row * LDS_LD + (lane & 31)] = acc[j][e];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // finished values back into the patch; positions outside the image never win a maximum (MaxPool2d pads with -inf)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        floatx4 v = *reinterpret_cast<const floatx4 *>(sE + (erow + 8 * u) * LDS_LD + ec4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float o = fmaf(v[c] * inv_sa, sc[j][c], sh[j][c]);
+                            v[c] = o > 0.f ? o : o * slope + 0.0f;
+                        }
+                        const bool ok = row_ok && (unsigned)(x0 + erow + 8 * u) < (unsigned)p.W;
+                        const float rmx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        run_mx = fmaxf(run_mx, ok ? rmx : 0.f);
+                        if (!ok) v = floatx4{-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+                        *reinterpret_cast<floatx4 *>(sE + (erow + 8 * u) * LDS_LD + ec4) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int jx = erow + 8 * h;              // pooled column: tile columns 2 jx .. 2 jx + 2
+                        if (jx < PM_COLS) {
+                            const floatx4 a = *reinterpret_cast<const floatx4 *>(sE + (2 * jx) * LDS_LD + ec4);
+                            const floatx4 b = *reinterpret_cast<const floatx4 *>(sE + (2 * jx + 1) * LDS_LD + ec4);
+                            const floatx4 c = *reinterpret_cast<const floatx4 *>(sE + (2 * jx + 2) * LDS_LD + ec4);
+                            floatx4 m;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+                            *reinterpret_cast<floatx4 *>(xp + (wave * PM_COLS + jx) * K + j * 32 + ec4) = m;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int by = (y0 + 1) / (2 * PM_ROWS), bx = (x0 + 1) / (2 * PM_COLS);
+#pragma unroll
+            for (int it = 0; it < (PM_ROWS * PM_COLS * K4 + 511) / 512; ++it) {
+                const int i = tid + 512 * it;
+                const int r = i / (PM_COLS * K4), rem = i - r * (PM_COLS * K4);
+                const int jx = rem / K4, c4 = rem - jx * K4;
+                const int py = PM_ROWS * by + r, px = PM_COLS * bx + jx;
+                const bool ok = i < PM_ROWS * PM_COLS * K4 && py < q.Hp && px < q.Wp;
+                const int rr = ok ? r : 0, jj = ok ? jx : 0;
+                const floatx4 a = *reinterpret_cast<const floatx4 *>(xp + ((2 * rr) * PM_COLS + jj) * K + c4 * 4);
+                const floatx4 b = *reinterpret_cast<const floatx4 *>(xp + ((2 * rr + 1) * PM_COLS + jj) * K + c4 * 4);
+                const floatx4 c = *reinterpret_cast<const floatx4 *>(xp + ((2 * rr + 2) * PM_COLS + jj) * K + c4 * 4);
+                floatx4 m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+                const unsigned off = ok ? (unsigned)((n * q.Hp + py) * q.Wp + px) * (unsigned)(p.y_ld * 4) + (unsigned)c4 * 16u : PT_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, m), ry, (int)off, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // nobody rewrites the planes (next tile) before everybody has read the pooled rows
+            return;
+        }
         if constexpr (BNS) {      // training forward: the BatchNorm's first pass from here (conv_shared.h), one slice per (tile, output row)
             const int nv = row_ok ? min(max(p.W - x0, 0), 32) : 0;
             const float inv_f[1] = {inv_sa};
@@ -254,12 +335,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
 #endif
 }
 
-template <int TN, bool BNS = false>
+template <int TN, bool BNS = false, bool MPOOL = false>
 int launch_patch(const PatchArgs &q, hipStream_t stream) {
-    if constexpr (!BNS) {
+    if constexpr (!BNS && !MPOOL) {
         if (q.c.bn_part) return launch_patch<TN, true>(q, stream);
     }
-    auto k = conv3x3_patch_kernel<TN, BNS>;
+    auto k = conv3x3_patch_kernel<TN, BNS, MPOOL>;
     const size_t lds = (size_t)2 * PT_PLANE + (size_t)9 * 2 * 32 * TN * 64 + (size_t)8 * 32 * LDS_LD * sizeof(float);
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), (int)lds) != PPY_OK) return PPY_ERR_LAUNCH;
@@ -289,8 +370,29 @@ int ppy_patch_dispatch(const ConvArgs &p, int local, hipStream_t stream) {
     PatchArgs q;
     q.c = p;
     q.c.scale = p.scale_f16;
+    q.Hp = q.Wp = 0;
     q.tiles_x = ceil_div(p.W, PT_TW);
     q.tiles_y = ceil_div(p.H, PT_TH);
     q.ntiles = p.N * q.tiles_x * q.tiles_y;
     return p.K == 32 ? launch_patch<1>(q, stream) : launch_patch<2>(q, stream);
+}
+
+// conv3x3 (C = 32 -> K = 64, stride 1, pad 1) + affine + activation + MaxPool2d(3, 2, 1) in one launch (MPOOL above)
+int ppy_patch_maxpool_dispatch(const ConvArgs &p, int Hp, int Wp, hipStream_t stream) {
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.C != 32 || p.K != 64 || p.ups || p.posb || p.res || p.bn_part || p.xscale || p.yscale)
+        return PPY_ERR_BAD_ARG;
+    if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in) return PPY_ERR_BAD_ARG;
+    if (((uintptr_t)p.x & 15) != 0 || p.x_ld % 4 != 0 || ((uintptr_t)p.y & 15) != 0 || p.y_ld % 4 != 0) return PPY_ERR_BAD_ARG;
+    if (Hp != (p.H - 1) / 2 + 1 || Wp != (p.W - 1) / 2 + 1) return PPY_ERR_BAD_ARG;
+    const long long lim = 0x7FFFF000LL;
+    if ((long long)p.M * p.x_ld * 4 >= lim || (long long)p.N * Hp * Wp * p.y_ld * 4 >= lim) return PPY_ERR_UNSUPPORTED;
+    PatchArgs q;
+    q.c = p;
+    q.c.scale = p.scale_f16;
+    q.Hp = Hp;
+    q.Wp = Wp;
+    q.tiles_x = ceil_div(Wp, PM_COLS);
+    q.tiles_y = ceil_div(Hp, PM_ROWS);
+    q.ntiles = p.N * q.tiles_x * q.tiles_y;
+    return launch_patch<2, false, true>(q, stream);
 }

@@ -67,6 +67,7 @@ int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_
 // conv_patch.hip: 3x3 / stride 1 / pad 1 with C = 32 (the stem layers), input patch staged once per output tile (f16x2 operands)
 int ppy_patch_num_configs();
 int ppy_patch_dispatch(const ConvArgs &p, int local_cfg, hipStream_t stream);
+int ppy_patch_maxpool_dispatch(const ConvArgs &p, int Hp, int Wp, hipStream_t stream);      // + MaxPool2d(3, 2, 1) from the epilogue; p.y = the pooled tensor
 // conv_ws.hip: the f16x2 tiles with specialised waves (four deliver operands, four multiply)
 int ppy_ws_num_configs();
 int ppy_ws_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);

@@ -296,6 +296,34 @@ def link_pools(ops, op_io, has_f16, two_streams=False):
     return n
 
 
+def link_maxpools(ops, op_io, pinned, has_f16):
+    """Host logic of HipExecutor._link_maxpools, device-free (tests/test_plan_host_logic.py): a 'maxpool' op (MaxPool2d(3, 2, 1), the
+    stem's) whose input is the WHOLE buffer written by one convolution that ppy_conv3x3_maxpool_f32 accepts (3x3 / stride 1 / pad 1,
+    C = 32 -> K = 64, no shortcut / upsampling / position bias; has_f16(op): f16x2 operands at hand) and read by nothing else:
+    conv['mpool'] = the pooled slice, maxpool['owner'] = the convolution, whose launch then writes ONLY the pooled tensor.
+    Returns the number of links."""
+    n = 0
+    for i, op in enumerate(ops):
+        if op['op'] != 'maxpool':
+            continue
+        x = op['x']
+        prods = [o for o in ops if x.buf in op_io(o)[1]]
+        readers = [o for o in ops if o is not op and x.buf in op_io(o)[0]]
+        if len(prods) != 1 or prods[0]['op'] != 'conv' or readers or x.buf in pinned:
+            continue
+        c = prods[0]
+        Kout, R, S, C = c['w'].shape
+        y = c['y']
+        if (R, S, c['stride'], c['pad'], C, Kout) != (3, 3, 1, 1, 32, 64) or c['ups'] or c['posb'] is not None or c['res'] is not None \
+                or c.get('pool') is not None or not has_f16(c) or c.get('stream', 0) != op.get('stream', 0) \
+                or (y.buf, y.coff, y.C) != (x.buf, x.coff, x.C) or x.coff != 0:
+            continue
+        c['mpool'] = op['y']
+        op['owner'] = c
+        n += 1
+    return n
+
+
 def split_pairs(ops, op_io, buffers, pinned, has_f16, only_3x3=False):
     """Host logic of HipExecutor._link_splits, device-free (tests/test_plan_host_logic.py): [(producer, [consumers])] between which
     a tensor may travel PRE-SPLIT, whatever tiles they run on -- a buffer written by ONE convolution (the whole
@@ -395,6 +423,7 @@ class HipExecutor(object):
         self._assign_amax()
         self._want_streams = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' if multi_stream is None else bool(multi_stream)
         self._link_pools()
+        self._link_maxpools()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
         self._mark_split_candidates()
@@ -462,6 +491,15 @@ class HipExecutor(object):
             return
         link_pools(self.plan.ops, self._op_io, lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None,
                    self._want_streams)
+
+    def _link_maxpools(self):
+        """The stem's MaxPool2d(3, 2, 1) (reference model/resnet_vd.py:103, 136) belongs to the launch of the convolution in front of
+        it (csrc/conv_patch.hip, MPOOL): the 304 x 304 x 64 tensor between them is neither written nor read.
+        PPYOLO_HIP_MAXPOOL_FOLD=0: two launches."""
+        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_MAXPOOL_FOLD', '1') != '1':
+            return
+        pinned = {a.buf for a in list(self.plan.head_outs) + list(self.plan.feats)}
+        link_maxpools(self.plan.ops, self._op_io, pinned, lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None)
 
     def _split_capable(self, cfg, consumer):
         """Tile configurations that read (consumer) / write pre-split tensors: the f16x2 tiles of csrc/conv_x3.hip without slab
@@ -578,10 +616,12 @@ class HipExecutor(object):
         t = op['op']
         if t == 'conv':
             ins = [op['x'].buf] + ([op['res'].buf] if op['res'] is not None else [])
+            if op.get('mpool') is not None:          # only the pooled tensor is written (_link_maxpools)
+                return ins, [op['mpool'].buf]
             return ins, [op['y'].buf] + ([op['pool'].buf] if op.get('pool') is not None else [])
         if t == 'stem':
             return [], [op['y'].buf]
-        if t == 'avgpool' and op.get('owner') is not None:      # written by its producer's launch (_link_pools)
+        if t in ('avgpool', 'maxpool') and op.get('owner') is not None:      # written by its producer's launch (_link_pools / _link_maxpools)
             return [], []
         if t in ('maxpool', 'avgpool'):
             return [op['x'].buf], [op['y'].buf]
@@ -626,6 +666,9 @@ class HipExecutor(object):
             K.conv1x1_expand(self.view(op['x']), op['wf16'], op['shift'], self.view(op['y']), op['act'],
                              None if op['res'] is None else self.view(op['res']), self.view(op['pool']),
                              op['cfg'] - self._stream_first(), self._amax(op.get('amax_in_id')), self._amax(op.get('amax_out_id')))
+        elif t == 'conv' and op.get('mpool') is not None:
+            K.conv3x3_maxpool(self.view(op['x']), op['wf16'], op['shift'], self.view(op['mpool']), op['act'],
+                              self._amax(op.get('amax_in_id')), self._amax(op.get('amax_out_id')))
         elif t == 'conv':
             posb = op['posb']
             K.conv2d_bn_act(self.view(op['x']), op['w'], op['scale'], op['shift'], self.view(op['y']), op['stride'],
@@ -641,7 +684,8 @@ class HipExecutor(object):
                         self._amax(op.get('amax_out_id')),
                         mfma=self.math != 'fp32' and op['w'].shape[0] == 32 and os.environ.get('PPYOLO_HIP_STEM_MFMA', '1') == '1')
         elif t == 'maxpool':
-            K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
+            if op.get('owner') is None:          # (else: written by the producer's launch, _link_maxpools)
+                K.maxpool3x3s2(self.view(op['x']), self.view(op['y']))
         elif t == 'avgpool':
             if op.get('owner') is None:          # (else: written by the producer's launch, _link_pools)
                 K.avgpool2x2(self.view(op['x']), self.view(op['y']))
@@ -747,8 +791,8 @@ class HipExecutor(object):
             if self.ws.numel() * 4 < big:
                 self.ws = torch.empty(((big + 3) // 4,), dtype=torch.float32, device=self.device)
             for op in self.plan.ops:
-                if op['op'] not in kinds or (match and not all(m in tune_key(op) for m in match)):
-                    continue
+                if op['op'] not in kinds or (match and not all(m in tune_key(op) for m in match)) or op.get('mpool') is not None:
+                    continue          # (a convolution that owns the stem's max pool has one kernel: nothing to choose)
                 Kout = op['w'].shape[0]
                 Kred = op['w'].shape[1] * op['w'].shape[2] * op['w'].shape[3]
                 chunks = Kred // 32

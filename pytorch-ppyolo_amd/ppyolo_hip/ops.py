@@ -179,6 +179,16 @@ def conv1x1_expand(x, w_f16, shift, y, act=None, residual=None, pooled=None, var
     check(rc, 'ppy_conv1x1_expand_f32')
 
 
+def conv3x3_maxpool(x, w_f16, shift, pooled, act=None, amax_in=None, amax_out=None):
+    """The last stem convolution (3x3 / stride 1 / pad 1, C = 32 -> K = 64, f16x2 operands) and the MaxPool2d(3, 2, 1) behind it in
+    one launch: `pooled` (a View of [N, (H-1)//2+1, (W-1)//2+1, 64]) is all that is written.  See ppy_conv3x3_maxpool_f32."""
+    _dev(x.t, w_f16[0], w_f16[1], shift, pooled.t)
+    assert (pooled.N, pooled.H, pooled.W) == (x.N, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1)
+    rc = lib().ppy_conv3x3_maxpool_f32(x.ptr, x.ld, w_f16[0].data_ptr(), w_f16[1].data_ptr(), shift.data_ptr(), pooled.ptr, pooled.ld,
+                                       x.N, x.H, x.W, x.C, pooled.C, ACT[act], _p(amax_in), _p(amax_out), _stream())
+    check(rc, 'ppy_conv3x3_maxpool_f32')
+
+
 def conv2d_train_fwd(x, w_krsc, w_f16, bias, y, stride, pad, cfg, amax_in, partials):
     """Training-mode convolution + the first pass of its BatchNorm from the epilogue: y = conv(x, w) + bias on the f16x2 tile `cfg`
     (conv_x3.hip / conv_ws.hip ids), (n, mean, M2) triples into `partials` (a float32 tensor of at least

@@ -657,6 +657,26 @@ def test_shortcut_fold_same_detections(monkeypatch):
         assert (a - b).abs().max() <= 5e-5 * max(1.0, float(a.abs().max()))
 
 
+def test_maxpool_fold_same_bits(monkeypatch):
+    """Round 4 (engine._link_maxpools): the stem's max pool written by the epilogue of the convolution in front of it against the plan
+    with the pooling launch: one launch fewer, and EVERYTHING downstream equal bit for bit (same products in the same order per
+    pixel, exact maxima, the same tracked maximum) -- both model families."""
+    x, ims = synth.synth_images(2, 320).cuda(), synth.synth_im_size(2).cuda()
+    for cfgc in (PPYOLO_2x_Config, PPYOLO_r18vd_Config):
+        got = {}
+        for fold in ('0', '1'):
+            monkeypatch.setenv('PPYOLO_HIP_MAXPOOL_FOLD', fold)
+            model, _ = build_model(cfgc(), 0, 'cuda')
+            dets, cnt, keep = model.forward_padded(x, ims)
+            torch.cuda.synchronize()
+            ex = model._plans.executor(x)
+            got[fold] = (dets.clone(), cnt.clone(), keep.clone(), [ex.view(a).dense().clone() for a in ex.plan.head_outs],
+                         sum(1 for o in ex.plan.ops if o['op'] == 'maxpool' and o.get('owner') is None))
+        assert (got['0'][4], got['1'][4]) == (1, 0)
+        for a, b in zip(got['0'][:3] + tuple(got['0'][3]), got['1'][:3] + tuple(got['1'][3])):
+            assert torch.equal(a, b)
+
+
 def test_presplit_scales_leave_headroom_on_the_full_size_plan():
     """The pre-split links take their per-image scale from a STATIC bound of |y| (engine._link_splits): however pessimistic the
     bound is for the data at hand, that many of the 14 bits above the fp16 terms' floor are given away.  On the R50vd-608 plan

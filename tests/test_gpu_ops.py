@@ -1134,6 +1134,55 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
             assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
 
 
+def test_stem_conv_with_maxpool_from_the_epilogue_is_the_two_launches():
+    """ppy_conv3x3_maxpool_f32 (csrc/conv_patch.hip, MPOOL): conv1_3 of the stem (reference model/resnet_vd.py:110) + MaxPool2d(3, 2, 1)
+    (:103, :136) in one launch against the patch kernel followed by ppy_maxpool3x3s2_f32: EQUAL outputs and equal tracked maxima -- odd
+    and even sizes, maps smaller than a tile, sizes that are not multiples of the 3 x 15 pooled tile, images of very different magnitude,
+    an all-zero image, ReLU / LeakyReLU / no activation (negative values: padding must behave as -inf, not 0), and the pooled
+    tensor as a channel slice of a wider buffer (the first block's folded-shortcut input)."""
+    from ppyolo_hip import ops
+    from ppyolo_hip._lib import PPYoloHipError
+    g = torch.Generator().manual_seed(3103)
+    for N, H, W, act, wide in ((2, 38, 50, 'relu', False), (1, 7, 9, None, False), (3, 64, 64, 'leaky', True), (1, 1, 1, None, False),
+                               (2, 13, 31, 'relu', True), (2, 30, 90, None, False), (1, 2, 2, 'leaky', False), (2, 97, 45, 'relu', False)):
+        x = torch.randn(N, 32, H, W, generator=g) * torch.exp(2.0 * torch.randn(N, 1, 1, 1, generator=g))
+        if N > 2:
+            x[1] = 0
+        w = torch.randn(64, 32, 3, 3, generator=g) * (1.0 / 288 ** 0.5)
+        sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda()
+        wk, xd = w.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc)
+        Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        # two launches
+        y = torch.empty(N, H, W, 64).cuda()
+        am0 = ops.amax_slots(N=N, device=y.device)
+        ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y), 1, 1, act, cfg=ops.patch_first_cfg(), splitk=1, w_f16=wf,
+                          amax_in=ops.amax_slots(xd), amax_out=am0)
+        p0 = torch.empty(N, Hp, Wp, 64).cuda()
+        ops.maxpool3x3s2(ops.View(y), ops.View(p0))
+        # one
+        buf = torch.full((N, Hp, Wp, 128 if wide else 64), 7.0).cuda()
+        pv = ops.View(buf, 64, 64) if wide else ops.View(buf)
+        am1 = ops.amax_slots(N=N, device=y.device)
+        ops.conv3x3_maxpool(ops.View(xd), wf, sh, pv, act, amax_in=ops.amax_slots(xd), amax_out=am1)
+        torch.cuda.synchronize()
+        what = 'N%d %dx%d %s' % (N, H, W, act)
+        got = buf[..., 64:] if wide else buf
+        assert torch.equal(got, p0), '%s: %d values differ' % (what, int((got != p0).sum()))
+        if wide:
+            assert bool((buf[..., :64] == 7.0).all()), what + ': wrote outside its channel slice'
+        assert torch.equal(am0.view(N, -1).max(dim=1).values, am1.view(N, -1).max(dim=1).values), what + ': tracked maxima'
+        ref = F.max_pool2d(nchw(y), 3, 2, 1)
+        assert torch.equal(nchw(p0), ref), what + ': the pooling launch itself'
+    # any other geometry is refused
+    x = torch.randn(1, 8, 8, 64).cuda()
+    wk = torch.randn(64, 3, 3, 64).cuda()
+    one = torch.ones(64).cuda()
+    with pytest.raises(PPYoloHipError):
+        ops.conv3x3_maxpool(ops.View(x), ops.split_weights_f16x2(wk, one), one, ops.View(torch.empty(1, 4, 4, 64).cuda()), 'relu',
+                            amax_in=ops.amax_slots(x))
+
+
 # ------------------------------------------------------------------------------------------
 # "global pre-split": a producer convolution stores its output as its one consumer's finished MFMA operands
 def test_presplit_pair_matches_fp64_as_well_as_the_plain_pair():

@@ -105,6 +105,26 @@ def test_pool_links_of_the_r50_plan():
         assert torch.equal(a, b)
 
 
+def test_maxpool_link_of_the_stem():
+    """engine.link_maxpools (device-free part of HipExecutor._link_maxpools): the stem's MaxPool2d(3, 2, 1) goes to the convolution in
+    front of it (conv1_3: 3x3, C32 -> K64), whose launch then writes only the pooled tensor -- in the R50vd plan into the channel slice
+    of the first block's wide buffer; nothing is linked without f16x2 operands, and nothing when somebody else reads the tensor."""
+    from ppyolo_hip.engine import HipExecutor, link_maxpools
+    for cfgc in (PPYOLO_2x_Config, PPYOLO_r18vd_Config):
+        model, _ = build_model(cfgc())
+        plan = build_plan(model, 2, 160, 160, 'cpu')
+        assert link_maxpools(plan.ops, HipExecutor._op_io, set(), lambda c: False) == 0
+        mp = [o for o in plan.ops if o['op'] == 'maxpool']
+        assert len(mp) == 1
+        assert link_maxpools(plan.ops, HipExecutor._op_io, {mp[0]['x'].buf}, lambda c: True) == 0          # (a pinned tensor must exist)
+        assert link_maxpools(plan.ops, HipExecutor._op_io, set(), lambda c: True) == 1
+        c = mp[0]['owner']
+        assert tuple(c['w'].shape) == (64, 3, 3, 32) and c['mpool'] is mp[0]['y'] and c['act'] == 'relu'
+        assert HipExecutor._op_io(mp[0]) == ([], [])
+        assert HipExecutor._op_io(c) == ([c['x'].buf], [mp[0]['y'].buf])          # the full-resolution buffer is not written any more
+        del c['mpool'], mp[0]['owner']
+
+
 def test_split_pairs_of_the_r50_plan():
     """engine.split_pairs (device-free part of HipExecutor._link_splits): which tensors of the R50vd plan may travel pre-split.
     Every bottleneck's conv1 -> conv2 except where the DCNv2 reads conv1's output too (stage 5) -- 13 pairs; conv2 -> conv3
