@@ -158,6 +158,23 @@ int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f16x2, const 
                            const float *residual, int res_ld, float *y, int y_ld, float *pooled, int pooled_ld, int N, int H,
                            int W, int C, int K, int act, int variant, const float *amax_in, float *amax_out, void *stream);
 
+/* Training forward of a FROZEN 1x1 Conv2dUnit (reference model/custom_layers.py:243-253 with its BatchNorm2d on batch statistics;
+ * train.py:259-262 freezes the backbone) on the streaming kernel of ppy_conv1x1_expand_f32 WITHOUT the raw convolution output in memory:
+ *   ppy_conv1x1_stats_f32: the first pass of the BatchNorm only -- (n, mean, M2) partials [*bn_slices][K][3] exactly as
+ *     ppy_conv2d_train_fwd_f32 writes them (merge with ppy_bn_train_stats_merge_f32); nothing else is stored.
+ *   ppy_conv1x1_bn_apply_f32: the convolution again, y = act((conv + bias - mean) * (invstd * gamma) + beta [+ residual]) from its
+ *     epilogue, amax_out (or NULL) = tracked per-image max|y| -- value for value ppy_conv2d_train_fwd_f32 + ppy_bn_train_apply_f32.
+ * Same geometry rules as ppy_conv1x1_expand_f32 (C = 64 / 128, f16x2 operands, scale_f16x2 from ppy_conv2d_split_weights_f16x2 with
+ * scale = 1); mean / invstd / gamma / beta: [K], 16-byte aligned.  Pays the layer's MFMA work twice to save a write and a read of its
+ * output: for the HBM-bound stage-2 layers (6 GFLOP for 0.4-0.8 GB) that is a third of the time. */
+int ppy_conv1x1_stats_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *bias, int N, int H,
+                          int W, int C, int K, int variant, const float *amax_in, float *bn_partials, size_t bn_partials_bytes,
+                          int *bn_slices, void *stream);
+int ppy_conv1x1_bn_apply_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *bias,
+                             const float *mean, const float *invstd, const float *gamma, const float *beta, const float *residual,
+                             int res_ld, float *y, int y_ld, int N, int H, int W, int C, int K, int act, int variant,
+                             const float *amax_in, float *amax_out, void *stream);
+
 /* The last stem convolution (reference model/resnet_vd.py:110 conv1_3: 3x3, stride 1, pad 1, C = 32 -> K = 64, BatchNorm affine, ReLU)
  * AND the MaxPool2d(kernel_size=3, stride=2, padding=1) that follows it (model/resnet_vd.py:103, 136) in one launch: only the pooled
  * tensor [N][(H-1)/2+1][(W-1)/2+1][pooled_ld] is written; bit-identical to ppy_conv2d_bn_act_f32 on the patch kernel followed by

@@ -42,6 +42,8 @@ _PROTOS = {
     'ppy_conv1x1_expand_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]
                                + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
     'ppy_conv3x3_maxpool_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 6 + [c_void_p, c_void_p, c_void_p]),
+    'ppy_conv1x1_stats_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'ppy_conv1x1_bn_apply_f32': (c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
     'ppy_conv2d_num_configs': (c_int, []),
     'ppy_conv2d_stream_first_config': (c_int, []),
     'ppy_conv2d_patch_first_config': (c_int, []),

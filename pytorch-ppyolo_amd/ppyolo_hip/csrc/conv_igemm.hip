@@ -726,6 +726,64 @@ extern "C" int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f1
 }
 
 
+// Training forward of a FROZEN 1x1 Conv2dUnit on the streaming kernel without the raw tensor (round 4; reference
+// model/custom_layers.py:243-253 with the BatchNorm2d in training mode): ppy_conv1x1_stats_f32 = the convolution's BatchNorm
+// partials only (as ppy_conv2d_train_fwd_f32 writes them, nothing else is stored); ppy_conv1x1_bn_apply_f32 = the convolution
+// again with y = act((conv + bias - mean) * (invstd * gamma) + beta [+ residual]) from its epilogue -- value for value what
+// ppy_conv2d_train_fwd_f32 + ppy_bn_train_apply_f32 give.
+static long long bn_slice_capacity(long long M);
+extern "C" size_t ppy_conv2d_bn_partials_bytes(long long M, int K);
+static int stream_args(ConvArgs &p, const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *bias, int N, int H,
+                       int W, int C, int K, const float *amax_in) {
+    Geometry g;
+    if (!conv_geometry(N, H, W, C, K, 1, 1, 1, 0, &g)) return PPY_ERR_BAD_ARG;
+    if (x_ld < C) return PPY_ERR_BAD_ARG;
+    p.x = x; p.w = nullptr; p.w3 = nullptr; p.wf16 = (const unsigned short *)w_f16x2;
+    p.scale_f16 = scale_f16x2; p.posb_f16 = nullptr; p.amax_in = amax_in; p.amax_out = nullptr; p.scale = scale_f16x2; p.shift = bias;
+    p.res = nullptr; p.posb = nullptr; p.y = nullptr; p.part = nullptr;
+    p.x_ld = x_ld; p.res_ld = 0; p.y_ld = K;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = H; p.Wo = W; p.K = K; p.R = 1; p.S = 1;
+    p.stride = 1; p.pad = 0; p.act = PPY_ACT_NONE; p.ups = 0;
+    p.M = g.M; p.Kred = C; p.cchunks = C / BK; p.chunks_total = g.chunks; p.chunks_per_split = g.chunks;
+    p.nstages = 2;
+    p.trace = nullptr;
+    return PPY_OK;
+}
+
+extern "C" int ppy_conv1x1_stats_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *bias, int N, int H,
+                                     int W, int C, int K, int variant, const float *amax_in, float *bn_partials, size_t bn_partials_bytes,
+                                     int *bn_slices, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && w_f16x2 && scale_f16x2 && bias && amax_in && bn_partials && bn_slices);
+    ConvArgs p;
+    const int rc = stream_args(p, x, x_ld, w_f16x2, scale_f16x2, bias, N, H, W, C, K, amax_in);
+    if (rc != PPY_OK) return rc;
+    if (bn_partials_bytes < ppy_conv2d_bn_partials_bytes(p.M, K)) return PPY_ERR_WORKSPACE;
+    p.y = const_cast<float *>(x);           // (never written: bn_nostore; the vector-epilogue alignment checks want a pointer)
+    p.bn_part = bn_partials;
+    p.bn_slices_host = bn_slices;
+    p.bn_capacity = (int)bn_slice_capacity(p.M);
+    p.bn_nostore = 1;
+    *bn_slices = 0;
+    return ppy_stream_dispatch(p, variant, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int ppy_conv1x1_bn_apply_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *bias,
+                                        const float *mean, const float *invstd, const float *gamma, const float *beta, const float *residual,
+                                        int res_ld, float *y, int y_ld, int N, int H, int W, int C, int K, int act, int variant,
+                                        const float *amax_in, float *amax_out, void *stream) {
+    ppy_drop_stale_error();
+    PPY_CHECK_ARG(x && w_f16x2 && scale_f16x2 && bias && mean && invstd && gamma && beta && y && amax_in);
+    PPY_CHECK_ARG(act == PPY_ACT_NONE || act == PPY_ACT_RELU || act == PPY_ACT_LEAKY);
+    ConvArgs p;
+    const int rc = stream_args(p, x, x_ld, w_f16x2, scale_f16x2, bias, N, H, W, C, K, amax_in);
+    if (rc != PPY_OK) return rc;
+    PPY_CHECK_ARG(y_ld >= K && (!residual || res_ld >= K));
+    p.y = y; p.y_ld = y_ld; p.res = residual; p.res_ld = res_ld; p.act = act; p.amax_out = amax_out;
+    p.bn_mean = mean; p.bn_invstd = invstd; p.bn_gamma = gamma; p.bn_beta = beta;
+    return ppy_stream_dispatch(p, variant, nullptr, 0, (hipStream_t)stream);
+}
+
 extern "C" int ppy_conv3x3_maxpool_f32(const float *x, int x_ld, const void *w_f16x2, const float *scale_f16x2, const float *shift,
                                        float *pooled, int pooled_ld, int N, int H, int W, int C, int K, int act, const float *amax_in,
                                        float *amax_out, void *stream) {

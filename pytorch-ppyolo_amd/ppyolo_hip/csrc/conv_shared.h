@@ -27,6 +27,12 @@ struct ConvArgs {
     float *bn_part = nullptr;
     int *bn_slices_host = nullptr;
     int bn_capacity = 0;         // slices bn_part has room for (a launcher that needs more returns PPY_ERR_WORKSPACE)
+    // round 4, training forward of FROZEN layers on the streaming 1x1 kernel (conv_stream.hip): a first launch with bn_nostore
+    // writes the statistics only, a second one -- the batch statistics are known then -- applies the BatchNorm to its own
+    // accumulators, y = act((v - mean) * (invstd * gamma) + beta [+ res]) with v the convolution's value, the arithmetic of
+    // bn_apply_kernel (train.hip): the raw tensor is never written or read
+    int bn_nostore = 0;
+    const float *bn_mean = nullptr, *bn_invstd = nullptr, *bn_gamma = nullptr, *bn_beta = nullptr;
     // "global pre-split" (round 3; f16x2 kernels): a producer whose output has ONE consumer, a convolution on
     // these kernels, stores it as the consumer's MFMA operand -- per 32-channel group of a pixel 32 fp16 first terms then 32 fp16
     // second terms of y * s (the same 128 bytes the fp32 values would take) -- with s = a power of two per image from a STATIC

@@ -35,8 +35,11 @@ struct StreamArgs {
 // (coalesced loads one tile ahead -> ds_write -> ONE workgroup barrier per tile -> swizzled fragment reads); the K / 128
 // workgroups of a pixel stream sit on one XCD (block ids 8 apart), so the tile comes from HBM once.  (Three workgroups per CU
 // would need <= 168 VGPRs: 20-25 spilled, and scratch reloads queue behind the prefetches in the in-order vmcnt.)
-template <int KS, int TN, bool RES, bool POOL, bool ALDS, bool BNS = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
+// BNA: BatchNorm on batch statistics applied in the epilogue (ConvArgs::bn_mean ...; training forward of frozen layers).
+// NOSTORE (with BNS): statistics only, nothing is stored.
+template <int KS, int TN, bool RES, bool POOL, bool ALDS, bool BNS = false, bool BNA = false, bool NOSTORE = false>      // (BNS: BatchNorm statistics from the epilogue, conv_x3.hip)
 __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs q) {
+    static_assert(!NOSTORE || (BNS && !RES && !POOL && !BNA), "statistics-only launches");
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs &p = q.c;
     extern __shared__ __attribute__((aligned(16))) char smem_st[];
@@ -92,6 +95,21 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
     for (int j = 0; j < TN; ++j) {
         sc[j] = *reinterpret_cast<const floatx4 *>(p.scale + n0 + j * 32 + ec4);
         sh[j] = *reinterpret_cast<const floatx4 *>(p.shift + n0 + j * 32 + ec4);
+    }
+
+    floatx4 bmu[BNA ? TN : 1], bisg[BNA ? TN : 1], bbe[BNA ? TN : 1];
+    if constexpr (BNA) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = n0 + j * 32 + ec4;
+            bmu[j] = *reinterpret_cast<const floatx4 *>(p.bn_mean + c);
+            bbe[j] = *reinterpret_cast<const floatx4 *>(p.bn_beta + c);
+            const floatx4 is = *reinterpret_cast<const floatx4 *>(p.bn_invstd + c), ga = *reinterpret_cast<const floatx4 *>(p.bn_gamma + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bisg[j][k] = is[k] * ga[k];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bmu[j]), "+v"(bisg[j]), "+v"(bbe[j]));
     }
 
     // ---- requests of a tile: activations in the A-fragment layout, shortcut rows in the epilogue layout
@@ -279,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
         for (int u = 0; u < 4; ++u) rowscale[u] = (POOL ? idx0 : idx0 + 8 * u) < bnd ? inv0 : inv1;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < (NOSTORE ? 0 : TN); ++j) {
             const int col = n0 + j * 32 + ec4;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -295,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float o = fmaf(v[u][c] * rowscale[u], scj[c], shj[c]);
+                    if constexpr (BNA) o = fmaf(o - bmu[j][c], bisg[j][c], bbe[j][c]);      // (bn_apply_kernel's sub, mul, fma, add)
                     if (RES) o += __uint_as_float(rv[j][u][c]);
                     v[u][c] = o > 0.f ? o : o * slope + 0.0f;       // (+0: ReLU gives +0 for negative inputs, as max(o, 0) does)
                 }
@@ -335,10 +354,19 @@ int launch_stream_one(const StreamArgs &q, int grid, hipStream_t stream) {
 
 template <int KS, int TN, bool ALDS>
 int launch_stream(const StreamArgs &q, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)4 * 32 * LDS_LD * sizeof(float) + (ALDS ? 2 * 32 * KS * 16 * sizeof(float) : 0);
     if (q.c.bn_part) {       // (the dispatcher has checked: no pooled output, no shortcut)
-        auto k = conv1x1_stream_kernel<KS, TN, false, false, ALDS, true>;
-        const size_t lds = (size_t)4 * 32 * LDS_LD * sizeof(float) + (ALDS ? 2 * 32 * KS * 16 * sizeof(float) : 0);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream, q);
+        if (q.c.bn_nostore)
+            hipLaunchKernelGGL((conv1x1_stream_kernel<KS, TN, false, false, ALDS, true, false, true>), dim3(grid), dim3(256), lds, stream, q);
+        else
+            hipLaunchKernelGGL((conv1x1_stream_kernel<KS, TN, false, false, ALDS, true>), dim3(grid), dim3(256), lds, stream, q);
+        return ppy_launch_status();
+    }
+    if (q.c.bn_mean) {       // (the dispatcher has checked: no pooled output)
+        if (q.c.res)
+            hipLaunchKernelGGL((conv1x1_stream_kernel<KS, TN, true, false, ALDS, false, true>), dim3(grid), dim3(256), lds, stream, q);
+        else
+            hipLaunchKernelGGL((conv1x1_stream_kernel<KS, TN, false, false, ALDS, false, true>), dim3(grid), dim3(256), lds, stream, q);
         return ppy_launch_status();
     }
     if (q.pool) return q.c.res ? launch_stream_one<KS, TN, true, true, ALDS>(q, grid, stream) : launch_stream_one<KS, TN, false, true, ALDS>(q, grid, stream);
@@ -369,6 +397,11 @@ int ppy_stream_dispatch(const ConvArgs &p, int local, float *pool, int pool_ld, 
     const long long lim = 0x7FFFF000LL;
     if ((long long)p.M * p.x_ld * 4 >= lim || (long long)p.M * p.y_ld * 4 >= lim || (p.res && (long long)p.M * p.res_ld * 4 >= lim))
         return PPY_ERR_UNSUPPORTED;
+    if (p.bn_nostore && !p.bn_part) return PPY_ERR_BAD_ARG;
+    if (p.bn_mean) {         // BatchNorm applied in the epilogue: all four vectors, 16-byte aligned; not combined with the statistics pass
+        if (!p.bn_invstd || !p.bn_gamma || !p.bn_beta || p.bn_part || pool) return PPY_ERR_BAD_ARG;
+        if ((((uintptr_t)p.bn_mean | (uintptr_t)p.bn_invstd | (uintptr_t)p.bn_gamma | (uintptr_t)p.bn_beta) & 15) != 0) return PPY_ERR_BAD_ARG;
+    }
     if (p.bn_part) {         // BatchNorm statistics from the epilogue: plain conv + bias, one slice per 32-pixel tile
         if (pool || p.res || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;
         if (ceil_div(p.M, 32) > p.bn_capacity) return PPY_ERR_WORKSPACE;

@@ -203,6 +203,27 @@ def conv2d_train_fwd(x, w_krsc, w_f16, bias, y, stride, pad, cfg, amax_in, parti
     return n.value
 
 
+def conv1x1_stats(x, w_f16, bias, Kout, variant, amax_in, partials):
+    """The BatchNorm partials of a 1x1 convolution on the streaming kernel WITHOUT storing its output (frozen layers of the training
+    step).  Returns the slice count for bn_train_stats_merge.  See ppy_conv1x1_stats_f32."""
+    _dev(x.t, w_f16[0], w_f16[1], bias, partials)
+    n = ctypes.c_int(0)
+    check(lib().ppy_conv1x1_stats_f32(x.ptr, x.ld, w_f16[0].data_ptr(), w_f16[1].data_ptr(), bias.data_ptr(), x.N, x.H, x.W, x.C, Kout, variant,
+                                      amax_in.data_ptr(), partials.data_ptr(), partials.numel() * partials.element_size(), ctypes.byref(n),
+                                      _stream()), 'ppy_conv1x1_stats_f32')
+    return n.value
+
+
+def conv1x1_bn_apply(x, w_f16, bias, mean, invstd, gamma, beta, y, act=None, residual=None, variant=0, amax_in=None, amax_out=None):
+    """1x1 convolution + BatchNorm on the given batch statistics + shortcut + activation in one launch of the streaming kernel
+    (frozen layers of the training step).  See ppy_conv1x1_bn_apply_f32."""
+    _dev(x.t, w_f16[0], w_f16[1], bias, mean, invstd, gamma, beta, y.t)
+    check(lib().ppy_conv1x1_bn_apply_f32(x.ptr, x.ld, w_f16[0].data_ptr(), w_f16[1].data_ptr(), bias.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                         gamma.data_ptr(), beta.data_ptr(), None if residual is None else residual.ptr,
+                                         0 if residual is None else residual.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, y.C, ACT[act], variant,
+                                         _p(amax_in), _p(amax_out), _stream()), 'ppy_conv1x1_bn_apply_f32')
+
+
 def conv2d_bn_partials_bytes(M, K):
     return int(lib().ppy_conv2d_bn_partials_bytes(M, K))
 

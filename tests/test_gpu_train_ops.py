@@ -338,6 +338,55 @@ def test_last_workgroup_finalisation_is_bit_identical_to_the_second_launch():
     both(stats)
 
 
+def test_frozen_1x1_layers_without_the_raw_tensor():
+    """Round 4: ppy_conv1x1_stats_f32 + ppy_conv1x1_bn_apply_f32 (the streaming kernel run twice: statistics only, then the
+    BatchNorm applied to its own accumulators) against ppy_conv2d_train_fwd_f32 + ppy_bn_train_apply_f32 on the same kernel:
+    EQUAL partials, EQUAL y, equal tracked maxima -- C = 64 and C = 128, both grids, with / without shortcut, every
+    activation, rows that do not fill the last tile, images of very different magnitude, y as a channel slice."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(5200)
+    first = ops.stream_first_cfg()
+    for N, H, W, C, K, act, use_res, variant, wide in ((3, 24, 20, 64, 256, 'relu', True, 0, False), (2, 9, 7, 128, 128, None, False, 0, False),
+                                                      (2, 19, 19, 64, 64, 'leaky', False, 1, True), (4, 13, 11, 128, 512, 'relu', True, 1, False),
+                                                      (8, 38, 38, 64, 256, 'relu', True, 0, False)):
+        x = torch.randn(N, H, W, C, generator=g) * torch.exp(1.5 * torch.randn(N, 1, 1, 1, generator=g)) + 0.3
+        wk = (torch.randn(K, 1, 1, C, generator=g) * (1.0 / C ** 0.5)).cuda()
+        bias = torch.zeros(K).cuda()
+        gamma, beta = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        res = torch.randn(N, H, W, K, generator=g).cuda() if use_res else None
+        xd = x.cuda()
+        wf = ops.split_weights_f16x2(wk, torch.ones(K).cuda())
+        M = N * H * W
+        # two tensors: raw output + statistics, then the apply pass
+        raw = torch.empty(N, H, W, K).cuda()
+        part0 = torch.full((ops.conv2d_bn_partials_bytes(M, K) // 4,), float('nan')).cuda()
+        s0 = ops.conv2d_train_fwd(ops.View(xd), wk, wf, bias, ops.View(raw), 1, 0, first + variant, ops.amax_slots(xd), part0)
+        m0, i0 = torch.empty(K).cuda(), torch.empty(K).cuda()
+        ops.bn_train_stats_merge(part0.clone(), s0, 1e-5, 0.1, m0, i0)
+        y0 = torch.empty(N, H, W, K).cuda()
+        am0 = ops.amax_slots(N=N, device=y0.device)
+        ops.bn_train_apply(ops.View(raw), m0, i0, gamma, beta, ops.View(y0), act, None if res is None else ops.View(res), am0)
+        # none
+        part1 = torch.full((ops.conv2d_bn_partials_bytes(M, K) // 4,), float('nan')).cuda()
+        s1 = ops.conv1x1_stats(ops.View(xd), wf, bias, K, variant, ops.amax_slots(xd), part1)
+        assert s1 == s0 and torch.equal(part0[:s0 * K * 3], part1[:s1 * K * 3])
+        m1, i1 = torch.empty(K).cuda(), torch.empty(K).cuda()
+        ops.bn_train_stats_merge(part1, s1, 1e-5, 0.1, m1, i1)
+        assert torch.equal(m0, m1) and torch.equal(i0, i1)
+        buf = torch.full((N, H, W, 2 * K if wide else K), 5.0).cuda()
+        yv = ops.View(buf, K, K) if wide else ops.View(buf)
+        am1 = ops.amax_slots(N=N, device=y0.device)
+        ops.conv1x1_bn_apply(ops.View(xd), wf, bias, m1, i1, gamma, beta, yv, act, None if res is None else ops.View(res), variant,
+                             ops.amax_slots(xd), am1)
+        torch.cuda.synchronize()
+        what = 'N%d %dx%d C%d K%d %s res %s variant %d' % (N, H, W, C, K, act, use_res, variant)
+        got = buf[..., K:] if wide else buf
+        assert torch.equal(got, y0), '%s: %d values differ, max %.3e' % (what, int((got != y0).sum()), float((got - y0).abs().max()))
+        if wide:
+            assert bool((buf[..., :K] == 5.0).all()), what
+        assert torch.equal(am0.view(N, -1).max(dim=1).values, am1.view(N, -1).max(dim=1).values), what + ': tracked maxima'
+
+
 def test_batchnorm_statistics_from_the_convolution_epilogue():
     """ppy_conv2d_train_fwd_f32 + ppy_bn_train_stats_merge_f32 against the two-kernel form (ppy_conv2d_bn_act_f32, then
     ppy_bn_train_stats_f32 reading y back): y is EQUAL (same tile, same epilogue), mean / invstd / running statistics agree to
