@@ -745,10 +745,26 @@ class TrainStep(object):
             m = self.masks.pop(0).to(self.dev).permute(0, 2, 3, 1).contiguous()
             scale = torch.tensor([float(m.numel()) / float(m.sum())], dtype=torch.float32, device=self.dev)
         else:
-            m = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=self.dev)
-            scale = torch.empty(1, dtype=torch.float32, device=self.dev)
             self.seed += 1
-            K.dropblock_mask(m, scale, keep_prob, (self.seed_base + self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF, ws=self.ws)
+            seed = (self.seed_base + self.seed * 0x9E3779B1 + self.steps_done * 7919) & 0xFFFFFFFFFFFF
+            if self._wgrad_side:
+                # the mask depends on the seed only: drawn on the second stream, beside whatever the main stream still has queued
+                # (the host runs ahead of the device); allocated there too, so that no block the main stream has just freed --
+                # and may still be reading -- is written early
+                if self._ws_side is None:
+                    self._ws_side = torch.empty_like(self.ws)
+                main = torch.cuda.current_stream(self.dev)
+                with torch.cuda.stream(self._wstream):
+                    m = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=self.dev)
+                    scale = torch.empty(1, dtype=torch.float32, device=self.dev)
+                    K.dropblock_mask(m, scale, keep_prob, seed, ws=self._ws_side)
+                main.wait_stream(self._wstream)
+                m.record_stream(main)
+                scale.record_stream(main)
+            else:
+                m = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=self.dev)
+                scale = torch.empty(1, dtype=torch.float32, device=self.dev)
+                K.dropblock_mask(m, scale, keep_prob, seed, ws=self.ws)
         y = self.new(x.N, x.H, x.W, x.C, req=True) if coord_tag is None else self.new_coord(coord_tag, x.N, x.H, x.W, x.C, req=True)
         y.amax = None if x.amax is None else x.amax * scale     # y = x * mask * scale, mask in {0, 1}
         K.dropblock_apply(x.view(), m, scale, y.view())
