@@ -143,6 +143,12 @@ class TrainStep(object):
         self._ws_side = None
         self._wkeep = []
         self._wpending = False
+        # ... and so do the optimizer step, the EMA update and the re-split of the updated weights (sgd, _prepare_weights): the next
+        # step's frozen layers do not read a trainable parameter, so its forward starts while they run; the first use of a trainable
+        # parameter (weight() / param()) or a reader outside the step (sync_to_model, grads) waits for them (_await_params).
+        # PPYOLO_HIP_TRAIN_ASYNC_TAIL=0: in line.
+        self._async_tail = self._wgrad_side and os.environ.get('PPYOLO_HIP_TRAIN_ASYNC_TAIL', '1') == '1'
+        self._params_pending = False
         self.steps_done = 0
         self.momentum = cfg.optimizerBuilder['optimizer']['momentum']
         self.weight_decay = cfg.optimizerBuilder['regularizer']['factor']
@@ -246,6 +252,8 @@ class TrainStep(object):
         multiple of 32 input channels behind a CoordConv; trainable weights keep a MASTER copy here (updated by SGD, written
         back by sync_to_model) and get their bf16 planes re-split every step."""
         ent = self._wcache.get(key)
+        if ent is not None and ent['trainable']:
+            self._await_params()
         if ent is None:
             w = self.sd[key].detach().float()
             Kout, Cin, R, S = w.shape
@@ -314,9 +322,18 @@ class TrainStep(object):
             elif k in self.P:
                 self.P[k].copy_(src)
 
+    def _await_params(self):
+        """The current stream waits for the optimizer tail of the previous step (sgd / EMA / weight planes on the second stream)."""
+        if self._params_pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wstream)
+            self._params_pending = False
+
     def param(self, key):
         """A bias / BatchNorm scale or offset as the kernels should read it: the flat master copy once it exists."""
-        return self.P[key] if key in self.P else self.sd.get(key)
+        if key in self.P:
+            self._await_params()
+            return self.P[key]
+        return self.sd.get(key)
 
     # ---- forward ops ---------------------------------------------------------------------------------------------------
     def coord_concat(self, x):
@@ -482,7 +499,11 @@ class TrainStep(object):
         self._prep_done = True
         if self._prep is not None:
             if self._prep.current():
-                self._prep.build()
+                if self._params_pending:      # behind the optimizer step on the second stream (the planes' readers wait: weight())
+                    with torch.cuda.stream(self._wstream):
+                        self._prep.build()
+                else:
+                    self._prep.build()
             else:                       # somebody re-bound a master copy: back to the per-layer splits, rebuild the table after this step
                 for e in self._prep.entries:
                     self._wcache[e['key']]['prep'] = None
@@ -1023,12 +1044,23 @@ class TrainStep(object):
         ema.update() (train.py:443-444, model/EMA.py:29-44)."""
         first = self.steps_done == 0
         nd, n = self.n_decay, self.pflat.numel()
-        K.sgd_momentum(self.pflat[:nd], self.gflat[:nd], self.vflat[:nd], lr, self.momentum, self.weight_decay, first)
-        if n > nd:
-            K.sgd_momentum(self.pflat[nd:], self.gflat[nd:], self.vflat[nd:], lr, self.momentum, 0.0, first)
+
+        def tail():
+            K.sgd_momentum(self.pflat[:nd], self.gflat[:nd], self.vflat[:nd], lr, self.momentum, self.weight_decay, first)
+            if n > nd:
+                K.sgd_momentum(self.pflat[nd:], self.gflat[nd:], self.vflat[nd:], lr, self.momentum, 0.0, first)
+            if self.use_ema:
+                K.ema_update(self.sflat, self.pflat, self.ema_steps, self.ema_decay)
+        if self._async_tail:
+            self._await_params()
+            self._wstream.wait_stream(torch.cuda.current_stream(self.dev))      # the gradients are complete (and averaged)
+            with torch.cuda.stream(self._wstream):
+                tail()
+            self._params_pending = True
+        else:
+            tail()
         self.steps_done += 1
         if self.use_ema:
-            K.ema_update(self.sflat, self.pflat, self.ema_steps, self.ema_decay)
             self.ema_steps += 1
 
     def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None):
@@ -1062,6 +1094,7 @@ class TrainStep(object):
     def sync_to_model(self, ema=False):
         """Write the trained parameters (kept flat, in kernel layout, during training) back into the module; `ema=True` writes
         the EMA shadows instead -- what the reference evaluates and saves after ema.apply() (train.py:476-500)."""
+        self._await_params()
         src = self.sflat if ema else self.pflat
         if ema and src is None:
             raise PPYoloHipError('EMA is off (cfg.use_ema)')
