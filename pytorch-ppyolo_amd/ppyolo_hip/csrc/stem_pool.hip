@@ -185,17 +185,43 @@ __global__ void __launch_bounds__(256) stem_conv_mfma_kernel(const float *__rest
     const long long ntiles = (long long)N * tiles_y * tiles_x;
     int run_n = -1;
     float run_mx = 0.f;
+    // the 3 x NR input rows of 2 SM_TC + 1 columns of a tile: half a workgroup per row, a lane per column -- no division per element (the
+    // flat index walk this replaces spent more VALU cycles on i % 129 and i / 129 than the tile spends on its MFMAs: 50 -> 41 us).
+    // (Requesting them one tile ahead into registers measured SLOWER, 48 us: eight workgroups per CU already hide the latency.)
+    static_assert(2 * SM_TC == 128, "a half workgroup = one input row");
+    constexpr int NIT = (3 * NR + 1) / 2;
+    const int half = tid >> 7, jcol = tid & 127;
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), n = (int)(t / ((long long)tiles_x * tiles_y));
         const int ho0 = ty * SM_TR, wo0 = tx * SM_TC;
         __syncthreads();                                     // (the previous tile's gathers are done)
-        for (int i = tid; i < 3 * NR * (2 * SM_TC + 1); i += 256) {
-            const int j = i % (2 * SM_TC + 1), cr = i / (2 * SM_TC + 1);
-            const int c = cr / NR, r = cr - NR * c;
-            const int hi = 2 * ho0 - 1 + r, wi = 2 * wo0 - 1 + j;
-            float v = 0.f;
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)n * 3 + c) * H + hi) * W + wi];
-            s_in[c][r][(j & 1) ^ 1][j >> 1] = v;             // j even: odd input column (taps s = 0 / s = 2 of the pixel before)
+        {
+            const int wi = 2 * wo0 - 1 + jcol;
+            const bool wok = (unsigned)wi < (unsigned)W;
+            float pre[NIT], pre_l = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {               // loads first (all in flight), LDS writes after
+                const int cr = 2 * it + half;
+                const int c = (cr >= NR) + (cr >= 2 * NR), r = cr - NR * c;
+                const int hi = 2 * ho0 - 1 + r;
+                pre[it] = 0.f;
+                if (cr < 3 * NR && wok && (unsigned)hi < (unsigned)H) pre[it] = x[(((long long)n * 3 + c) * H + hi) * W + wi];
+            }
+            if (tid < 3 * NR) {                              // the last column (j = 2 SM_TC) of row `tid`
+                const int c = (tid >= NR) + (tid >= 2 * NR), r = tid - NR * c;
+                const int hi = 2 * ho0 - 1 + r, wl = 2 * wo0 - 1 + 2 * SM_TC;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wl < (unsigned)W) pre_l = x[(((long long)n * 3 + c) * H + hi) * W + wl];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cr = 2 * it + half;
+                const int c = (cr >= NR) + (cr >= 2 * NR), r = cr - NR * c;
+                if (cr < 3 * NR) s_in[c][r][(jcol & 1) ^ 1][jcol >> 1] = pre[it];      // j even: odd input column (taps s = 0 / s = 2 of the pixel before)
+            }
+            if (tid < 3 * NR) {
+                const int c = (tid >= NR) + (tid >= 2 * NR), r = tid - NR * c;
+                s_in[c][r][1][SM_TC] = pre_l;
+            }
         }
         __syncthreads();
         floatx16_t acc;
