@@ -699,9 +699,18 @@ __global__ void __launch_bounds__(256) wgrad_combine_kernel(const float *part, f
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if ((n & 3) == 0) {       // (n % 4 == 0 whenever C % 4 == 0: slices stay 16-byte aligned)
+        // (four slices requested at a time, added in index order: the same sums with a quarter of the round trips)
         floatx4 v = *reinterpret_cast<const floatx4 *>(part + i);
-        for (int sl = 1; sl < slices; ++sl) {
-            const floatx4 u = *reinterpret_cast<const floatx4 *>(part + sl * n + i);
+        int sl = 1;
+        for (; sl + 3 < slices; sl += 4) {
+            floatx4 u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const floatx4 *>(part + (long long)(sl + k) * n + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[0] += u[k][0]; v[1] += u[k][1]; v[2] += u[k][2]; v[3] += u[k][3]; }
+        }
+        for (; sl < slices; ++sl) {
+            const floatx4 u = *reinterpret_cast<const floatx4 *>(part + (long long)sl * n + i);
             v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
         }
         *reinterpret_cast<floatx4 *>(dw + i) = v;
