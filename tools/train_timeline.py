@@ -12,6 +12,15 @@ import glob
 import os
 
 
+def short(name):
+    """Kernel name without return type, namespaces, template and call arguments."""
+    import re
+    n = name[5:] if name.startswith('void ') else name
+    n = n.replace('(anonymous namespace)::', '')
+    n = re.split(r'[<(]', n)[0]
+    return n.split('::')[-1][:40] or name[:40]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('dir')
@@ -30,7 +39,7 @@ def main():
     win = [(s, e, n) for s, e, n in ks if s >= t0 and s < t1]
     steps = float(a.count)
     ksum = sum(e - s for s, e, n in win)
-    busy, gaps, ce = 0, [], None
+    busy, gaps, ce, last = 0, [], None, ''
     for s, e, n in win:
         if ce is None:
             cs, ce = s, e
@@ -38,8 +47,9 @@ def main():
             ce = max(ce, e)
         else:
             busy += ce - cs
-            gaps.append((s - ce, n))
+            gaps.append((s - ce, short(last) + ' -> ' + short(n)))
             cs, ce = s, e
+        last = n
     busy += ce - cs
     wall = t1 - t0
     lines = ['training step timeline: %d steps, %d launches per step' % (a.count, len(win) / steps),
@@ -50,7 +60,7 @@ def main():
         lines.append('gaps %6.0f - %-8s us: %5.1f per step, %7.1f us per step' % (lo / 1e3, '%.0f' % (hi / 1e3) if hi < 10 ** 12 else 'inf',
                                                                               len(g) / steps, sum(g) / steps / 1e3))
     big = sorted(gaps, reverse=True)[:12]
-    lines.append('largest gaps (us, the kernel that follows): ' + '; '.join('%.0f %s' % (g / 1e3, n.split('(')[0][-40:]) for g, n in big))
+    lines.append('largest gaps (us, the kernel that follows): ' + '; '.join('%.0f %s' % (g / 1e3, n) for g, n in big))
     open(a.out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
