@@ -217,6 +217,39 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
                                     seconds=round(time.perf_counter() - t0, 1), stale=False)
 
 
+class _SmiSampler(object):
+    """Socket power and shader clock from rocm-smi every ~0.25 s on a thread (diagnostic: --power-trace)."""
+
+    def __init__(self):
+        import threading
+        self.samples, self._stop = [], False
+        self._th = threading.Thread(target=self._poll, daemon=True)
+        self._th.start()
+
+    def _poll(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(['rocm-smi', '--showpower', '--showclocks'], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r'Power \(W\): ([0-9.]+)', o)
+                ck = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', o)
+                if pw and ck:
+                    self.samples.append((float(pw.group(1)), int(ck.group(1))))
+            except Exception:
+                pass
+            time.sleep(0.25)
+
+    def stop(self):
+        self._stop = True
+        self._th.join(timeout=10)
+        if not self.samples:
+            return dict(samples=0)
+        sm = self.samples[1:] or self.samples        # (the first sample may precede the loop)
+        return dict(samples=len(sm), mean_w=round(sum(p for p, _ in sm) / len(sm), 1), max_w=max(p for p, _ in sm),
+                    mean_sclk_mhz=round(sum(c for _, c in sm) / len(sm)), min_sclk_mhz=min(c for _, c in sm))
+
+
 def _tuned_path(mode):
     from ppyolo_hip import engine
     return engine._TUNED_PATHS[mode]
@@ -280,6 +313,63 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
         ideal_s += per_op_flops[i] / (peak * 1e12)
         fam_flops[fam] += per_op_flops[i]
     return best, sum(per_op_flops[i] for i in convs), len(convs), ideal_s, fam_flops
+
+
+def batch_scaling_leg(model, wl, dev, ex8, seconds=0.6, batches=(8, 16, 32)):
+    """Diagnostic, not `value`: ONE lane at batch 8 / 16 / 32 on the SAME kernels (a larger batch takes the tile configuration and
+    split-K its layer has in the batch-8 table: only the grid grows), so that what a step loses to grid quantisation, launch tails
+    and per-launch latency -- all of which shrink as 1 / batch -- is separated from the main loops' own efficiency, which does
+    not.  Per batch: images/s of one lane (hipGraph replay), `frac` = conv FLOPs / solo conv kernel time / the mix's MFMA peak
+    (as roofline.frac), `frac_one_lane` = conv FLOPs / whole-step time / that peak."""
+    from ppyolo_hip import synth
+    rows = []
+    for bs in batches:
+        try:
+            x = synth.synth_images(bs, wl['size'], seed=4321 + bs).to(dev)
+            ims = synth.synth_im_size(bs).to(dev)
+            ex = model._plans.executor(x)
+            borrowed = 0
+            for op, src in zip(ex.plan.ops, ex8.plan.ops):
+                if op['op'] in ('conv', 'dcn') and (bs != ex8.plan.N):
+                    op['cfg'], op['splitk'] = src['cfg'], src['splitk']
+                    borrowed += 1
+            if borrowed:
+                ex._size_workspace()
+                ex._link_splits()
+                ex.invalidate_graph()
+            ex.set_inputs(x, ims)
+            ex.use_graph = True
+            for _ in range(3):
+                ex.run()
+            torch.cuda.synchronize()
+            n = 8
+            while True:
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    ex.run()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if dt >= seconds or n >= 4096:
+                    break
+                n *= 2
+            ms_step = dt / n * 1e3
+            ex.use_graph = False
+            total_flops, per_op = conv_flops(ex.plan)
+            conv_ms, covered, nconv, ideal_s, _ = timed_conv_pass(ex, per_op)
+            ex.use_graph = True
+            peak = covered / ideal_s / 1e12
+            rows.append(dict(batch=bs, one_lane_images_per_s=round(bs * n / dt, 1), ms_per_step=round(ms_step, 3),
+                             conv_kernel_ms=round(conv_ms, 3), conv_tflops=round(covered / (conv_ms * 1e-3) / 1e12, 1),
+                             frac=round(covered / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                             frac_one_lane=round(total_flops / (ms_step * 1e-3) / 1e12 / peak, 4),
+                             tiles='batch-8 table' if bs == ex8.plan.N else 'the batch-8 entry of every layer (cfg, split-K) on a %dx grid' % (bs // ex8.plan.N)))
+        except Exception as exc:          # a diagnostic must not take the benchmark line with it
+            rows.append(dict(batch=bs, error='%s: %s' % (type(exc).__name__, str(exc)[:200])))
+        finally:
+            ex = x = None
+            model._plans._ex = {k: v for k, v in model._plans._ex.items() if k[0] == ex8.plan.N}
+            torch.cuda.empty_cache()
+    return rows
 
 
 def layer_report(ex, per_op, path):
@@ -773,6 +863,10 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
                     '(then the committed summary under profiles/ is quoted, marked stale)')
     ap.add_argument('--pmc-child', action='store_true', help='(internal) the short eager one-lane run the PMC passes profile')
+    ap.add_argument('--tune-cu-mask', default=None, help='with --autotune: measure the layers on a stream restricted to these CUs (one term of '
+                    'runtime.lane_cu_masks, e.g. m256:0-127 = half of every XCD) -- the table a CU-masked lane would want')
+    ap.add_argument('--power-trace', action='store_true', help='sample rocm-smi (socket power, shader clock) during the `sustained` loop')
+    ap.add_argument('--no-batch-scaling', action='store_true', help='skip roofline.batch_scaling (one lane at batch 8 / 16 / 32 on the batch-8 kernels)')
     ap.add_argument('--no-worst-case', action='store_true', help='skip the whole-step measurement in the all-pass score regime')
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state running before the timed K steps and '
                     'length of the `sustained` measurement (the board is power-managed: DESIGN.md 4.1)')
@@ -819,8 +913,16 @@ def main():
         e.run()
     torch.cuda.synchronize()
     if a.autotune:
-        for alt in (a.tune_match.split('|') if a.tune_match else [None]):      # "a,b|c,d": layers matching (a and b) or (c and d)
-            ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
+        import contextlib
+        tune_ctx = contextlib.nullcontext()
+        if a.tune_cu_mask:
+            from ppyolo_hip import runtime as _rt
+            _tune_stream = _rt._MaskedStream(dev, _rt.lane_cu_masks(a.tune_cu_mask, 1, torch.cuda.get_device_properties(dev).multi_processor_count)[0])
+            tune_ctx = torch.cuda.stream(_tune_stream.stream)
+        with tune_ctx:
+            for alt in (a.tune_match.split('|') if a.tune_match else [None]):      # "a,b|c,d": layers matching (a and b) or (c and d)
+                ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
+            torch.cuda.synchronize()
         if a.co_tune and depth > 1:
             lanes[1][0].use_graph = True
             changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)
@@ -891,15 +993,17 @@ def main():
         dt = float(t.item())
 
     # `sustained`: the same loop over at least --min-seconds (a multiple of K steps), timed the same way
-    sustained = None
+    sustained, power = None, None
     if a.min_seconds > 0:
         n_sus = a.steps * max(1, int(a.min_seconds / max(dt, 1e-6)) + 1)
         barrier()
+        smi = _SmiSampler() if (a.power_trace and rank == 0) else None
         t1 = time.perf_counter()
         for _ in range(n_sus):
             step()
         barrier()
         dts = time.perf_counter() - t1
+        power = smi.stop() if smi is not None else None
         if world > 1:
             t = torch.tensor([dts], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -1029,9 +1133,13 @@ def main():
                    roofline=roof, ranks=ranks)
         if sustained is not None:
             out['sustained'] = sustained
+            if power is not None:
+                out['sustained']['power'] = power
         if one_at_a_time is not None:
             out['one_batch_at_a_time'] = dict(value=one_at_a_time, unit='images/s',
                                               note='the graph of lane 0 replayed alone (= --in-flight 1)')
+        if world == 1 and not a.no_batch_scaling and a.batch == 8:
+            roof['batch_scaling'] = batch_scaling_leg(model, wl, dev, ex)
         out['roofline_other'] = decode_nms_leg(ex)
         hbm_conv = hbm_conv_leg(ex)
         if hbm_conv is not None:

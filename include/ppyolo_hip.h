@@ -483,6 +483,17 @@ int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, float score
                            uint32_t *cand_key, uint32_t *cand_idx, int *cand_count, int cand_cap,
                            void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Lanes.  The reference evaluates one batch at a time (model/ppyolo.py:19-22, called from model/decode_np.py:142-150); this
+ * path keeps several batches on the device at once, each on its own stream ("lane", ppyolo_hip/runtime.py InFlight).
+ * ppy_lane_stream_create makes such a stream: mask_words == 0 -> an ordinary non-blocking stream; else h_cu_mask (HOST memory,
+ * mask_words x 32 bits) restricts every kernel launched on it -- directly or as nodes of a hipGraph launched on it -- to the
+ * compute units whose bit is set (hipExtStreamCreateWithCUMask).  On MI355X bit i is CU i / 8 of XCD i % 8
+ * (tools/probes/cu_mask_probe.hip), so `i % 8 < 4` gives a lane four whole XCDs with their L2s.  An all-zero mask is refused.
+ * These two calls are the only ones of the library that create or destroy state; they synchronise nothing. */
+int ppy_lane_stream_create(void **stream, const uint32_t *h_cu_mask, int mask_words);
+int ppy_lane_stream_destroy(void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,10 +46,11 @@ class PPYOLO(torch.nn.Module):
         ex = self._run(x, im_size)
         return ex.out_dets, ex.out_count, ex.out_keep
 
-    def in_flight(self, depth=2):
+    def in_flight(self, depth=2, cu_masks=None):
         """Throughput mode (not in the reference): a submit/collect pipeline that keeps `depth` batches on the device
-        at once -- see ppyolo_hip.runtime.InFlight."""
-        return InFlight(self, depth)
+        at once -- see ppyolo_hip.runtime.InFlight.  cu_masks: how the lanes share the chip's CUs (default: the
+        PPYOLO_HIP_LANE_CUS environment switch; runtime.lane_cu_masks)."""
+        return InFlight(self, depth, cu_masks)
 
     # ---- native weight blob (SURVEY.md section 8f rank 3; ppyolo_hip/blob.py) ----
     def save_native_blob(self, path):

@@ -18,3 +18,37 @@ extern "C" const char *ppy_error_string(int code) {
 static thread_local int g_last_hip_error = 0;
 extern "C" void ppy_note_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 extern "C" const char *ppy_last_hip_error(void) { return hipGetErrorName((hipError_t)g_last_hip_error); }
+
+// Lane streams (ppyolo_hip/runtime.py InFlight).  The two batches kept in flight share the chip; with a CU mask per
+// lane each batch owns a fixed part of it (hipExtStreamCreateWithCUMask: bit i of the mask enables one CU; on MI355X consecutive
+// bits walk over the eight XCDs first -- tools/probes/cu_mask_probe.hip), so one lane's store phase always runs beside the other
+// lane's MFMA phase instead of waiting for a chip-wide launch to drain.  The only entry points of the library that create state.
+extern "C" int ppy_lane_stream_create(void **stream, const uint32_t *h_cu_mask, int mask_words) {
+    if (stream == nullptr || mask_words < 0 || (mask_words > 0 && h_cu_mask == nullptr)) return PPY_ERR_BAD_ARG;
+    hipStream_t st = nullptr;
+    hipError_t e;
+    if (mask_words == 0) {
+        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    } else {
+        bool any = false;
+        for (int i = 0; i < mask_words; ++i) any = any || h_cu_mask[i] != 0;
+        if (!any) return PPY_ERR_BAD_ARG;          // a stream without a CU would never finish a kernel
+        e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask_words, h_cu_mask);
+    }
+    if (e != hipSuccess) {
+        ppy_note_hip_error((int)e);
+        return PPY_ERR_LAUNCH;
+    }
+    *stream = (void *)st;
+    return PPY_OK;
+}
+
+extern "C" int ppy_lane_stream_destroy(void *stream) {
+    if (stream == nullptr) return PPY_ERR_BAD_ARG;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        ppy_note_hip_error((int)e);
+        return PPY_ERR_LAUNCH;
+    }
+    return PPY_OK;
+}

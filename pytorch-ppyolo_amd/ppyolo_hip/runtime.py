@@ -189,10 +189,97 @@ class Ticket(object):
         return out
 
 
+def lane_cu_masks(spec, depth, ncu):
+    """Host logic of the lanes' CU partition (no device): `spec` = one term per lane, '|'-separated, a term = 'm<mod>:<lo>-<hi>'
+    (the CUs whose mask bit i has lo <= i % mod <= hi), 'h:<hex>,<hex>,...' (raw 32-bit mask words) or 'all'.  On MI355X bit i of a stream's CU mask is CU i // 8 of XCD
+    i % 8 (tools/probes/cu_mask_probe.hip), so 'm8:0-3|m8:4-7' gives each of two lanes four whole XCDs, 'm16:0-7|m16:8-15' half
+    of the CUs of every XCD.  Named forms: 'xcd' = whole XCDs dealt out evenly over the lanes, 'half' = an equal share of every
+    XCD's CUs.  -> list of `depth` masks, each a list of 32-bit words (None = no mask); '' / '0' / 'off' -> all None."""
+    if not spec or spec in ('0', 'off', 'none'):
+        return [None] * depth
+    if depth < 1 or ncu < 1:
+        raise PPYoloHipError('lane_cu_masks: depth and ncu must be positive')
+    if spec == 'xcd':
+        if 8 % depth:
+            raise PPYoloHipError('PPYOLO_HIP_LANE_CUS=xcd needs a lane count that divides 8 (got %d)' % depth)
+        per = 8 // depth
+        spec = '|'.join('m8:%d-%d' % (k * per, (k + 1) * per - 1) for k in range(depth))
+    elif spec == 'half':
+        per_xcd = max(1, ncu // 8)
+        if per_xcd % depth:
+            raise PPYoloHipError('PPYOLO_HIP_LANE_CUS=half: %d CUs per XCD do not divide over %d lanes' % (per_xcd, depth))
+        per = per_xcd // depth
+        spec = '|'.join('m%d:%d-%d' % (8 * per_xcd, 8 * k * per, 8 * (k + 1) * per - 1) for k in range(depth))
+    terms = spec.split('|')
+    if len(terms) != depth:
+        raise PPYoloHipError('PPYOLO_HIP_LANE_CUS=%r names %d lanes, InFlight has %d' % (spec, len(terms), depth))
+    masks = []
+    for t in terms:
+        if t == 'all':
+            masks.append(None)
+            continue
+        if t.startswith('h:'):          # raw 32-bit words, hexadecimal, lowest CUs first
+            try:
+                words = [int(w, 16) & 0xffffffff for w in t[2:].split(',')]
+            except ValueError:
+                raise PPYoloHipError('PPYOLO_HIP_LANE_CUS: cannot read term %r' % t)
+            if not any(words):
+                raise PPYoloHipError('PPYOLO_HIP_LANE_CUS: term %r enables no CU' % t)
+            masks.append(words)
+            continue
+        try:
+            mod, rng = t[1:].split(':')
+            lo, hi = rng.split('-')
+            mod, lo, hi = int(mod), int(lo), int(hi)
+            assert t[0] == 'm' and mod > 0 and 0 <= lo <= hi < mod
+        except (ValueError, AssertionError):
+            raise PPYoloHipError('PPYOLO_HIP_LANE_CUS: cannot read term %r (want m<mod>:<lo>-<hi> or all)' % t)
+        words = [0] * ((ncu + 31) // 32)
+        for i in range(ncu):
+            if lo <= i % mod <= hi:
+                words[i // 32] |= 1 << (i % 32)
+        if not any(words):
+            raise PPYoloHipError('PPYOLO_HIP_LANE_CUS: term %r enables no CU of %d' % (t, ncu))
+        masks.append(words)
+    return masks
+
+
+class _MaskedStream(object):
+    """A lane's HIP stream restricted to part of the chip (ppy_lane_stream_create), wrapped for torch."""
+
+    def __init__(self, device, words):
+        import ctypes
+        from ._lib import lib, check
+        self._lib, self._check = lib, check
+        ptr = ctypes.c_void_p()
+        arr = (ctypes.c_uint32 * len(words))(*words)
+        with torch.cuda.device(device):
+            check(lib().ppy_lane_stream_create(ctypes.byref(ptr), arr, len(words)), 'ppy_lane_stream_create')
+        self.ptr = ptr.value
+        self.words = list(words)
+        self.stream = torch.cuda.ExternalStream(self.ptr, device=device)
+        # the HIP stream lives as long as the torch object that names it (callers keep `lane.stream`, not the lane: bench.py)
+        self.stream._ppy_owner = self
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib().ppy_lane_stream_destroy(self.ptr)
+                self.ptr = None
+        except Exception:      # interpreter shutdown
+            pass
+
+
 class _Lane(object):
-    def __init__(self, ex, device):
+    def __init__(self, ex, device, cu_mask=None):
         self.ex = ex
-        self.stream = torch.cuda.Stream(device=device)
+        self._masked = None
+        if cu_mask is None:
+            self.stream = torch.cuda.Stream(device=device)
+        else:
+            self._masked = _MaskedStream(device, cu_mask)
+            self.stream = self._masked.stream
+        self.cu_mask = cu_mask
         self.done = torch.cuda.Event()
         self.ticket = None
 
@@ -209,7 +296,7 @@ class InFlight(object):
         preds0 = t0.result(); t2 = pipe.submit(x2, im2); ...
     """
 
-    def __init__(self, model, depth=2):
+    def __init__(self, model, depth=2, cu_masks=None):
         if depth < 1:
             raise PPYoloHipError('InFlight depth must be >= 1')
         self._model = model
@@ -217,6 +304,9 @@ class InFlight(object):
         self._lanes = {}
         self._generation = model._plans.generation
         self._next = 0
+        # CU partition of the lanes (round 5): PPYOLO_HIP_LANE_CUS, see lane_cu_masks
+        self.cu_spec = os.environ.get('PPYOLO_HIP_LANE_CUS', '') if cu_masks is None else cu_masks
+        self._masks = None
 
     def _lane(self, x, k):
         self._model._plans.check_current()                           # parameters modified in place since the lanes were built
@@ -231,7 +321,10 @@ class InFlight(object):
             # one executor alone keeps its forked graph; executors that overlap each other run single-branch graphs
             # lanes 1..depth: lane 0 is the executor of model.forward, which must stay free to be called beside open tickets
             ex = self._model._plans.executor(x, lane=k + 1, multi_stream=None if self.depth == 1 else False)
-            lane = _Lane(ex, x.device)
+            if self._masks is None:
+                ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+                self._masks = lane_cu_masks(self.cu_spec, self.depth, ncu)
+            lane = _Lane(ex, x.device, self._masks[k])
             self._lanes[key] = lane
         return lane
 

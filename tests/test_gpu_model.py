@@ -459,6 +459,45 @@ def test_in_flight_matches_forward(cfgc, S, N, depth):
     _check_preds([g.cpu() for g in got[3]], ref, box_tol=3e-3)
 
 
+@pytest.mark.parametrize('spec,depth', [('half', 2), ('all|m256:0-63', 2), ('half', 4)])
+def test_cu_masked_lanes_match_forward(spec, depth):
+    """Lanes on CU-masked streams (ppy_lane_stream_create; runtime.lane_cu_masks): a kernel does not know which CUs run it, so every
+    batch comes back bit for bit as from model.forward -- through hipGraph replay on the masked streams -- and a lane dropped while
+    its stream object is still held by the caller keeps a live HIP stream (bench.py keeps `lanes(x)`, not the InFlight)."""
+    cfg = PPYOLO_r18vd_Config()
+    model, _ = build_model(cfg, 0, 'cuda')
+    N, S = 4, 320
+    batches = [(synth.synth_images(N, S, seed=700 + i).cuda(), synth.synth_im_size(N).cuda()) for i in range(2 * depth + 1)]
+    want = [[p.clone() for p in model(x, ims)] for x, ims in batches]
+    pipe = model.in_flight(depth, cu_masks=spec)
+    tickets, got = [], {}
+    for i, (x, ims) in enumerate(batches):
+        if len(tickets) == depth:
+            j, t = tickets.pop(0)
+            got[j] = t.result()
+        tickets.append((i, pipe.submit(x, ims)))
+    for j, t in tickets:
+        got[j] = t.result()
+    for j in range(len(batches)):
+        for a, b in zip(got[j], want[j]):
+            assert torch.equal(a, b), 'batch %d differs between a masked lane and forward' % j
+    masked = [ln for ln in pipe._lanes.values() if ln.cu_mask is not None]
+    assert masked and all(ln.stream.cuda_stream == ln._masked.ptr for ln in masked)
+    # the (executor, stream) pairs outlive the InFlight object
+    lanes = model.in_flight(depth, cu_masks=spec).lanes(batches[0][0])
+    import gc
+    gc.collect()
+    for k, (ex, st) in enumerate(lanes):
+        ex.set_inputs(*batches[k % len(batches)])
+        with torch.cuda.stream(st):
+            ex.run()
+    torch.cuda.synchronize()
+    for k, (ex, _) in enumerate(lanes):
+        for i, w in enumerate(want[k % len(batches)]):
+            n = int(ex.out_count[i])
+            assert torch.equal(ex.out_dets[i, :max(n, 1)], w) or (n == 0 and w[0, 0] == -1)
+
+
 def test_forward_beside_open_tickets():
     """InFlight owns its executors: a plain model(x) call while tickets are open neither disturbs the batches in flight
     nor is disturbed by them (lane 0 used to be the executor of forward itself)."""
