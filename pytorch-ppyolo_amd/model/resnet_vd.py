@@ -57,13 +57,17 @@ class ConvBlock(_Units, torch.nn.Module):
     # shortcut tensor -- written by one launch and read back by the next as the residual, 2 x 189 MB at 152 x 152 -- never
     # exists.  One launch less per stage; the reduction of conv3 grows from f2 to f2 + in_c channels, same FLOPs in total.
     @staticmethod
-    def _fold():
-        return os.environ.get('PPYOLO_HIP_FOLD_SHORTCUT', '1') == '1'
+    def _fold(b):
+        """The switch is read ONCE per plan (Builder), so wide_input() and emit() of one plan cannot disagree."""
+        f = getattr(b, 'fold_shortcut', None)
+        if f is None:
+            f = b.fold_shortcut = os.environ.get('PPYOLO_HIP_FOLD_SHORTCUT', '1') == '1'
+        return f
 
     def wide_input(self, b, N, H, W):
         """Stage 2 (no pooling in front of the projection): the block's INPUT is the shortcut operand, so its producer writes it
         straight into the wide buffer -> the slice to hand to that producer (None when the fold is off)."""
-        if not (self._fold() and self.is_first):
+        if not (self._fold(b) and self.is_first):
             return None
         f2, cs = self.conv2.filters, self.conv4.conv.in_channels
         wide = b.new_buf(N, H, W, f2 + cs)
@@ -72,8 +76,11 @@ class ConvBlock(_Units, torch.nn.Module):
         return A(wide, f2, cs, N, H, W)
 
     def emit(self, b, x, out=None):
-        if self._fold():
+        # (a stage-2 block whose input was NOT placed into a wide buffer by its producer -- stand-alone emission, another stem -- takes
+        # the unfolded path: the fold needs the producer's cooperation there, wide_input())
+        if self._fold(b) and not (self.is_first and not (id(self) in b.wide_of_block and x.buf == b.wide_of_block[id(self)])):
             return self._emit_folded(b, x, out)
+        b.wide_of_block.pop(id(self), None)
         with b.side():              # projection shortcut: independent of conv1 -> conv2
             s = x if self.is_first else b.avgpool(x)
             s = self.conv4.emit(b, s)
@@ -87,14 +94,11 @@ class ConvBlock(_Units, torch.nn.Module):
         f2, cs, f3 = self.conv2.filters, self.conv4.conv.in_channels, self.conv3.filters
         Ho, Wo = (x.H, x.W) if self.is_first else (x.H // 2, x.W // 2)
         wide = b.wide_of_block.pop(id(self), None)
-        if self.is_first and wide is not None and x.buf == wide:      # x already sits in its slice (wide_input)
-            pass
+        if self.is_first:      # x already sits in its slice of the wide buffer (wide_input; emit() checked it)
+            assert wide is not None and x.buf == wide
         else:
             wide = b.new_buf(x.N, Ho, Wo, f2 + cs)
-            s_slot = A(wide, f2, cs, x.N, Ho, Wo)
-            if self.is_first:
-                raise AssertionError('stage-2 ConvBlock: hand wide_input() to the producer of x first')
-            b.avgpool(x, out=s_slot)
+            b.avgpool(x, out=A(wide, f2, cs, x.N, Ho, Wo))
         y = self.conv1.emit(b, x)
         self.conv2.emit(b, y, out=A(wide, 0, f2, x.N, Ho, Wo))
         skel = getattr(b, 'skeleton', False)

@@ -27,9 +27,16 @@ import torch
 from ._lib import PPYoloHipError
 
 MAGIC = b'PPYBLOB1'
-VERSION = 1
+VERSION = 2          # 2: the header names the plan-shaping switches the weights were folded under (round 5)
 _KEYS = ('w', 'scale', 'shift', 'w3')
 _DT = {'float32': torch.float32, 'int16': torch.int16}
+
+
+def plan_switches():
+    """The environment switches that change WHICH weight tensors a plan holds (not how they are run): a blob written under other
+    settings does not fit the plans this process builds -- with the shortcut fold conv3 and conv4 of a stage's first block are one
+    [f3, f2 + in_c] tensor, with the K padding the 258-filter output convolutions carry 260."""
+    return dict(fold_shortcut=os.environ.get('PPYOLO_HIP_FOLD_SHORTCUT', '1') == '1', pad_k=os.environ.get('PPYOLO_HIP_PAD_K', '1') == '1')
 
 
 def fingerprint(state_dict):
@@ -83,7 +90,7 @@ def save(ex, path, fp):
                 off += (a.nbytes + 255) // 256 * 256
             ents.append(rec)
         lists[name] = ents
-    header = json.dumps(dict(version=VERSION, math=ex.math, fingerprint=fp, data_bytes=off, lists=lists)).encode()
+    header = json.dumps(dict(version=VERSION, math=ex.math, fingerprint=fp, data_bytes=off, lists=lists, switches=plan_switches())).encode()
     start = (16 + len(header) + 4095) // 4096 * 4096
     tmp = path + '.tmp.%d' % os.getpid()
     with open(tmp, 'wb') as fh:
@@ -107,7 +114,11 @@ def read_header(path):
         n, = struct.unpack('<Q', head[8:])
         hdr = json.loads(fh.read(n).decode())
     if hdr.get('version') != VERSION:
-        raise PPYoloHipError('%s: blob version %r, this build reads %d' % (path, hdr.get('version'), VERSION))
+        raise PPYoloHipError('%s: blob version %r, this build reads %d -- rebuild it with model.save_native_blob()' % (path, hdr.get('version'), VERSION))
+    if hdr.get('switches') != plan_switches():
+        raise PPYoloHipError('%s was written under other plan-shaping switches (%r) than this process runs with (%r): rebuild it with '
+                             'model.save_native_blob(), or set PPYOLO_HIP_FOLD_SHORTCUT / PPYOLO_HIP_PAD_K as they were'
+                             % (path, hdr.get('switches'), plan_switches()))
     return hdr, (16 + n + 4095) // 4096 * 4096
 
 

@@ -374,12 +374,7 @@ class HipExecutor(object):
         self.graph = None
         self._graph_stream = None
         p = plan
-        self.bufs = []
-        for i, (N, H, W, ld) in enumerate(p.buffers):
-            if i in p.consts:
-                self.bufs.append(p.consts[i].to(self.device).contiguous())
-            else:
-                self.bufs.append(torch.empty((N, H, W, ld), dtype=torch.float32, device=self.device))
+        self.bufs = None          # allocated after the pooling links are known (_alloc_buffers)
         self.x_in = torch.zeros((p.N, 3, p.H, p.W), dtype=torch.float32, device=self.device)
         self.im_size = torch.zeros((p.N, 2), dtype=torch.float32, device=self.device)
         d = p.decode
@@ -410,7 +405,10 @@ class HipExecutor(object):
                             op[k] = src[k]
         else:
             if placeholders:
-                raise PPYoloHipError('skeleton plan without a matching weight owner (math mode %s)' % self.math)
+                raise PPYoloHipError('skeleton plan without a matching weight owner (math mode %s; this plan has %d + %d ops, the owner %s) -- '
+                                     'a native blob written under another PPYOLO_HIP_FOLD_SHORTCUT / PPYOLO_HIP_MATH must be rebuilt'
+                                     % (self.math, len(p.setup_ops), len(p.ops),
+                                        'none' if share is None else '%d + %d, math %s' % (len(share.plan.setup_ops), len(share.plan.ops), share.math)))
             self._to_device(p.setup_ops)
             self._to_device(p.ops)
             if self.math in ('bf16x3', 'f16x2'):
@@ -424,6 +422,7 @@ class HipExecutor(object):
         self._want_streams = os.environ.get('PPYOLO_HIP_STREAMS', '1') == '2' if multi_stream is None else bool(multi_stream)
         self._link_pools()
         self._link_maxpools()
+        self._alloc_buffers()
         tab = tuned_table(self.math)
         tab_x3 = tuned_table('bf16x3') if self.math == 'f16x2' else {}
         self._mark_split_candidates()
@@ -456,6 +455,28 @@ class HipExecutor(object):
                     s_w = torch.where(op['scale'] != 0, op['scale'] / op['wf16'][1], torch.ones_like(op['scale']))
                     op['posb_f16'] = (self.bufs[op['posb'].buf] * s_w).contiguous()
             self._link_splits()
+
+    def _alloc_buffers(self):
+        """One tensor per plan buffer that some op still reads or writes once the pooling links are made: the full-resolution stem
+        tensor between conv1_3 and the max pool written from its epilogue (189 MB at 608 x 608, batch 8, per executor and lane) is
+        referenced by nothing and stays unallocated (None)."""
+        p = self.plan
+        used = set(p.consts)
+        for op in p.setup_ops + p.ops:
+            ins, outs = self._op_io(op)
+            used.update(ins)
+            used.update(outs)
+            if op.get('posb') is not None:
+                used.add(op['posb'].buf)
+        used.update(a.buf for a in list(p.feats) + list(p.head_outs))
+        self.bufs = []
+        for i, (N, H, W, ld) in enumerate(p.buffers):
+            if i in p.consts:
+                self.bufs.append(p.consts[i].to(self.device).contiguous())
+            elif i in used:
+                self.bufs.append(torch.empty((N, H, W, ld), dtype=torch.float32, device=self.device))
+            else:
+                self.bufs.append(None)
 
     def _assign_amax(self):
         """Tracked per-image tensor maxima for the f16x2 kernels: every conv / DCN launch merges max|y| into the slots of its

@@ -428,12 +428,17 @@ class TrainStep(object):
         Ho, Wo = K.conv_out_hw(xin.H, xin.W, R, S, stride, pad)
         bias = self.param(prefix + '.conv.bias')
         has_bn = prefix + '.bn.weight' in sd
-        raw = self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn)
+        raw_box = []
+
+        def get_raw():          # (allocated on first use: a layer whose BatchNorm is applied from the convolution's epilogue never stores it)
+            if not raw_box:
+                raw_box.append(self.new(xin.N, Ho, Wo, Kout, ld=_r32(Kout) if not has_bn else None, req=trainable, zero=not has_bn))
+            return raw_box[0]
         one, b0 = self._vec('one', Kout, 1.0), bias if bias is not None else self._vec('zero', Kout, 0.0)
         use_f16 = self.f16 and xin.amax is not None and ent['f16'] is not None
 
         def run(cfg_id, splitk):
-            K.conv2d_bn_act(xin.view(), krsc, one, b0, raw.view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
+            K.conv2d_bn_act(xin.view(), krsc, one, b0, get_raw().view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
                             w_x3=None if use_f16 else self._planes(ent), w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
         key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
         cfg_id, splitk = self._choose(key, run, R * S * Cp // 32, use_f16)
@@ -457,10 +462,11 @@ class TrainStep(object):
             need = K.conv2d_bn_partials_bytes(xin.N * Ho * Wo, Kout) // 4
             if self._bn_part is None or self._bn_part.numel() < need:
                 self._bn_part = torch.empty(need, dtype=torch.float32, device=self.dev)
-            slices = K.conv2d_train_fwd(xin.view(), krsc, ent['f16'], b0, raw.view(), stride, pad, cfg_id, xin.amax, self._bn_part)
+            slices = K.conv2d_train_fwd(xin.view(), krsc, ent['f16'], b0, get_raw().view(), stride, pad, cfg_id, xin.amax, self._bn_part)
         else:
             run(cfg_id, splitk)
         self.flops += 2 * xin.N * Ho * Wo * Kout * R * S * ent['Cin']
+        raw = None if epi else get_raw()
         if not has_bn:
             y = raw
             mean = invstd = None

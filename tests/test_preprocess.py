@@ -113,8 +113,13 @@ def test_process_image_layout():
 
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize('kernel', ['tile', 'pixel'])
 @pytest.mark.parametrize('to_rgb', [True, False])
-def test_kernel_matches_oracle_bitwise(to_rgb):
+def test_kernel_matches_oracle_bitwise(to_rgb, kernel, monkeypatch):
+    """Both forms of the kernel -- the separable, tiled one of round 5 (default) and the one-thread-per-pixel form (PPY_PRE_PIXEL=1,
+    read per call) -- against the numpy oracle, bit for bit; S = 608 / 416 (multiples of 4: 16-byte stores), 64, and 333 / 37 (scalar
+    stores, a tile wider than the image)."""
+    monkeypatch.setenv('PPY_PRE_PIXEL', '1' if kernel == 'pixel' else '0')
     from ppyolo_hip import ops
     from ppyolo_hip.preprocess import normalisation_table
     cfg = PPYOLO_2x_Config()
@@ -122,7 +127,10 @@ def test_kernel_matches_oracle_bitwise(to_rgb):
     lut = torch.from_numpy(normalisation_table(n['mean'], n['std'], n['is_scale'])).cuda()
     sizes = [(480, 640), (1080, 1920), (37, 53), (1, 1), (3, 500), (416, 416), (375, 500), (2, 3), (600, 13)]
     sizes += [(100 + 7 * i, 90 + 11 * i) for i in range(12)]                 # 21 images: two launches of <= 16
-    for S in (416, 64):
+    sizes += [(2400, 31), (31, 2400)]                                        # 4x down: the tile's row count shrinks to fit the LDS
+    for S in ((416, 64, 333, 37, 608) if kernel == 'tile' else (416, 64)):
+        if S in (333, 37, 608):
+            sizes = sizes[:9] + sizes[-2:]
         imgs = [rand_image(h, w, 7 * h + w) for h, w in sizes]
         wide = [torch.from_numpy(np.pad(im, ((0, 0), (0, 5), (0, 0)))).cuda() for im in imgs]
         dev = [t[:, :im.shape[1]] for t, im in zip(wide, imgs)]             # padded rows: row stride > 3 w
