@@ -139,7 +139,7 @@ def worst_case_leg(wl, dev, x, ims, sd, cfg, depth, seconds, cpu_threads):
     return out
 
 
-def pmc_traffic_leg(argv_tail, nconv, timeout=120):
+def pmc_traffic_leg(argv_tail, nconv, timeout=120, extra_kernels=()):
     """HBM-side bytes of the convolution launches, MEASURED BY THIS RUN: bench.py re-executes itself twice under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (counters need their own passes and their own process: the guide's
     HBM / rocprofv3 section) as a short eager one-lane child, and sums the counters of the convolution kernels per pass of the
@@ -153,8 +153,9 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None, 'rocprofv3 not found'
-    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused')
+    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused') + tuple(extra_kernels)
     tot = {}
+    launches = 0.0
     t0 = time.perf_counter()
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='ppy_pmc_')
@@ -164,7 +165,7 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
         try:
             subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             files = glob.glob(os.path.join(d, '**', '*counter_collection*.csv'), recursive=True)
-            val, passes = 0.0, 0
+            val, passes, nl = 0.0, 0, 0
             for f in files:
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
@@ -175,9 +176,11 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
                             passes += 1
                         if any(n in k for n in main_k) or 'splitk_reduce' in k:
                             val += float(r['Counter_Value'])
+                            nl += 0 if 'splitk_reduce' in k else 1
             if not passes:
                 return None, 'no counter rows for %s' % counter
             tot[counter] = val / passes
+            launches = nl / passes
         except Exception as exc:       # a profiler that is missing / hangs / fails must not take the benchmark line with it
             return None, '%s pass failed: %s' % (counter, type(exc).__name__)
         finally:
@@ -211,7 +214,9 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120):
     finally:
         shutil.rmtree(d, ignore_errors=True)
     byt = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
-    return round(byt / nconv), dict(mfma_busy_pmc=mfma, measured_by='this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an eager one-lane child process',
+    if not nconv:
+        nconv = max(1.0, launches)
+    return round(byt / nconv), dict(launches_per_step=round(launches, 1), mfma_busy_pmc=mfma, measured_by='this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of an eager one-lane child process',
                                     hbm_bytes_per_step=round(byt), fetch_size_kb_per_step=round(tot['FETCH_SIZE'], 1),
                                     write_size_kb_per_step=round(tot['WRITE_SIZE'], 1), gfx950_fetch_correction=2.0,
                                     seconds=round(time.perf_counter() - t0, 1), stale=False)
@@ -295,8 +300,11 @@ def timed_conv_pass(ex, per_op_flops, reps=3):
             else:
                 ex._run_op(op)
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e in evs)
-        best = ms if best is None else min(best, ms)
+        per = [s.elapsed_time(e) for s, e in evs]
+        ms = sum(per)
+        if best is None or ms < best:
+            best = ms
+            timed_conv_pass.last_per_op = dict(zip(convs, per))      # (ms per conv / DCN op of the best pass: per-class tables)
     # MFMA-pipe time the same launches would need at peak: per launch flops / (peak of the kernel family it ran on)
     ideal_s = 0.0
     fam_flops = {'fp32': 0, 'bf16x3': 0, 'f16x2': 0}
@@ -358,7 +366,14 @@ def batch_scaling_leg(model, wl, dev, ex8, seconds=0.6, batches=(8, 16, 32)):
             conv_ms, covered, nconv, ideal_s, _ = timed_conv_pass(ex, per_op)
             ex.use_graph = True
             peak = covered / ideal_s / 1e12
-            rows.append(dict(batch=bs, one_lane_images_per_s=round(bs * n / dt, 1), ms_per_step=round(ms_step, 3),
+            cls = {}
+            for i, ms in timed_conv_pass.last_per_op.items():
+                op = ex.plan.ops[i]
+                c = 'dcn' if op['op'] == 'dcn' else ('3x3' if op['w'].shape[1] == 3 else '1x1')
+                d = cls.setdefault(c, [0.0, 0.0])
+                d[0] += ms
+                d[1] += per_op[i]
+            rows.append(dict(batch=bs, tflops_by_class={c: round(d[1] / (d[0] * 1e-3) / 1e12, 1) for c, d in sorted(cls.items())}, one_lane_images_per_s=round(bs * n / dt, 1), ms_per_step=round(ms_step, 3),
                              conv_kernel_ms=round(conv_ms, 3), conv_tflops=round(covered / (conv_ms * 1e-3) / 1e12, 1),
                              frac=round(covered / (conv_ms * 1e-3) / 1e12 / peak, 4),
                              frac_one_lane=round(total_flops / (ms_step * 1e-3) / 1e12 / peak, 4),
@@ -627,21 +642,32 @@ def preprocess_leg(cfg, size, batch, lanes, steps, with_cpu):
     raw = [torch.from_numpy(rng.randint(0, 256, size=(480, 640, 3)).astype(np.uint8)).pin_memory() for _ in range(batch)]
     on_dev = [r.to(dev) for r in raw]
     out = torch.empty((batch, 3, size, size), dtype=torch.float32, device=dev)
+    # a launch is ~15 us of kernel behind ~40 us of host work (ctypes marshalling of four per-image arrays): one launch between two
+    # events measures the host (rounds 1-4 quoted 56 us that way).  As for the decode launch: 20 launches captured into a graph,
+    # replayed between two events.
+    K.preprocess_images(on_dev, size, pre.lut, out, swap_rb=pre.to_rgb)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            K.preprocess_images(on_dev, size, pre.lut, out, swap_rb=pre.to_rgb)
+    g.replay()
     best = None
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        K.preprocess_images(on_dev, size, pre.lut, out, swap_rb=pre.to_rgb)
+        g.replay()
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1)
+        ms = e0.elapsed_time(e1) / 20.0
         best = ms if best is None else min(best, ms)
+    g.reset()
     byt = sum(r.numel() for r in raw) + out.numel() * 4
     gbs = byt / (best * 1e-3) / 1e9
     res = dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s', frac=round(gbs / 8000.0, 4),
                bytes_per_launch=byt, us_per_launch=round(best * 1e3, 1),
-               kernel='preprocess_kernel (BGR->RGB, 8-bit bicubic resize 480x640 -> %dx%d, normalise, HWC->CHW; %d images, '
-                      'one launch)' % (size, size, batch))
+               kernel='preprocess_tile_kernel (BGR->RGB, 8-bit bicubic resize 480x640 -> %dx%d, normalise, HWC->CHW; %d images per '
+                      'launch; mean of 20 launches replayed from a graph)' % (size, size, batch))
     ims = torch.tensor([[480., 640.]] * batch, device=dev)
     stage = [[torch.empty_like(o) for o in on_dev] for _ in lanes]
 
@@ -773,6 +799,11 @@ def train_bench(a, wl, dev, rank, world):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+    if a.pmc_child:          # profiled by pmc_traffic_leg: a few eager steps, nothing else
+        for _ in range(3):
+            ts.step(x, gt, targets, lr)
+        torch.cuda.synchronize()
+        return
     for _ in range(max(1, a.warmup)):
         losses.append(ts.step(x, gt, targets, lr))
     barrier()
@@ -813,16 +844,43 @@ def train_bench(a, wl, dev, rank, world):
                                            'products per multiply-add' % (3 if ts.f16 else 6)))
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = train_cpu_baseline(sd, cfg, x, gt, targets)
-        # HBM-side bytes of the convolution launches from the committed rocprofv3 PMC summary (tools/prof_train.sh)
+        # `value_fp32_exact` (round 5): the same step with every convolution, data gradient and weight gradient on the exact-fp32 MFMA
+        # -- its own process, because the kernel choices are read once per process
+        if world == 1 and not a.no_alt_math and os.environ.get('PPYOLO_HIP_TRAIN_MATH', 'f16x2') != 'fp32':
+            import subprocess
+            env = dict(os.environ, PPYOLO_HIP_TRAIN_MATH='fp32', PPY_WGRAD_FP32='1', PPY_DGRAD_FP32='1')
+            cmd = [sys.executable, os.path.abspath(__file__), '--train', '--steps', str(min(a.steps, 10)), '--warmup', '2', '--no-cpu-baseline',
+                   '--no-alt-math', '--no-pmc', '--workload', a.workload, '--batch', str(a.batch)] + (['--freeze-at', str(a.freeze_at)] if a.freeze_at is not None else [])
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True, universal_newlines=True)
+                child = json.loads(r.stdout.strip().splitlines()[-1])
+                out['value_fp32_exact'] = child['value']
+                out['value_fp32_exact_note'] = ('same step, PPYOLO_HIP_TRAIN_MATH=fp32 PPY_WGRAD_FP32=1 PPY_DGRAD_FP32=1: forward, data and weight gradients on '
+                                                'v_mfma_f32_32x32x2_f32 (%.2f ms per step, loss %s -> %s); `value` builds every product from 2-term fp16 splits'
+                                                % (child['ms_per_step'], child.get('loss_first'), child.get('loss_last')))
+            except Exception as exc:
+                out['value_fp32_exact'] = None
+                out['value_fp32_exact_note'] = 'the exact-fp32 child run failed: %s' % type(exc).__name__
+        # HBM-side bytes of the convolution launches (forward, data gradient, weight gradient), MEASURED BY THIS RUN like the inference
+        # line's: two rocprofv3 --pmc child passes of three eager steps; the committed summary only as a fallback, marked stale
+        measured = None
+        if world == 1 and not a.no_pmc and a.workload == 'r50vd_608':
+            measured, src = pmc_traffic_leg(['--train', '--workload', a.workload, '--batch', str(a.batch)], None, timeout=300,
+                                            extra_kernels=('conv_wgrad',))
+            if measured is not None:
+                src.pop('mfma_busy_pmc', None)
+                out['roofline']['traffic'] = measured
+                out['roofline']['traffic_unit'] = 'bytes per launch (mean over the convolution launches of a step: forward, dgrad, wgrad; PMC 2*FETCH_SIZE+WRITE_SIZE)'
+                out['roofline']['traffic_source'] = src
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_pmc_traffic.json')))
-        if files and a.workload == 'r50vd_608' and a.batch == 8 and ts.freeze_at == 5:
+        if measured is None and files and a.workload == 'r50vd_608' and a.batch == 8 and ts.freeze_at == 5:
             with open(files[-1]) as fh:
                 rec = json.load(fh)
             out['roofline']['traffic'] = round(rec['hbm_bytes_per_step'] / max(1, rec['conv_launches_per_step']))
             out['roofline']['traffic_unit'] = 'bytes per launch (mean over the convolution launches of a step: forward, dgrad, wgrad; PMC 2*FETCH_SIZE+WRITE_SIZE)'
-            out['roofline']['traffic_source'] = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured'),
-                                                     note='NOT measured by this run: rocprofv3 PMC passes need their own processes (tools/prof_train.sh)')
+            out['roofline']['traffic_source'] = dict(file='profiles/' + os.path.basename(files[-1]), measured=rec.get('measured'), stale=True,
+                                                     note='NOT measured by this run (--no-pmc, N > 1 or the profiler failed): committed summary of tools/prof_train.sh')
         print(json.dumps(out), flush=True)
 
 

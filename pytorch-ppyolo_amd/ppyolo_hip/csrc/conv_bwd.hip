@@ -813,6 +813,12 @@ extern "C" int ppy_conv2d_dgrad_f32(const float *dy, int dy_ld, const float *w_k
         src_ld = Kp;
     }
     const size_t rest = ws_bytes - (size_t)(base - (char *)ws);
+    // PPY_DGRAD_FP32=1 (read once per process; bench.py's `value_fp32_exact` leg of the training step): the same contraction on the
+    // exact-fp32 MFMA kernels -- no operand planes, the library's own tile choice
+    static const bool force_fp32 = getenv("PPY_DGRAD_FP32") && getenv("PPY_DGRAD_FP32")[0] == '1';
+    if (force_fp32)
+        return ppy_conv2d_bn_act_f32(src, src_ld, wt, nullptr, nullptr, ones, nullptr, zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N, g.Ho, g.Wo,
+                                     Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0, -1, 0, nullptr, nullptr, base, rest, stream);
     // dy is [N, Ho, Wo, K]; for stride 1 the forward convolution with pad' = R-1-pad maps it back onto [N, H, W, C]
     return ppy_conv2d_bn_act_f32(src, src_ld, wt, amax_dy ? nullptr : planes, amax_dy ? planes : nullptr, ones, amax_dy ? scale_f16 : nullptr,
                                  zeros, nullptr, 0, nullptr, nullptr, dx, dx_ld, N, g.Ho, g.Wo, Kp, C, R, S, 1, R - 1 - pad, PPY_ACT_NONE, 0,

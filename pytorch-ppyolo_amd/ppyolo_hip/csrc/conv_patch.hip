@@ -26,7 +26,7 @@
 #pragma clang fp contract(off)
 
 #ifndef PPY_PATCH_ABL
-#define PPY_PATCH_ABL 0   // ablation switch (tools/patch_ablate.sh; results are garbage, only the timing means something): 1 = no MFMA
+#define PPY_PATCH_ABL 0   // ablation switch (tools/experiments/patch_ablate.sh; results are garbage, only the timing means something): 1 = no MFMA
                           // phase, 2 = no split / plane writes, 3 = no epilogue, 4 = no patch requests, 5 = MFMAs without LDS reads
 #endif
 

@@ -39,7 +39,7 @@
 #define PPY_X3_XCD 1      // XCD-contiguous tile order (0 = plain blockIdx order, for A/B rebuilds: +1.3 % on the R50 step)
 #endif
 #ifndef PPY_X3_ABL
-#define PPY_X3_ABL 0      // ablation switch for experiments (tools/x3_ablate.sh; results are garbage, only the timing means something):
+#define PPY_X3_ABL 0      // ablation switch for experiments (tools/experiments/x3_ablate.sh; results are garbage, only the timing means something):
                           // 1 = no DMA in the loop, 2 = no split, 3 = neither, 4 = no mid-chunk barrier either, 5 = MFMA only,
                           // 6 = everything, but every DMA piece out of range (no memory traffic), 7 = operand delivery only (DMA +
                           // barriers), 8 = 7 with the weight pieces only, 9 = 7 with the activation pieces only.  DESIGN.md 8 item 1.

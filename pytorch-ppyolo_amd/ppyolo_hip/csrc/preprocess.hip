@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs p) {
 //            as 16-byte LDS reads, FixedPtCast, the normalisation table from LDS, one 16-byte store per channel.
 // Integer arithmetic is exact and the float expressions are the pixel kernel's own functions, so the result is bit-identical
 // (tests/test_preprocess.py compares both kernels with the numpy oracle).
-constexpr int PRE_TW = 128, PRE_MAXROWS = 40, PRE_MAXR = 32;
+constexpr int PRE_TW = 128, PRE_MAXROWS = 24, PRE_MAXR = 16;      // 40 KB of LDS: four workgroups per CU (40 rows / 32: two, 27 -> 21 us)
 struct PreTileArgs {
     PreArgs a;
     int rows_per_tile[PRE_MAX_IMAGES];
@@ -160,33 +160,45 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs 
             int cj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) cj[j] = min(max(sx - 1 + j, 0), im.w - 1) * 3;
-            for (int r = lane; r < nrows; r += 2) {
-                const unsigned char *row = im.src + (long long)min(max(r_lo + r, 0), im.h - 1) * im.stride;
-                unsigned px[3];
-                if (inside) {
-                    const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(row + (sx - 1) * 3);
-                    px[0] = q[0];
-                    px[1] = q[1];
-                    px[2] = q[2];
-                } else {
-                    unsigned char b[12];
+            // PRE_U rows per pass, all their loads in flight together (one row at a time left every thread in a chain of dependent
+            // ~1 us loads: the phase was latency-bound)
+            constexpr int PRE_U = 4;
+            for (int rb = lane; rb < nrows; rb += 2 * PRE_U) {
+                unsigned px[PRE_U][3];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int u = 0; u < PRE_U; ++u) {
+                    const int r = min(rb + 2 * u, nrows - 1);       // (a repeated last row: same bytes, result not stored)
+                    const unsigned char *row = im.src + (long long)min(max(r_lo + r, 0), im.h - 1) * im.stride;
+                    if (inside) {
+                        const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(row + (sx - 1) * 3);
+                        px[u][0] = q[0];
+                        px[u][1] = q[1];
+                        px[u][2] = q[2];
+                    } else {
+                        unsigned char b[12];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) b[3 * j + c] = row[cj[j] + c];
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
-                        px[d] = (unsigned)b[4 * d] | ((unsigned)b[4 * d + 1] << 8) | ((unsigned)b[4 * d + 2] << 16) | ((unsigned)b[4 * d + 3] << 24);
+                            for (int c = 0; c < 3; ++c) b[3 * j + c] = row[cj[j] + c];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+                            px[u][d] = (unsigned)b[4 * d] | ((unsigned)b[4 * d + 1] << 8) | ((unsigned)b[4 * d + 2] << 16) | ((unsigned)b[4 * d + 3] << 24);
+                    }
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {          // c = SOURCE channel (byte position in the pixel)
-                    int hs = 0;
+                for (int u = 0; u < PRE_U; ++u) {
+                    const int r = rb + 2 * u;
+                    if (r >= nrows) break;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int byte = 3 * j + c;
-                        hs += (int)((px[byte >> 2] >> (8 * (byte & 3))) & 0xffu) * ax[j];
+                    for (int c = 0; c < 3; ++c) {          // c = SOURCE channel (byte position in the pixel)
+                        int hs = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int byte = 3 * j + c;
+                            hs += (int)((px[u][byte >> 2] >> (8 * (byte & 3))) & 0xffu) * ax[j];
+                        }
+                        s_h[r][c][col] = hs;
                     }
-                    s_h[r][c][col] = hs;
                 }
             }
         }

@@ -178,6 +178,9 @@ class TrainStep(object):
         # bn_train_apply for every normalised activation, propagated through concatenations / pooling / DropBlock here;
         # PPYOLO_HIP_TRAIN_MATH=bf16x3 keeps every convolution on the exact bf16 split
         self.f16 = os.environ.get('PPYOLO_HIP_TRAIN_MATH', 'f16x2') == 'f16x2'
+        # PPYOLO_HIP_TRAIN_MATH=fp32 (bench.py's value_fp32_exact leg; with PPY_WGRAD_FP32=1 and PPY_DGRAD_FP32=1 in the environment of
+        # the process): every convolution, data gradient and weight gradient on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+        self.fp32 = os.environ.get('PPYOLO_HIP_TRAIN_MATH', 'f16x2') == 'fp32'
         self._tuned_f = dict(tuned_table('f16x2')) if self.f16 else {}
         if self.f16 and os.path.exists(TRAIN_TABLE_F16):
             with open(TRAIN_TABLE_F16) as fh:
@@ -439,9 +442,10 @@ class TrainStep(object):
 
         def run(cfg_id, splitk):
             K.conv2d_bn_act(xin.view(), krsc, one, b0, get_raw().view(), stride, pad, None, cfg=cfg_id, splitk=splitk, ws=self.ws,
-                            w_x3=None if use_f16 else self._planes(ent), w_f16=ent['f16'] if use_f16 else None, amax_in=xin.amax if use_f16 else None)
+                            w_x3=None if (use_f16 or self.fp32) else self._planes(ent), w_f16=ent['f16'] if use_f16 else None,
+                            amax_in=xin.amax if use_f16 else None)
         key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
-        cfg_id, splitk = self._choose(key, run, R * S * Cp // 32, use_f16)
+        cfg_id, splitk = (-1, 0) if self.fp32 else self._choose(key, run, R * S * Cp // 32, use_f16)
         # BatchNorm statistics from the convolution's epilogue (the f16x2 kernels, one split): saves the
         # statistics kernel's pass over the raw output
         slices = 0
@@ -620,7 +624,7 @@ class TrainStep(object):
         Ho, Wo = K.dcn_out_hw(x.H, x.W, stride, 1)
         om = self.new(x.N, Ho, Wo, 27, ld=32, zero=True)
         K.conv2d_bn_act(x.view(), co['krsc'], self._vec('one', 27, 1.0), self.param(prefix + '.conv.conv_offset.bias'), om.view(), stride, 1,
-                        None, ws=self.ws, w_x3=self._planes(co))
+                        None, ws=self.ws, w_x3=None if self.fp32 else self._planes(co))
         w = self.weight(prefix + '.conv.dcn_weight')
         Kout = w['krsc'].shape[0]
         raw = self.new(x.N, Ho, Wo, Kout)
@@ -628,7 +632,8 @@ class TrainStep(object):
         ent = (self._tuned_f if use_f16 else self._tuned).get('dcnf:N%d:H%d:W%d:C%d:K%d:R3:s%d%s' % (x.N, x.H, x.W, x.C, Kout, stride,
                                                                                                 ':f' if use_f16 else ''))
         K.dcnv2(x.view(), w['krsc'], self._vec('one', Kout, 1.0), self._vec('zero', Kout, 0.0), om.view(), raw.view(), stride, 1, None,
-                self.ws, cfg=ent[0] if ent else -1, splitk=ent[1] if ent else 0, w_x3=None if use_f16 else self._planes(w), w_f16=w['f16'] if use_f16 else None,
+                self.ws, cfg=ent[0] if (ent and not self.fp32) else -1, splitk=ent[1] if (ent and not self.fp32) else 0,
+                w_x3=None if (use_f16 or self.fp32) else self._planes(w), w_f16=w['f16'] if use_f16 else None,
                 amax_in=x.amax if use_f16 else None)
         self.flops += 2 * x.N * Ho * Wo * (Kout * 9 * x.C + 27 * 9 * x.C)
         mean = torch.empty(Kout, dtype=torch.float32, device=self.dev)

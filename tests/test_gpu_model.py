@@ -273,7 +273,7 @@ def test_headline_sizes_against_reference_fixtures(golden, tag, cfgc, math, monk
     scores <= 1e-4 (north star); boxes <= the LITERAL 1e-3 px on every set where the reference agrees with itself to 1e-3 px
     (r18vd-416, both sets); where it does not (R50vd-608: its own runs are 1.2e-3 / 1.8e-3 px apart) every box within
     max(1e-3 px, 2 x the reference's own relative spread x the box side) -- the error of a box IS logit noise times its side
-    (tools/g18_dump.py + profiles/r04_g18_postmortem.txt: the reference's own decode applied to the HIP logits reproduces the
+    (tools/experiments/g18_dump.py + profiles/r04_g18_postmortem.txt: the reference's own decode applied to the HIP logits reproduces the
     HIP boxes' error to 2.4e-4 px, and the worst HIP box, 4.4e-3 px, is 4.6e-6 of its 964-px side) -- the head logits no
     further from the primary run than 2 x the reference's own runs are, and the HIP rows as close to the float64 rows as the
     reference's fp32 runs are.  The count of boxes beyond the literal 1e-3 px is printed for HIP and for the reference's runs."""
