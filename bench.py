@@ -923,6 +923,8 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help='(internal) the short eager one-lane run the PMC passes profile')
     ap.add_argument('--tune-cu-mask', default=None, help='with --autotune: measure the layers on a stream restricted to these CUs (one term of '
                     'runtime.lane_cu_masks, e.g. m256:0-127 = half of every XCD) -- the table a CU-masked lane would want')
+    ap.add_argument('--lane-phase', type=float, default=0.0, help='diagnostic: start lane 1 this fraction of a one-lane step behind lane 0 (a spin '
+                    'kernel on its stream, once, before the steady-state loop): do the lanes run in lockstep, and would an offset help?')
     ap.add_argument('--power-trace', action='store_true', help='sample rocm-smi (socket power, shader clock) during the `sustained` loop')
     ap.add_argument('--no-batch-scaling', action='store_true', help='skip roofline.batch_scaling (one lane at batch 8 / 16 / 32 on the batch-8 kernels)')
     ap.add_argument('--no-worst-case', action='store_true', help='skip the whole-step measurement in the all-pass score regime')
@@ -1021,6 +1023,24 @@ def main():
 
     for _ in range(max(a.warmup, depth)):
         step()
+    if a.lane_phase > 0 and depth > 1:
+        # one-lane step time, then a calibrated spin on lane 1's stream: lane 1 runs that far behind lane 0 from here on
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(lanes[0][1]):
+            for _ in range(5):
+                lanes[0][0].run()
+        torch.cuda.synchronize()
+        t_one = (time.perf_counter() - t0) / 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(10000000)
+        e1.record()
+        e1.synchronize()
+        per_cycle = e0.elapsed_time(e1) * 1e-3 / 1e7
+        with torch.cuda.stream(lanes[1][1]):
+            torch.cuda._sleep(int(a.lane_phase * t_one / per_cycle))
+        it[0] = 0
     # Untimed steady-state running before the clock starts: under dense 16-bit MFMA the board sits at its power cap and
     # the governor needs a moment to settle the shader clock -- K timed steps of 4 ms right after a cold
     # start would be measured at a clock the board does not sustain.  Every rank runs the same number of steps.
