@@ -271,11 +271,11 @@ class _MaskedStream(object):
 
 
 class _Lane(object):
-    def __init__(self, ex, device, cu_mask=None):
+    def __init__(self, ex, device, cu_mask=None, priority=0):
         self.ex = ex
         self._masked = None
         if cu_mask is None:
-            self.stream = torch.cuda.Stream(device=device)
+            self.stream = torch.cuda.Stream(device=device, priority=priority)
         else:
             self._masked = _MaskedStream(device, cu_mask)
             self.stream = self._masked.stream
@@ -324,7 +324,9 @@ class InFlight(object):
             if self._masks is None:
                 ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
                 self._masks = lane_cu_masks(self.cu_spec, self.depth, ncu)
-            lane = _Lane(ex, x.device, self._masks[k])
+            # PPYOLO_HIP_LANE_PRIORITY="-1,0": HIP stream priorities of the lanes (lower = dispatched first); an experiment of round 5
+            pr = [int(v) for v in os.environ.get('PPYOLO_HIP_LANE_PRIORITY', '').split(',') if v.strip()]
+            lane = _Lane(ex, x.device, self._masks[k], pr[k] if k < len(pr) else 0)
             self._lanes[key] = lane
         return lane
 
