@@ -801,17 +801,33 @@ def train_bench(a, wl, dev, rank, world):
         torch.cuda.synchronize()
     if a.pmc_child:          # profiled by pmc_traffic_leg: a few eager steps, nothing else
         for _ in range(3):
-            ts.step(x, gt, targets, lr)
+            ts.step(x, gt, targets, lr)          # (plain steps: the counters are per kernel, not per overlap)
         torch.cuda.synchronize()
         return
-    for _ in range(max(1, a.warmup)):
-        losses.append(ts.step(x, gt, targets, lr))
+    # Round 5: the loop hands step() the NEXT batch as well (a loader has it): with the backbone frozen (freeze_at = 5) its
+    # training-mode forward runs on a third stream beside this batch's head / loss / backward (TrainStep.prefetch_backbone) -- every
+    # step still computes everything, results are bit-identical to the plain loop (tests/test_gpu_train_step.py).  --no-prefetch:
+    # the plain loop, which is also timed afterwards as `one_step_at_a_time`.
+    pre = not a.no_prefetch
+
+    def loop(n, prefetch):
+        for _ in range(n):
+            losses.append(ts.step(x, gt, targets, lr, next_x=x if prefetch else None))
+    loop(max(1, a.warmup), pre)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses.append(ts.step(x, gt, targets, lr))
+    loop(a.steps, pre)
     barrier()
     dt = time.perf_counter() - t0
+    dt_plain = None
+    if pre and world == 1:
+        ts._pref = None
+        loop(2, False)
+        barrier()
+        t1 = time.perf_counter()
+        loop(a.steps, False)
+        barrier()
+        dt_plain = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -835,13 +851,18 @@ def train_bench(a, wl, dev, rank, world):
                                math=('f16x2 (two fp16 terms after power-of-two scaling by tracked maxima, 3 MFMA products, fp32 accumulate) for the '
                                      'forward convolutions, the data and the weight gradients' if ts.f16 else
                                      'bf16x3 (exact 3-term bf16 split, 6 products) for every convolution and gradient'), eager=True),
-                   loss_first=round(tot[0], 4), loss_last=round(tot[-1], 4),
+                   loss_first=round(tot[0], 4), loss_last=round(tot[min(len(tot), max(1, a.warmup) + a.steps) - 1], 4),
+                   pipelining=('the next batch\'s frozen-backbone forward runs beside this batch\'s head / loss / backward (step(next_x=)); '
+                               'bit-identical to the plain loop' if (pre and ts.freeze_at == 5) else 'none'),
                    roofline=dict(bound='mfma', achieved=round(ach, 2), peak=round(F16X2_PEAK_TFLOPS if ts.f16 else X3_PEAK_TFLOPS, 1), unit='TFLOP/s',
                                  frac=round(ach / (F16X2_PEAK_TFLOPS if ts.f16 else X3_PEAK_TFLOPS), 4), traffic=None, flops_per_step=flops,
                                  kernel='conv_igemm_x3_kernel<*> forward + dgrad, conv_wgrad_x3_kernel<F16> (%s)' % ('f16x2' if ts.f16 else 'bf16x3'),
                                  peak_note='achieved = algorithmic convolution FLOPs of forward + backward / WHOLE step time (BatchNorm, loss, '
                                            'SGD, EMA and launch gaps included: the step is not graph-captured); peak = dense 16-bit MFMA / %d '
                                            'products per multiply-add' % (3 if ts.f16 else 6)))
+        if dt_plain is not None:
+            out['one_step_at_a_time'] = dict(value=round(world * a.batch * a.steps / dt_plain, 2), unit='images/s', ms_per_step=round(dt_plain / a.steps * 1e3, 3),
+                                             note='the plain loop: step(x) without the next batch (what the reference\'s loop does, train.py:416-443)')
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = train_cpu_baseline(sd, cfg, x, gt, targets)
         # `value_fp32_exact` (round 5): the same step with every convolution, data gradient and weight gradient on the exact-fp32 MFMA
@@ -923,6 +944,7 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help='(internal) the short eager one-lane run the PMC passes profile')
     ap.add_argument('--tune-cu-mask', default=None, help='with --autotune: measure the layers on a stream restricted to these CUs (one term of '
                     'runtime.lane_cu_masks, e.g. m256:0-127 = half of every XCD) -- the table a CU-masked lane would want')
+    ap.add_argument('--no-prefetch', action='store_true', help='--train: the plain loop (no backbone prefetch of the next batch)')
     ap.add_argument('--lane-phase', type=float, default=0.0, help='diagnostic: start lane 1 this fraction of a one-lane step behind lane 0 (a spin '
                     'kernel on its stream, once, before the steady-state loop): do the lanes run in lockstep, and would an offset help?')
     ap.add_argument('--power-trace', action='store_true', help='sample rocm-smi (socket power, shader clock) during the `sustained` loop')

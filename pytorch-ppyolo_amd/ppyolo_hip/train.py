@@ -203,6 +203,15 @@ class TrainStep(object):
         self._measured = {}
         self._nbt = []                      # keys of the BatchNorm step counters touched by this forward (bumped in one launch)
         self._nbt_flat, self._nbt_keys = None, None
+        # Round 5: with the whole backbone frozen (freeze_at = 5, the reference's configurations) its training-mode forward reads no
+        # trainable parameter, so the NEXT batch's backbone can run on a third stream beside THIS batch's head forward / loss /
+        # backward (prefetch_backbone, step(..., next_x=...)): same kernels on the same inputs in the same order per tensor --
+        # bit-identical losses, gradients and running statistics -- with its own workspace, BatchNorm partials and (two alternating)
+        # blocks of tracked-maximum slots.  PPYOLO_HIP_TRAIN_PREFETCH=0 ignores next_x.
+        self._prefetch_on = os.environ.get('PPYOLO_HIP_TRAIN_PREFETCH', '1') == '1'
+        self._bstream = None
+        self._pref = None
+        self._b_res = None                  # [ws, bn_part, [arena0, arena1], which]
 
     @staticmethod
     def _stage_of(key):
@@ -897,12 +906,62 @@ class TrainStep(object):
             self._amax_arena.zero_()
             self._amax_next = 0
         self.masks = list(dropblock_masks) if dropblock_masks is not None else None
+        pref, self._pref = self._pref, None
         with torch.no_grad():
             if self.external:
                 self._pull_params()
             self._prepare_weights()
-            feats = self.backbone(x_nchw.float().contiguous())
+            if pref is not None and pref['key'] == self._pref_key(x_nchw):
+                # the backbone of this batch ran on the side stream during the previous step
+                main = torch.cuda.current_stream(self.dev)
+                main.wait_event(pref['event'])
+                feats = pref['feats']
+                for f in feats:
+                    f.t.record_stream(main)          # (allocated under the side stream: not to be reused before the head has read it)
+                self._nbt = list(pref['nbt']) + self._nbt
+                self.flops += pref['flops']
+            else:
+                feats = self.backbone(x_nchw.float().contiguous())
         return self.head_loss_backward(feats, gt_box, targets, inject_douts)
+
+    @staticmethod
+    def _pref_key(x):
+        return (x.data_ptr(), tuple(x.shape), x._version)
+
+    def prefetch_backbone(self, x_next, ready=None):
+        """Enqueue the frozen backbone's training-mode forward of the NEXT batch on the side stream (freeze_at = 5 only; else a
+        no-op).  `ready`: an event after which x_next may be read (default: everything issued on the current stream so far --
+        call this BEFORE issuing the current batch's work if x_next is ready earlier; step(..., next_x=) does).  The next
+        forward_backward(x_next, ...) picks the features up if x_next is still the same tensor, unmodified."""
+        if not self._prefetch_on or self.freeze_at != 5 or self.external or self.tune or self.acts is not None:
+            return False
+        if self._bstream is None:
+            self._bstream = torch.cuda.Stream(device=self.dev)
+            self._b_res = [torch.empty_like(self.ws), None, [None, None], 0]
+        main = torch.cuda.current_stream(self.dev)
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        res = self._b_res
+        res[3] ^= 1
+        saved = (self.ws, self._bn_part, self._amax_arena, self._amax_next, self._nbt, self.flops, self.tape)
+        self._bstream.wait_event(ready)
+        try:
+            with torch.cuda.stream(self._bstream), torch.no_grad():
+                self.ws, self._bn_part = res[0], res[1]
+                self._amax_arena, self._amax_next = res[2][res[3]], 0
+                if self._amax_arena is not None:
+                    self._amax_arena.zero_()
+                self._nbt, self.flops, self.tape = [], 0, []
+                feats = self.backbone(x_next.float().contiguous())
+                assert not self.tape, 'prefetch_backbone: a frozen backbone records no backward'
+                ev = torch.cuda.Event()
+                ev.record(self._bstream)
+                self._pref = dict(key=self._pref_key(x_next), feats=feats, event=ev, nbt=self._nbt, flops=self.flops)
+                res[1], res[2][res[3]] = self._bn_part, self._amax_arena
+        finally:
+            self.ws, self._bn_part, self._amax_arena, self._amax_next, self._nbt, self.flops, self.tape = saved
+        return True
 
     def head_loss_backward(self, feats, gt_box, targets, inject_douts=None):
         """Head forward on the given backbone features (list of Act, shallowest first), loss, backward, -> loss terms [6]."""
@@ -1074,10 +1133,19 @@ class TrainStep(object):
         if self.use_ema:
             self.ema_steps += 1
 
-    def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None):
+    def step(self, x_nchw, gt_box, targets, lr, dropblock_masks=None, next_x=None):
+        """One iteration of the reference's loop (train.py:416-443).  next_x: the NEXT iteration's images, if the loader already has
+        them (round 5): with the backbone frozen their backbone forward runs beside this iteration's head, loss and backward
+        (prefetch_backbone) and the next step(next_x, ...) finds it done -- results are those of the plain loop, bit for bit."""
         if self.external:
             raise PPYoloHipError('external_optimizer: the caller owns the update (loss.backward(); optimizer.step())')
+        ready = None
+        if next_x is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.dev))      # next_x is ready here, before this step's kernels are issued
         loss6 = self.forward_backward(x_nchw, gt_box, targets, dropblock_masks)
+        if next_x is not None:
+            self.prefetch_backbone(next_x, ready)
         self.all_reduce()
         self.sgd(lr)
         return loss6
@@ -1106,6 +1174,8 @@ class TrainStep(object):
         """Write the trained parameters (kept flat, in kernel layout, during training) back into the module; `ema=True` writes
         the EMA shadows instead -- what the reference evaluates and saves after ema.apply() (train.py:476-500)."""
         self._await_params()
+        if self._bstream is not None:       # a prefetched backbone forward may still be writing BatchNorm running statistics
+            torch.cuda.current_stream(self.dev).wait_stream(self._bstream)
         src = self.sflat if ema else self.pflat
         if ema and src is None:
             raise PPYoloHipError('EMA is off (cfg.use_ema)')
