@@ -819,8 +819,11 @@ def train_bench(a, wl, dev, rank, world):
     loop(a.steps, pre)
     barrier()
     dt = time.perf_counter() - t0
+    if a.dump_dets and rank == 0:                       # tests: the averaged gradients of the last timed step
+        torch.cuda.synchronize()
+        np.save(a.dump_dets, ts.gflat.cpu().numpy())
     dt_plain = None
-    if pre and world == 1:
+    if pre and world == 1 and not a.dump_dets:
         ts._pref = None
         loop(2, False)
         barrier()
@@ -832,8 +835,6 @@ def train_bench(a, wl, dev, rank, world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    if a.dump_dets and rank == 0:                       # tests: the averaged gradients of the last step
-        np.save(a.dump_dets, ts.gflat.cpu().numpy())
     if rank == 0:
         tot = [float(l.sum()) for l in losses]
         flops = ts.flops

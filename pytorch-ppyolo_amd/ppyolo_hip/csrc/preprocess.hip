@@ -129,12 +129,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs p) {
 //            as 16-byte LDS reads, FixedPtCast, the normalisation table from LDS, one 16-byte store per channel.
 // Integer arithmetic is exact and the float expressions are the pixel kernel's own functions, so the result is bit-identical
 // (tests/test_preprocess.py compares both kernels with the numpy oracle).
-constexpr int PRE_TW = 128, PRE_MAXROWS = 24, PRE_MAXR = 16;      // 40 KB of LDS: four workgroups per CU (40 rows / 32: two, 27 -> 21 us)
+constexpr int PRE_TW = 128;      // output columns of a tile; rows: template parameters (MAXROWS source rows in LDS, MAXR output rows, U rows of loads in flight)
 struct PreTileArgs {
     PreArgs a;
     int rows_per_tile[PRE_MAX_IMAGES];
 };
 
+template <int PRE_MAXROWS, int PRE_U>
 __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs p) {
     __shared__ int s_h[PRE_MAXROWS][3][PRE_TW];
     __shared__ float s_lut[3 * 256];
@@ -162,7 +163,6 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs 
             for (int j = 0; j < 4; ++j) cj[j] = min(max(sx - 1 + j, 0), im.w - 1) * 3;
             // PRE_U rows per pass, all their loads in flight together (one row at a time left every thread in a chain of dependent
             // ~1 us loads: the phase was latency-bound)
-            constexpr int PRE_U = 4;
             for (int rb = lane; rb < nrows; rb += 2 * PRE_U) {
                 unsigned px[PRE_U][3];
 #pragma unroll
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs 
 
 // output rows per tile such that the source rows a tile touches fit PRE_MAXROWS: first_tap is monotone, and rows dy0 .. dy0 + R - 1
 // touch at most ceil((R - 1) * scale) + 1 (float rounding of the map) + 4 (taps) source rows
-static int rows_for(double scale_y) {
-    int R = PRE_MAXR;
-    while (R > 1 && (long long)__builtin_ceil((R - 1) * scale_y) + 6 > PRE_MAXROWS) --R;
+static int rows_for(double scale_y, int maxr, int maxrows) {
+    int R = maxr;
+    while (R > 1 && (long long)__builtin_ceil((R - 1) * scale_y) + 6 > maxrows) --R;
     return R;
 }
 
@@ -289,14 +289,23 @@ extern "C" int ppy_preprocess_u8_f32(int n, const unsigned char *const *images, 
             hipLaunchKernelGGL(preprocess_kernel, dim3(ceil_div(S, 64), ceil_div(S, 4), cnt), dim3(256), 0, (hipStream_t)stream, a);
             continue;
         }
+        // tile variants (PPY_PRE_VARIANT, read per call; default 0): 0 = 16 output rows / 24 source rows in LDS (40 KB: four workgroups
+        // per CU) with four rows of loads in flight; 1 = the same with eight; 2 = 32 / 40 rows (two workgroups per CU); 3 = 8 / 16 rows
+        const char *ev = getenv("PPY_PRE_VARIANT");
+        const int variant = ev ? atoi(ev) : 0;
+        const int maxr = variant == 2 ? 32 : (variant == 3 ? 8 : 16), maxrows = variant == 2 ? 40 : (variant == 3 ? 16 : 24);
         PreTileArgs t;
         t.a = a;
-        int rmin = PRE_MAXR;
+        int rmin = maxr;
         for (int i = 0; i < cnt; ++i) {
-            t.rows_per_tile[i] = rows_for(a.img[i].scale_y);
+            t.rows_per_tile[i] = rows_for(a.img[i].scale_y, maxr, maxrows);
             rmin = t.rows_per_tile[i] < rmin ? t.rows_per_tile[i] : rmin;
         }
-        hipLaunchKernelGGL(preprocess_tile_kernel, dim3(ceil_div(S, PRE_TW), ceil_div(S, rmin), cnt), dim3(256), 0, (hipStream_t)stream, t);
+        const dim3 grid(ceil_div(S, PRE_TW), ceil_div(S, rmin), cnt);
+        if (variant == 1) hipLaunchKernelGGL((preprocess_tile_kernel<24, 8>), grid, dim3(256), 0, (hipStream_t)stream, t);
+        else if (variant == 2) hipLaunchKernelGGL((preprocess_tile_kernel<40, 4>), grid, dim3(256), 0, (hipStream_t)stream, t);
+        else if (variant == 3) hipLaunchKernelGGL((preprocess_tile_kernel<16, 4>), grid, dim3(256), 0, (hipStream_t)stream, t);
+        else hipLaunchKernelGGL((preprocess_tile_kernel<24, 4>), grid, dim3(256), 0, (hipStream_t)stream, t);
     }
     return ppy_launch_status();
 }

@@ -935,6 +935,10 @@ class TrainStep(object):
         forward_backward(x_next, ...) picks the features up if x_next is still the same tensor, unmodified."""
         if not self._prefetch_on or self.freeze_at != 5 or self.external or self.tune or self.acts is not None:
             return False
+        if self.world > 1 and not self.overlap:
+            # data-parallel ranks under RCCL: the gradient all-reduce is kept clear of this rank's MFMA kernels unless the overlap is
+            # opted into (PPYOLO_HIP_TRAIN_OVERLAP=1, see __init__) -- a prefetched backbone would run beside it
+            return False
         if self._bstream is None:
             self._bstream = torch.cuda.Stream(device=self.dev)
             self._b_res = [torch.empty_like(self.ws), None, [None, None], 0]
