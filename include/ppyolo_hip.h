@@ -484,6 +484,22 @@ int ppy_nms_candidates_f32(const float *scores, int N, int M, int C, float score
                            void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * conv2 -> conv3 of an identity bottleneck in ONE launch (round 5; reference model/resnet_vd.py:81-87:
+ * relu(bn3(conv3(relu(bn2(conv2(t))))) + x)): conv A = 3x3 / stride 1 / pad 1, CA -> KA, BatchNorm, ReLU; conv B = 1x1, KA -> KB,
+ * BatchNorm, + residual, ReLU.  The KA-channel intermediate stays on chip (csrc/conv_b2b.hip).  x_split: conv A's input as its
+ * producer stored it pre-split (ppy_conv2d_bn_act_split_f32), xscale its [N] per-image scales, amax_in the tracked max|.| of that
+ * tensor.  wA / wB + scaleA / scaleB: outputs of ppy_conv2d_split_weights_f16x2 for the two weight tensors; shiftA / shiftB the
+ * folded BatchNorm shifts.  t_mul, t_add: static bound |intermediate| <= t_mul * max|x| + t_add (per-image operand scale of the
+ * second contraction).  pool (or NULL) / pool_ld: [N, H/2, W/2, pool_ld] receives AvgPool2d(2, 2) of y as well (the vd shortcut of the
+ * next stage, reference model/resnet_vd.py:29-33; H, W even), evaluated (((a + b) + c) + d) * 0.25 as ppy_avgpool2x2_f32.
+ * Supported: CA = KA = 64, KB = 256 (stage 2 of ResNet50-vd); else PPY_ERR_UNSUPPORTED.  f16x2 arithmetic as
+ * ppy_conv2d_bn_act_f32; agrees with the two-launch form to fp32 rounding. */
+int ppy_conv3x3_conv1x1_f32(const float *x_split, int x_ld, const float *xscale, const float *amax_in, const void *wA_f16x2,
+                            const float *scaleA_f16x2, const float *shiftA, const void *wB_f16x2, const float *scaleB_f16x2,
+                            const float *shiftB, const float *residual, int res_ld, float *y, int y_ld, float *pool, int pool_ld, int N,
+                            int H, int W, int CA, int KA, int KB, float t_mul, float t_add, float *amax_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Lanes.  The reference evaluates one batch at a time (model/ppyolo.py:19-22, called from model/decode_np.py:142-150); this
  * path keeps several batches on the device at once, each on its own stream ("lane", ppyolo_hip/runtime.py InFlight).
  * ppy_lane_stream_create makes such a stream: mask_words == 0 -> an ordinary non-blocking stream; else h_cu_mask (HOST memory,

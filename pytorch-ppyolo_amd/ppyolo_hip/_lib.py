@@ -114,6 +114,8 @@ _PROTOS = {
     'ppy_matrix_nms_workspace_bytes': (c_size_t, [c_int]),
     'ppy_nms_candidates_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                        c_int, c_void_p]),
+    'ppy_conv3x3_conv1x1_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 6 + [c_float, c_float, c_void_p, c_void_p]),
     'ppy_lane_stream_create': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_uint32), c_int]),
     'ppy_lane_stream_destroy': (c_int, [c_void_p]),
 }

@@ -361,6 +361,42 @@ def split_pairs(ops, op_io, buffers, pinned, has_f16, only_3x3=False):
     return pairs
 
 
+def b2b_pairs(ops, op_io, buffers, pinned, has_f16):
+    """Host logic of HipExecutor._mark_b2b, device-free: [(conv A, conv B)] that ppy_conv3x3_conv1x1_f32 can run as ONE launch --
+    conv2 -> conv3 of an identity bottleneck (reference model/resnet_vd.py:81-87): A = 3x3 / stride 1 / pad 1, 64 -> 64, ReLU, no
+    shortcut / position bias / upsampling, writing a whole buffer that ONLY B reads; B = 1x1 / stride 1, 64 -> 256, ReLU, with a
+    shortcut, no position bias / upsampling."""
+    readers, writers = {}, {}
+    for op in ops:
+        ins, outs = op_io(op)
+        for b in ins:
+            readers.setdefault(b, []).append(op)
+        for b in outs:
+            writers.setdefault(b, []).append(op)
+    out = []
+    for a in ops:
+        if a['op'] != 'conv' or not has_f16(a):
+            continue
+        Ka, R, S, Ca = a['w'].shape
+        y = a['y']
+        if (R, S, a['stride'], a['pad'], Ca, Ka, a['act']) != (3, 3, 1, 1, 64, 64, 'relu') or a['res'] is not None or a['posb'] is not None \
+                or a['ups'] or a.get('pool') is not None or a.get('mpool') is not None or y.buf in pinned \
+                or y.coff != 0 or y.C != buffers[y.buf][3] or len(writers.get(y.buf, [])) != 1:
+            continue
+        rd = readers.get(y.buf, [])
+        if len(rd) != 1 or rd[0]['op'] != 'conv':
+            continue
+        b = rd[0]
+        Kb, Rb, Sb, Cb = b['w'].shape
+        x = b['x']
+        if (Rb, Sb, b['stride'], b['pad'], Cb, Kb, b['act']) != (1, 1, 1, 0, 64, 256, 'relu') or b['res'] is None or b['posb'] is not None \
+                or b['ups'] or not has_f16(b) or (x.buf, x.coff, x.C) != (y.buf, 0, 64) or b['res'].buf == y.buf \
+                or b.get('stream', 0) != a.get('stream', 0):
+            continue
+        out.append((a, b))
+    return out
+
+
 # =========================================================================================
 class HipExecutor(object):
     """Binds a Plan to device buffers and replays it through libppyolo_hip.so."""
@@ -469,6 +505,7 @@ class HipExecutor(object):
             if op.get('posb') is not None:
                 used.add(op['posb'].buf)
         used.update(a.buf for a in list(p.feats) + list(p.head_outs))
+        used.update(op['y'].buf for op in p.ops if op['op'] == 'conv')          # (also behind a fused pair: the plan may fall back to two launches)
         self.bufs = []
         for i, (N, H, W, ld) in enumerate(p.buffers):
             if i in p.consts:
@@ -559,10 +596,13 @@ class HipExecutor(object):
         of |y| -- per output channel |scale| * sum|w| times the input's tracked maximum, plus |shift| and the CoordConv bias --
         so the producer needs no second pass.  Bottleneck conv1 -> conv2 (3x3) and the head's 1x1 -> 3x3 pairs qualify."""
         self._unlink_splits()
+        self._mark_b2b()
         n = 0
         for pr, cons in self._split_pairs():
+            if pr.get('b2b') is not None or pr.get('b2b_of') is not None:
+                continue          # (the fused pair's output is plain fp32: it is a shortcut as well)
             if pr.get('splitk', 0) > 1 or not self._split_capable(pr['cfg'], False) \
-                    or any(c.get('splitk', 0) > 1 or not self._split_capable(c['cfg'], True) for c in cons):
+                    or any(c.get('b2b') is None and (c.get('splitk', 0) > 1 or not self._split_capable(c['cfg'], True)) for c in cons):
                 continue          # (every reader must take the tensor in that form, or none does)
             w, sc, sh = pr['w'], pr['scale'], pr['shift']
             l1 = w.abs().double().sum(dim=(1, 2, 3))
@@ -577,7 +617,49 @@ class HipExecutor(object):
             for c in cons:
                 c['x_split'] = ps
                 n += 1
+        # a fused pair needs its input pre-split (csrc/conv_b2b.hip reads finished operands): without the link it is two launches again
+        undone = False
+        for op in self.plan.ops:
+            if op.get('b2b') is not None and op.get('x_split') is None:
+                op['b2b'].pop('b2b_of', None)
+                op.pop('b2b', None)
+                undone = True
+        if undone:      # (the links were derived with the pair fused: its stand-alone form may allow others)
+            return self._link_splits_plain()
         return n
+
+    def _link_splits_plain(self):
+        """_link_splits without (re-)marking fused pairs: the fall-back when a marked pair did not get its pre-split input."""
+        keep, self._b2b_off = getattr(self, '_b2b_off', False), True
+        try:
+            return self._link_splits()
+        finally:
+            self._b2b_off = keep
+
+    def _unlink_b2b(self):
+        for op in self.plan.ops:
+            if op.get('b2b') is not None:
+                op['b2b'].pop('b2b_of', None)
+                op.pop('b2b', None)
+
+    def _mark_b2b(self):
+        """conv2 -> conv3 of an identity bottleneck as ONE launch (round 5, csrc/conv_b2b.hip; PPYOLO_HIP_B2B=0: two launches): the
+        64-channel tensor between them is neither written nor read.  The static bound of the intermediate (per-image operand scale
+        of the second contraction) is derived as for a pre-split link."""
+        self._unlink_b2b()
+        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_B2B', '1') != '1' or getattr(self, '_b2b_off', False):
+            return 0
+        pinned = {a.buf for a in list(self.plan.head_outs) + list(self.plan.feats)}
+        pairs = b2b_pairs(self.plan.ops, self._op_io, self.plan.buffers, pinned,
+                          lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None)
+        for a, b in pairs:
+            if a.get('t_bound') is None:
+                w, sc, sh = a['w'], a['scale'], a['shift']
+                l1 = w.abs().double().sum(dim=(1, 2, 3))
+                a['t_bound'] = (float((sc.abs().double() * l1).max()) * (1.0 + 2.0 ** -8), float(sh.abs().double().max()) * (1.0 + 2.0 ** -8) + 1e-30)
+            a['b2b'] = b
+            b['b2b_of'] = a
+        return len(pairs)
 
     def presplit_headroom(self):
         """Diagnostic (host sync; after a run): for every pre-split link and image, (key of the producer, log2 of the SCALED
@@ -635,6 +717,11 @@ class HipExecutor(object):
     def _op_io(op):
         """(input buffer ids, output buffer ids) of a plan op."""
         t = op['op']
+        if t == 'conv' and op.get('b2b_of') is not None:         # computed inside the launch of the convolution in front of it (_mark_b2b)
+            return [], []
+        if t == 'conv' and op.get('b2b') is not None:
+            b = op['b2b']
+            return [op['x'].buf, b['res'].buf], [b['y'].buf] + ([b['pool'].buf] if b.get('pool') is not None else [])
         if t == 'conv':
             ins = [op['x'].buf] + ([op['res'].buf] if op['res'] is not None else [])
             if op.get('mpool') is not None:          # only the pooled tensor is written (_link_maxpools)
@@ -683,6 +770,14 @@ class HipExecutor(object):
     def _run_op(self, op, ws=None):
         t = op['op']
         ws = self.ws if ws is None else ws
+        if t == 'conv' and op.get('b2b_of') is not None:
+            return                  # (computed by the launch of the convolution in front of it)
+        if t == 'conv' and op.get('b2b') is not None:
+            b = op['b2b']
+            K.conv3x3_conv1x1(self.view(op['x']), op['x_split'], self._amax(op['amax_in_id']), op['wf16'], op['shift'], b['wf16'], b['shift'],
+                              self.view(b['res']), self.view(b['y']), op['t_bound'][0], op['t_bound'][1], self._amax(b.get('amax_out_id')),
+                              None if b.get('pool') is None else self.view(b['pool']))
+            return
         if t == 'conv' and op.get('pool') is not None and self._stream_first() <= op['cfg'] < self._stream_first() + 2:
             K.conv1x1_expand(self.view(op['x']), op['wf16'], op['shift'], self.view(op['y']), op['act'],
                              None if op['res'] is None else self.view(op['res']), self.view(op['pool']),
@@ -801,6 +896,7 @@ class HipExecutor(object):
         splits = (1, 2, 3, 4, 6, 8, 9, 12, 16)
         report = []
         self._unlink_splits()          # (layers are measured on plain fp32 tensors; the links are re-derived from the new choices)
+        self._unlink_b2b()
         with torch.cuda.device(self.device):
             big = 0
             for op in self.plan.ops:
@@ -898,6 +994,7 @@ class HipExecutor(object):
         other lane can finish the pair sooner.  Measured, R50-608 bs8, two lanes: +0.6 %."""
         import time
         self._unlink_splits()
+        self._unlink_b2b()
         with torch.cuda.device(self.device):
             sa, sb = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
             with torch.cuda.stream(sb):

@@ -147,6 +147,19 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
     check(rc, 'ppy_conv2d_bn_act_f32')
 
 
+def conv3x3_conv1x1(x, x_split, amax_in, wA_f16, shiftA, wB_f16, shiftB, residual, y, t_mul, t_add, amax_out=None, pool=None):
+    """conv2 -> conv3 of an identity bottleneck in one launch (ppy_conv3x3_conv1x1_f32, csrc/conv_b2b.hip).  x: View of the
+    PRE-SPLIT input, x_split its [N] scales; wA_f16 / wB_f16: split_weights_f16x2 results; residual, y: Views; pool: View that
+    receives AvgPool2d(2, 2) of y, or None."""
+    _dev(x.t, x_split, amax_in, wA_f16[0], wA_f16[1], shiftA, wB_f16[0], wB_f16[1], shiftB, residual.t, y.t)
+    KA, KB = shiftA.numel(), shiftB.numel()
+    check(lib().ppy_conv3x3_conv1x1_f32(x.ptr, x.ld, x_split.data_ptr(), amax_in.data_ptr(), wA_f16[0].data_ptr(), wA_f16[1].data_ptr(),
+                                        shiftA.data_ptr(), wB_f16[0].data_ptr(), wB_f16[1].data_ptr(), shiftB.data_ptr(), residual.ptr,
+                                        residual.ld, y.ptr, y.ld, None if pool is None else pool.ptr, 0 if pool is None else pool.ld, x.N, x.H, x.W, x.C, KA, KB,
+                                        float(t_mul), float(t_add), _p(amax_out),
+                                        _stream()), 'ppy_conv3x3_conv1x1_f32')
+
+
 def stream_first_cfg():
     """First conv cfg id of the streaming 1x1 kernel (csrc/conv_stream.hip; + variant 0 / 1)."""
     return lib().ppy_conv2d_stream_first_config()

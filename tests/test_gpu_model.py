@@ -498,6 +498,38 @@ def test_cu_masked_lanes_match_forward(spec, depth):
             assert torch.equal(ex.out_dets[i, :max(n, 1)], w) or (n == 0 and w[0, 0] == -1)
 
 
+def test_b2b_pairs_in_the_plan_and_same_detections(monkeypatch):
+    """Round 5: conv2 -> conv3 of stage 2's two identity bottlenecks run as one launch each (csrc/conv_b2b.hip).  The R50vd plan has
+    exactly those two pairs fused (with their conv1 -> conv2 tensors still pre-split), the feature maps agree with the two-launch
+    plan to fp32 rounding and the detections are the same rows in the same order."""
+    cfg = PPYOLO_2x_Config()
+    N, S = 2, 320
+    x, ims = synth.synth_images(N, S, seed=77).cuda(), synth.synth_im_size(N).cuda()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('PPYOLO_HIP_B2B', mode)
+        model, _ = build_model(cfg, 0, 'cuda')
+        # (the table knows the bench geometry only: give the stage-2 layers of this size f16x2 tiles that read / write pre-split tensors)
+        ex = model._plans.executor(x)
+        for op in ex.plan.ops:
+            if op['op'] == 'conv' and op['x'].H == S // 4 and op['cfg'] < 0 and op.get('wf16') is not None and op.get('amax_in_id') is not None:
+                op['cfg'], op['splitk'] = 44, 1
+        ex._size_workspace()
+        ex._link_splits()
+        ex.invalidate_graph()
+        fused = [op for op in ex.plan.ops if op.get('b2b') is not None]
+        assert len(fused) == (2 if mode == '1' else 0)
+        assert all(op.get('x_split') is not None for op in fused)
+        preds = model(x, ims)
+        feats = [ex.view(f).dense().clone() for f in ex.plan.feats]
+        res[mode] = ([p.clone() for p in preds], feats)
+    for a, b in zip(res['0'][1], res['1'][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    for a, b in zip(res['0'][0], res['1'][0]):
+        assert a.shape == b.shape and torch.equal(a[:, 0], b[:, 0])
+        assert float((a[:, 1] - b[:, 1]).abs().max()) <= 1e-5 and float((a[:, 2:] - b[:, 2:]).abs().max()) <= 2e-3
+
+
 def test_forward_beside_open_tickets():
     """InFlight owns its executors: a plain model(x) call while tickets are open neither disturbs the batches in flight
     nor is disturbed by them (lane 0 used to be the executor of forward itself)."""

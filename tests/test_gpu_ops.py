@@ -1184,6 +1184,77 @@ def test_stem_conv_with_maxpool_from_the_epilogue_is_the_two_launches():
 
 
 # ------------------------------------------------------------------------------------------
+# conv2 -> conv3 of an identity bottleneck in one launch (round 5, csrc/conv_b2b.hip)
+@pytest.mark.parametrize('N,H,W,pool', [(2, 19, 19, False), (3, 24, 40, False), (1, 76, 76, False), (4, 8, 8, False),
+                                        (3, 24, 40, True), (1, 76, 76, True), (4, 8, 8, True), (2, 6, 10, True)])
+def test_conv3x3_conv1x1_matches_two_launches_and_fp64(N, H, W, pool):
+    """relu(bn3(conv3(relu(bn2(conv2(t))))) + x) with t pre-split by conv1 (reference model/resnet_vd.py:81-87), ONE launch
+    (ppy_conv3x3_conv1x1_f32) against the two-launch form and float64: error vs float64 no larger than 1.5 x the two launches'
+    (fp32-grade), the tracked maxima equal to max|y| per image, tiles that straddle rows / images / the end of the tensor
+    (M = 722, 2880, 5776, 256), images of very different magnitude and an all-zero image.  pool: the tile's rows are 2x2 blocks and
+    AvgPool2d(2, 2) of the output is written too -- bit-equal to (((a + b) + c) + d) * 0.25 of the y the same launch stored."""
+    from ppyolo_hip import ops
+    g = torch.Generator().manual_seed(23 + H)
+    f0 = 40
+    C = 256
+    x = torch.relu(torch.randn(N, H, W, C, generator=g))
+    if N > 1:
+        x[1] *= 200.0
+    if N > 2:
+        x[2] = 0.0
+    w1 = torch.randn(64, 1, 1, C, generator=g) * (2.0 / C) ** 0.5
+    w2 = torch.randn(64, 3, 3, 64, generator=g) * (2.0 / 576) ** 0.5
+    w3 = torch.randn(256, 1, 1, 64, generator=g) * (2.0 / 64) ** 0.5
+    sc = [torch.rand(k, generator=g) + 0.5 for k in (64, 64, 256)]
+    sh = [torch.randn(k, generator=g) * 0.1 for k in (64, 64, 256)]
+    t = torch.relu(torch.einsum('nhwc,kc->nhwk', x.double(), w1[:, 0, 0].double()) * sc[0].double() + sh[0].double())
+    t = F.conv2d(t.permute(0, 3, 1, 2), w2.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    t = torch.relu(t * sc[1].double() + sh[1].double())
+    ref = torch.relu(torch.einsum('nhwc,kc->nhwk', t, w3[:, 0, 0].double()) * sc[2].double() + sh[2].double() + x.double())
+
+    def run(fused):
+        xd = x.cuda()
+        t1, t2, out = torch.zeros(N, H, W, 64).cuda(), torch.zeros(N, H, W, 64).cuda(), torch.full((N, H, W, 256), float('nan')).cuda()
+        a_in, a1, a2, a_out = ops.amax_slots(xd), ops.amax_slots(N=N, device='cuda'), ops.amax_slots(N=N, device='cuda'), ops.amax_slots(N=N, device='cuda')
+        wd = [w.cuda() for w in (w1, w2, w3)]
+        scd, shd = [v.cuda() for v in sc], [v.cuda() for v in sh]
+        fs = [ops.split_weights_f16x2(w, s_) for w, s_ in zip(wd, scd)]
+        mul = float((sc[0].abs().double() * w1.abs().double().sum(dim=(1, 2, 3))).max()) * (1 + 2.0 ** -8)
+        ys = (torch.ones(N).cuda(), mul, float(sh[0].abs().max()) * (1 + 2.0 ** -8))
+        ops.conv2d_bn_act(ops.View(xd), wd[0], scd[0], shd[0], ops.View(t1), 1, 0, 'relu', None, None, False, f0 + 4, 1, None, None, fs[0], a_in, a1,
+                          None, None, ys)
+        if fused:
+            tm = float((sc[1].abs().double() * w2.abs().double().sum(dim=(1, 2, 3))).max()) * (1 + 2.0 ** -8)
+            pl = torch.full((N, H // 2, W // 2, 256), float('nan')).cuda() if pool else None
+            ops.conv3x3_conv1x1(ops.View(t1), ys[0], a1, fs[1], shd[1], fs[2], shd[2], ops.View(xd), ops.View(out), tm,
+                                float(sh[1].abs().max()) * (1 + 2.0 ** -8), a_out, None if pl is None else ops.View(pl))
+            if pool:
+                o = out
+                want = (((o[:, 0::2, 0::2] + o[:, 0::2, 1::2]) + o[:, 1::2, 0::2]) + o[:, 1::2, 1::2]) * 0.25
+                assert torch.equal(pl, want)
+        else:
+            ops.conv2d_bn_act(ops.View(t1), wd[1], scd[1], shd[1], ops.View(t2), 1, 1, 'relu', None, None, False, f0 + 4, 1, None, None, fs[1], a1, a2,
+                              None, ys[0], None)
+            ops.conv2d_bn_act(ops.View(t2), wd[2], scd[2], shd[2], ops.View(out), 1, 0, 'relu', ops.View(xd), None, False, f0 + 4, 1, None, None, fs[2],
+                              a2, a_out)
+        torch.cuda.synchronize()
+        return out.cpu().double(), a_out.view(N, -1).amax(dim=1).cpu()
+    two, mx_two = run(False)
+    one, mx_one = run(True)
+    assert torch.isfinite(one).all()
+    for n in range(N):
+        den = ref[n].abs().max().clamp_min(1e-30)
+        e_two = float((two[n] - ref[n]).abs().max() / den)
+        e_one = float((one[n] - ref[n]).abs().max() / den)
+        assert e_one <= 1.5 * e_two + 2e-7, (n, e_one, e_two)
+        assert float(mx_one[n]) == float(one[n].abs().max().float()), (n, float(mx_one[n]), float(one[n].abs().max()))
+    # shapes outside the supported family are refused
+    from ppyolo_hip._lib import PPYoloHipError, lib
+    assert lib().ppy_conv3x3_conv1x1_f32(None, 64, None, None, None, None, None, None, None, None, None, 256, None, 256, None, 0, 1, 8, 8, 64, 64,
+                                         256, 1.0, 1.0, None, None) == -1
+
+
+# ------------------------------------------------------------------------------------------
 # "global pre-split": a producer convolution stores its output as its one consumer's finished MFMA operands
 def test_presplit_pair_matches_fp64_as_well_as_the_plain_pair():
     """1x1 (+ CoordConv bias map, LeakyReLU) -> 3x3 as in the head, and 1x1 (ReLU) -> strided 3x3 as in a bottleneck: the

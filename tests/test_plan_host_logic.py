@@ -163,6 +163,40 @@ def test_split_pairs_of_the_r50_plan():
     assert any(id(c) in prods for _, cs in pairs for c in cs)
 
 
+def test_b2b_pairs_of_the_r50_plan():
+    """engine.b2b_pairs (device-free part of HipExecutor._mark_b2b, round 5): conv2 -> conv3 of the two IDENTITY bottlenecks of stage 2
+    (64 -> 64 3x3, 64 -> 256 1x1 with the shortcut) run as one launch; not the stage's first block (its conv3 is the folded
+    128-channel one), not the deeper stages, nothing in r18vd.  With a pair marked, its first launch reads the shortcut and writes
+    the block's output (and the pooled twin), the second does nothing, and conv1 -> conv2 stays a pre-split pair."""
+    from ppyolo_hip.engine import HipExecutor, b2b_pairs, split_pairs
+    cfg = PPYOLO_2x_Config()
+    model, _ = build_model(cfg)
+    plan = build_plan(model, 2, 160, 160, 'cpu')
+    pinned = {a.buf for a in list(plan.head_outs) + list(plan.feats)}
+    assert b2b_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: False) == []
+    pairs = b2b_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: True)
+    assert len(pairs) == 2
+    for a, b in pairs:
+        assert tuple(a['w'].shape) == (64, 3, 3, 64) and tuple(b['w'].shape) == (256, 1, 1, 64) and b['res'] is not None
+        assert b['x'].buf == a['y'].buf and a['y'].buf not in pinned
+    n_before = len(split_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: True))
+    for a, b in pairs:
+        a['b2b'], b['b2b_of'] = b, a
+        assert HipExecutor._op_io(b) == ([], [])
+        ins, outs = HipExecutor._op_io(a)
+        assert ins == [a['x'].buf, b['res'].buf] and outs[0] == b['y'].buf
+    after = split_pairs(plan.ops, HipExecutor._op_io, plan.buffers, pinned, lambda c: True)
+    # the two conv2 -> conv3 tensors are gone as links (never written), the conv1 -> conv2 links of those blocks stay
+    assert len(after) == n_before - 2
+    assert all(any(any(c is a for c in cs) for _, cs in after) for a, _ in pairs)
+    for a, b in pairs:
+        del a['b2b'], b['b2b_of']
+    cfg18 = PPYOLO_r18vd_Config()
+    m18, _ = build_model(cfg18)
+    p18 = build_plan(m18, 2, 160, 160, 'cpu')
+    assert b2b_pairs(p18.ops, HipExecutor._op_io, p18.buffers, set(), lambda c: True) == []
+
+
 def test_dcn_configuration_ids_and_weight_prep_descriptor_layout():
     """Host-side bookkeeping of round 3 that needs no device: (1) the fused-DCNv2 ids -- [0, 18) = scheme * 6 + four-wave tile, from
     18 the eight-wave f16x2 tiles -- as ops.dcnv2_scheme / dcnv2_configs hand them to the plan and the tuner; every committed
