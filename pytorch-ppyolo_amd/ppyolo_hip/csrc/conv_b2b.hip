@@ -149,8 +149,6 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         b_foff[s] = frow * 64 + (((2 * s + fkh) ^ b_sw) << 4);
     }
 
-    issue(0, 0);
-    issue(1, 1);
     // per-image scales of this lane's tile row (row lane & 31 of the wave's 32)
     float inv_sa, s2, inv_s2;
     {
@@ -160,7 +158,30 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         s2 = split_scale_of(fmaf(p.t_mul, pow2_above(amax_read(p.amax_in, n)), p.t_add));
         inv_s2 = pow2_inverse(s2);
     }
-
+    issue(0, 0);
+    issue(1, 1);
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    int pix[4];                              // pixel of the rows erow + 8t this lane finishes
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pix[t] = pixel_of(wave * 32 + erow + 8 * t);
+    unsigned roff[4], yoff[4];               // 32-bit byte offsets (the entry point bounds the tensors): uniform base + offset addressing
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        roff[t] = ((unsigned)max(pix[t], 0) * (unsigned)p.res_ld + (unsigned)ec4) * 4u;
+        yoff[t] = ((unsigned)max(pix[t], 0) * (unsigned)p.y_ld + (unsigned)ec4) * 4u;
+    }
+    const char *res_b = reinterpret_cast<const char *>(p.res);
+    char *y_b = reinterpret_cast<char *>(p.y);
+    floatx4 rv[TNH][4];
+    auto load_res = [&](int col0, floatx4 (&dst)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)          // unconditional (rows beyond the tensor read pixel 0 and are never stored): the count below relies on it
+            dst[t] = *reinterpret_cast<const floatx4 *>(res_b + (size_t)roff[t] + col0 * 4);
+    };
+    // the shortcut rows of the first column half are requested HERE, behind the first two chunks: they cross the main loop in flight
+    // (HBM is nearly idle during it) instead of standing between the two multiplications and their stores
+#pragma unroll
+    for (int jj = 0; jj < TNH; ++jj) load_res(jj * 32, rv[jj]);
     // ================= conv A: 128 x KA over 9 * CA; three LDS stages, chunks requested two ahead, one barrier per chunk =================
     floatx16 acc[TNA];
 #pragma unroll
@@ -169,10 +190,17 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     if (!(p.skip & 1))
     for (int k = 0; k < NCH; ++k) {
-        if (k + 1 < NCH)
+        if (k < 2 && (p.skip & 16))
+            wait_vmcnt<0>();
+        else if (k < 2)
+            wait_vmcnt<G + 4 * TNH>();       // chunk k has landed; behind it, in order: (chunk 1,) the shortcut requests, chunk k + 1
+        else if (k + 1 < NCH)
             wait_vmcnt<G>();                 // chunk k has landed (chunk k + 1 may be in flight)
         else
             wait_vmcnt<0>();
+        // (the compiler moves the last fragment read's wait and its products BEHIND a bare s_barrier: without this wait another
+        // wave's DMA into the stage just read overtakes the read -- seen as run-to-run differences of 3e-4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();        // chunk k is visible, and every wave has finished chunk k - 1: its stage takes chunk k + 2
         if (k + 2 < NCH) issue((k + 2) % 3, k + 2);
         const int st = k % 3;
@@ -220,7 +248,6 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
     issue_w2(0);             // (the stages are dead: the last loop iteration ended with a barrier, and its region holds no stage)
 
     // ================= the intermediate: BatchNorm + ReLU, scaled, split, into LDS as GEMM B's A operand =================
-    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
     float *sE = reinterpret_cast<float *>(smem + E_OFF) + wave * 1024;       // [32][32], column c of row r at c ^ ((r & 7) << 2)
     {
         float rs1[4], rs2[4];
@@ -267,17 +294,6 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
     float rs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) rs[t] = __shfl(inv_s2, (lane >> 3) + 8 * t);
-    int pix[4];                              // pixel of the rows erow + 8t this lane finishes
-#pragma unroll
-    for (int t = 0; t < 4; ++t) pix[t] = pixel_of(wave * 32 + erow + 8 * t);
-    unsigned roff[4], yoff[4];               // 32-bit byte offsets (the entry point bounds the tensors): uniform base + offset addressing
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        roff[t] = ((unsigned)max(pix[t], 0) * (unsigned)p.res_ld + (unsigned)ec4) * 4u;
-        yoff[t] = ((unsigned)max(pix[t], 0) * (unsigned)p.y_ld + (unsigned)ec4) * 4u;
-    }
-    const char *res_b = reinterpret_cast<const char *>(p.res);
-    char *y_b = reinterpret_cast<char *>(p.y);
     int n_lo, n_hi, bnd;
     {
         const int f = pixel_of(wave * 32), l = POOL ? pixel_of(wave * 32 + 7) : pixel_of(wave * 32 + 31);
@@ -287,25 +303,17 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         bnd = (n_lo + 1) * hw;
     }
     float amx = 0.f, amx_hi = 0.f;
-    floatx4 rv[TNH][4];
-    auto load_res = [&](int col0, floatx4 (&dst)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)          // unconditional (rows beyond the tensor read pixel 0 and are never stored): the count below relies on it
-            dst[t] = *reinterpret_cast<const floatx4 *>(res_b + (size_t)roff[t] + col0 * 4);
-    };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         // this half's weights have landed: the first half's are the only loads in flight; behind the second half's DMA come the 16
         // shortcut loads of epilogue 0 (and its stores), in order, so at most 8 outstanding means the DMA is done
         if (half == 0)
             wait_vmcnt<0>();
+        else if (p.skip & 8)
+            wait_vmcnt<0>();
         else
             wait_vmcnt<8>();
         __builtin_amdgcn_s_barrier();            // (first half: every wave's part of A2 is written too)
-        if (half == 0) {
-#pragma unroll
-            for (int jj = 0; jj < TNH; ++jj) load_res(jj * 32, rv[jj]);      // the shortcut rows of the first half: in flight during its GEMM
-        }
         floatx16 acc2[TNH];
 #pragma unroll
         for (int j = 0; j < TNH; ++j)
