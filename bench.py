@@ -153,7 +153,7 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120, extra_kernels=()):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None, 'rocprofv3 not found'
-    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused') + tuple(extra_kernels)
+    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'conv_b2b', 'dcn_fused') + tuple(extra_kernels)
     tot = {}
     launches = 0.0
     t0 = time.perf_counter()
@@ -280,13 +280,19 @@ def conv_flops(plan):
             f = 2 * y.N * y.H * y.W * op['w'].shape[0] * 27
         per_op.append(f)
         total += f
+    for i, op in enumerate(plan.ops):          # conv2 -> conv3 as one launch (csrc/conv_b2b.hip): the work belongs to the launch that does it
+        a = op.get('b2b_of') if op['op'] == 'conv' else None
+        if a is not None:
+            j = next(k for k, o in enumerate(plan.ops) if o is a)
+            per_op[j] += per_op[i]
+            per_op[i] = 0
     return total, per_op
 
 
 def timed_conv_pass(ex, per_op_flops, reps=3):
     """Eager replay with HIP events around every MFMA conv / DCN launch (current stream =
     the launch stream).  Returns (sum of conv launch ms per step, flops covered)."""
-    convs = [i for i, op in enumerate(ex.plan.ops) if op['op'] in ('conv', 'dcn')]
+    convs = [i for i, op in enumerate(ex.plan.ops) if op['op'] in ('conv', 'dcn') and op.get('b2b_of') is None]      # (a fused-away conv3 launches nothing)
     best = None
     for _ in range(reps):
         evs = []
@@ -369,7 +375,7 @@ def batch_scaling_leg(model, wl, dev, ex8, seconds=0.6, batches=(8, 16, 32)):
             cls = {}
             for i, ms in timed_conv_pass.last_per_op.items():
                 op = ex.plan.ops[i]
-                c = 'dcn' if op['op'] == 'dcn' else ('3x3' if op['w'].shape[1] == 3 else '1x1')
+                c = 'dcn' if op['op'] == 'dcn' else ('3x3+1x1 fused' if op.get('b2b') is not None else ('3x3' if op['w'].shape[1] == 3 else '1x1'))
                 d = cls.setdefault(c, [0.0, 0.0])
                 d[0] += ms
                 d[1] += per_op[i]
@@ -402,6 +408,10 @@ def layer_report(ex, per_op, path):
             ms = s.elapsed_time(e)
             best = ms if best is None else min(best, ms)
         key = tune_key(op) if op['op'] in ('conv', 'dcn') else op['op']
+        if op.get('b2b') is not None:
+            key += ' + ' + tune_key(op['b2b']) + ' (one launch)'
+        elif op.get('b2b_of') is not None:
+            key += ' (fused into the launch in front of it)'
         rows.append(dict(i=i, key=key, cfg=op.get('cfg'), splitk=op.get('splitk'), ms=round(best, 4),
                          gflop=round(per_op[i] / 1e9, 3), tflops=round(per_op[i] / (best * 1e-3) / 1e12, 2)))
     with open(path, 'w') as fh:
@@ -501,7 +511,7 @@ def hbm_conv_leg(ex, reps=5):
     plan against HBM bandwidth -- algorithmic bytes = activations + shortcut read once, output (+ its 2x2 average) written once."""
     from ppyolo_hip import ops as K
     first = K.stream_first_cfg()
-    cands = [op for op in ex.plan.ops if op['op'] == 'conv' and first <= op['cfg'] < first + 2]
+    cands = [op for op in ex.plan.ops if op['op'] == 'conv' and first <= op['cfg'] < first + 2 and op.get('b2b_of') is None]
     best = None
     for op in cands:
         x, y = op['x'], op['y']
@@ -527,6 +537,39 @@ def hbm_conv_leg(ex, reps=5):
                 kernel='conv1x1_stream_kernel: C%d -> K%d at %dx%d%s%s (largest launch of %d on this kernel)' % (
                     x.C, y.C, y.H, y.W, ' + shortcut' if op['res'] is not None else '', ' + pooled output' if op.get('pool') is not None else '',
                     len(cands)))
+
+
+def b2b_leg(ex, reps=5):
+    """conv2 -> conv3 of an identity bottleneck as one launch (csrc/conv_b2b.hip) against HBM bandwidth: algorithmic bytes = the
+    pre-split input and the shortcut read once, the output (+ its 2x2 average) written once; the 64-channel intermediate moves nothing."""
+    best = None
+    for op in ex.plan.ops:
+        b = op.get('b2b') if op['op'] == 'conv' else None
+        if b is None:
+            continue
+        x, y = op['x'], b['y']
+        M = y.N * y.H * y.W
+        byt = 4 * (M * x.C + 2 * M * y.C + (M // 4 * y.C if b.get('pool') is not None else 0))
+        t = None
+        for _ in range(reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ex._run_op(op)
+            e.record()
+            e.synchronize()
+            ms = s.elapsed_time(e)
+            t = ms if t is None else min(t, ms)
+        if best is None or byt > best[0]:
+            best = (byt, t, x, y, b)
+    if best is None:
+        return None
+    byt, t, x, y, b = best
+    gbs = byt / (t * 1e-3) / 1e9
+    flops = 2.0 * y.N * y.H * y.W * (x.C * 9 * x.C + x.C * y.C)
+    return dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s', frac=round(gbs / 8000.0, 4), bytes_per_launch=byt,
+                us_per_launch=round(t * 1e3, 1), tflops=round(flops / (t * 1e-3) / 1e12, 1),
+                kernel='conv_b2b_kernel: 3x3 C%d -> %d, then 1x1 -> K%d + shortcut at %dx%d%s (one launch between its own pair of events: ~4 us of '
+                       'event overhead included)' % (x.C, x.C, y.C, y.H, y.W, ' + pooled output' if b.get('pool') is not None else ''))
 
 
 def alt_math_leg(wl, dev, x, ims, steps, current, depth=1):
@@ -1245,6 +1288,9 @@ def main():
         hbm_conv = hbm_conv_leg(ex)
         if hbm_conv is not None:
             out['roofline_other']['expand_1x1'] = hbm_conv
+        fused = b2b_leg(ex)
+        if fused is not None:
+            out['roofline_other']['conv3x3_conv1x1'] = fused
         if a.layer_report:
             layer_report(ex, per_op, a.layer_report)
         if world == 1 and not a.no_alt_math:

@@ -53,7 +53,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
     p = lambda n: os.path.join(ROOT, 'profiles', '%s_%s.txt' % (tag, n))
     sq = table(p('pmc_sq'))
-    conv = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused')
+    conv = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'conv_b2b', 'dcn_fused')
     lines = ['MFMA utilisation from counters (profiles/%s_pmc_sq.txt): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)' % tag,
              '%-92s %6s %12s %9s' % ('kernel', 'calls', 'avg cycles', 'MFMA busy')]
     tb = tc = 0.0

@@ -36,7 +36,7 @@ def main():
     p = lambda n: os.path.join(ROOT, 'profiles', '%s_%s.txt' % (tag, n))
     fetch, write = table(p('pmc_fetch'), 'FETCH_SIZE'), table(p('pmc_write'), 'WRITE_SIZE')
     runs = [c for k, (c, _) in fetch.items() if 'stem_conv' in k][0]        # one stem launch per pass
-    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused')      # the plan's conv / DCN ops: tiles (incl. specialised waves), streaming 1x1, stem patch, fused DCNv2 (as bench.py's own PMC leg counts them)
+    main_k = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'conv_b2b', 'dcn_fused')      # the plan's conv / DCN ops: tiles (incl. specialised waves), streaming 1x1, stem patch, fused DCNv2 (as bench.py's own PMC leg counts them)
     is_conv = lambda k: any(n in k for n in main_k) or 'splitk_reduce' in k
     f_kb = sum(v for k, (_, v) in fetch.items() if is_conv(k)) / runs
     w_kb = sum(v for k, (_, v) in write.items() if is_conv(k)) / runs

@@ -15,7 +15,7 @@ import glob
 import os
 from collections import defaultdict
 
-CONV = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'dcn_fused', 'splitk_reduce')
+CONV = ('conv_igemm', 'conv1x1_stream', 'conv3x3_patch', 'conv_b2b', 'dcn_fused', 'splitk_reduce')
 
 
 def union(iv):
