@@ -334,15 +334,17 @@ int ppy_channel_sum_f32(const float *dy, int dy_ld, int P, int C, float *out, vo
  * dout: NHWC like head_out (channels beyond an*(5+C)(+an) are not written).  loss6: device floats
  * {loss_xy, loss_wh, loss_obj, loss_cls, loss_iou, loss_iou_aware}, each the batch mean as the reference logs it
  * (accumulate != 0: added to what is there, for the sum over levels).  ws: ppy_yolov3_loss_workspace_bytes().
+ * iou_loss_square: IouLoss(loss_square=), 1 = (1 - iou^2) * weight (both configurations), 0 = (1 - iou) * weight (iou_losses.py:66-70);
+ * IouLoss(ciou_term=True) is not implemented (the reference's own branch stops at `alpha.requires_grad = False`, :131, under autograd).
  * amax_dout (or NULL): zeroed per-image maximum slots that receive max|dout| -- the operand scale of the f16x2 gradient kernels
  * of the output convolution.
  */
 size_t ppy_yolov3_loss_workspace_bytes(int N, int S, int an);
 int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const float *target, const float *gt_box, int num_gt,
                         const float *h_anchors_px, int an, int num_classes, int N, int S, int downsample, double scale_x_y,
-                        double ignore_thresh, double iou_loss_weight, int iou_aware, double iou_aware_loss_weight,
-                        float *dout, int dout_ld, float *loss6, int accumulate, float *amax_dout, void *ws, size_t ws_bytes,
-                        void *stream);
+                        double ignore_thresh, double iou_loss_weight, int iou_loss_square, int iou_aware,
+                        double iou_aware_loss_weight, float *dout, int dout_ld, float *loss6, int accumulate, float *amax_dout,
+                        void *ws, size_t ws_bytes, void *stream);
 
 /* First backbone conv, `stage1_conv1_1` (reference model/resnet_vd.py:100, :133): 3x3
  * stride-2 conv C_in=3 -> K (K % 4 == 0, K <= 64) + BN affine + ReLU, reading the

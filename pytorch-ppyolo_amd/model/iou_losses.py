@@ -8,9 +8,11 @@ train.py:241-247 builds them unchanged."""
 
 class IouLoss(object):
     def __init__(self, loss_weight=2.5, max_height=608, max_width=608, ciou_term=False, loss_square=True):
-        if ciou_term or not loss_square:
-            raise NotImplementedError('the fused loss kernel implements the settings of both PP-YOLO configurations: ciou_term=False, '
-                                      'loss_square=True (reference model/iou_losses.py:66-70, :95)')
+        if ciou_term:
+            # (the reference's own branch cannot train either: get_ciou_term sets `alpha.requires_grad = False` on a non-leaf tensor,
+            #  model/iou_losses.py:131, which PyTorch refuses with a RuntimeError as soon as the head outputs require gradients)
+            raise NotImplementedError('ciou_term=True is not part of the fused loss kernel (no PP-YOLO configuration uses it; reference '
+                                      'model/iou_losses.py:95-133)')
         self._loss_weight = loss_weight
         self._MAX_HI, self._MAX_WI = max_height, max_width      # (held, unused: as in the reference)
         self.ciou_term, self.loss_square = ciou_term, loss_square

@@ -82,7 +82,7 @@ _PROTOS = {
     'ppy_channel_sum_f32': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_yolov3_loss_workspace_bytes': (c_size_t, [c_int] * 3),
     'ppy_yolov3_loss_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_int, c_int, c_int, c_int, c_int,
-                                     c_double, c_double, c_double, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_double, c_double, c_double, c_int, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
     'ppy_stem_conv3x3s2_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

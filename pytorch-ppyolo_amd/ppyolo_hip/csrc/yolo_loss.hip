@@ -30,6 +30,7 @@ struct LossArgs {
     int N, S, an, C, G, iou_aware;
     float aw[4], ah[4];
     float downsample, scale_x_y, ignore_thresh, w_iou, w_iou_aware, inv_n;
+    int loss_square;          // IouLoss(loss_square=): 1 - iou^2 (both PP-YOLO configurations), or 1 - iou (reference iou_losses.py:66-70)
 };
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -139,8 +140,8 @@ __global__ void __launch_bounds__(LOSS_CELLS * LOSS_MAXAN * LOSS_Q) yolo_loss_ke
     const float inter = iw * ih;
     const float uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter + 1e-10f;
     const float k = inter / uni;
-    const float l_iou = (1.f - k * k) * p.w_iou * ts;
-    float dk = -2.f * k * p.w_iou * ts;                                   // d(all losses) / d k, before the batch mean
+    const float l_iou = (p.loss_square ? 1.f - k * k : 1.f - k) * p.w_iou * ts;
+    float dk = (p.loss_square ? -2.f * k : -1.f) * p.w_iou * ts;         // d(all losses) / d k, before the batch mean
     float l_ia = 0.f, g_ioup = 0.f;
     if (p.iou_aware) {
         const float T = s_T[a * LOSS_CELLS + (h - h_first)];              // sum over grid x of tobj: the reference's broadcast
@@ -272,9 +273,9 @@ extern "C" size_t ppy_yolov3_loss_workspace_bytes(int N, int S, int an) { return
 
 extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const float *target, const float *gt_box, int num_gt,
                                    const float *h_anchors_px, int an, int num_classes, int N, int S, int downsample, double scale_x_y,
-                                   double ignore_thresh, double iou_loss_weight, int iou_aware, double iou_aware_loss_weight,
-                                   float *dout, int dout_ld, float *loss6, int accumulate, float *amax_dout, void *ws, size_t ws_bytes,
-                                   void *stream) {
+                                   double ignore_thresh, double iou_loss_weight, int iou_loss_square, int iou_aware,
+                                   double iou_aware_loss_weight, float *dout, int dout_ld, float *loss6, int accumulate, float *amax_dout,
+                                   void *ws, size_t ws_bytes, void *stream) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(head_out && target && gt_box && h_anchors_px && dout && loss6 && N > 0 && S > 0 && an > 0 && an <= 4 && num_classes > 0);
     const int nch = an * (5 + num_classes) + (iou_aware ? an : 0);
@@ -288,6 +289,7 @@ extern "C" int ppy_yolov3_loss_f32(const float *head_out, int out_ld, const floa
         p.ah[a] = h_anchors_px[2 * a + 1];
     }
     p.downsample = (float)downsample; p.scale_x_y = (float)scale_x_y; p.ignore_thresh = (float)ignore_thresh;
+    p.loss_square = iou_loss_square ? 1 : 0;
     p.w_iou = (float)iou_loss_weight; p.w_iou_aware = (float)iou_aware_loss_weight; p.inv_n = 1.0f / (float)N;
     // (a row must fit the staging: C up to a few hundred classes; the pair threads are LOSS_CELLS x an <= 256)
     const int pitch = nch | 1;

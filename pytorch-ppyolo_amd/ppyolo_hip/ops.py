@@ -485,7 +485,7 @@ def channel_sum(dy, out, ws=None):
 
 
 def yolov3_loss(head_out, target, gt_box, anchors_px, num_classes, downsample, scale_x_y, ignore_thresh, iou_loss_weight, iou_aware,
-                iou_aware_loss_weight, dout, loss6, accumulate=False, ws=None, amax_dout=None):
+                iou_aware_loss_weight, dout, loss6, accumulate=False, ws=None, amax_dout=None, iou_loss_square=True):
     """head_out / dout: View [N,S,S,*]; target [N,an,6+C,S,S]; gt_box [N,G,4]; loss6 [6] fp32.  See ppy_yolov3_loss_f32."""
     _dev(head_out.t, target, gt_box, dout.t, loss6)
     an = len(anchors_px)
@@ -496,7 +496,7 @@ def yolov3_loss(head_out, target, gt_box, anchors_px, num_classes, downsample, s
     ws = _ws_for(int(lib().ppy_yolov3_loss_workspace_bytes(N, S, an)), ws, head_out.t.device)
     check(lib().ppy_yolov3_loss_f32(head_out.ptr, head_out.ld, target.data_ptr(), gt_box.data_ptr(), gt_box.shape[1], arr, an, num_classes,
                                     N, S, int(downsample), float(scale_x_y), float(ignore_thresh), float(iou_loss_weight),
-                                    int(bool(iou_aware)), float(iou_aware_loss_weight), dout.ptr, dout.ld, loss6.data_ptr(),
+                                    int(bool(iou_loss_square)), int(bool(iou_aware)), float(iou_aware_loss_weight), dout.ptr, dout.ld, loss6.data_ptr(),
                                     int(bool(accumulate)), _p(amax_dout), ws.data_ptr(), ws.numel() * 4, _stream()), 'ppy_yolov3_loss_f32')
     return ws
 

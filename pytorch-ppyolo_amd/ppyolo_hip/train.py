@@ -87,7 +87,7 @@ class ModelSettings(object):
         if bool(hd.iou_aware) != (yl._iou_aware_loss is not None):
             raise PPYoloHipError('head.iou_aware and YOLOv3Loss(iou_aware_loss=...) disagree')
         self.yolo_loss = dict(scale_x_y=yl.scale_x_y, ignore_thresh=yl._ignore_thresh)
-        self.iou_loss = dict(loss_weight=yl._iou_loss._loss_weight)
+        self.iou_loss = dict(loss_weight=yl._iou_loss._loss_weight, loss_square=yl._iou_loss.loss_square)
         self.iou_aware_loss = dict(loss_weight=yl._iou_aware_loss._loss_weight if yl._iou_aware_loss is not None else 0.0)
         self.optimizerBuilder = dict(optimizer=dict(momentum=0.9), regularizer=dict(factor=0.0))      # (unused: torch.optim steps)
         self.use_ema = False
@@ -1000,7 +1000,7 @@ class TrainStep(object):
                 K.yolov3_loss(out.view(), targets[i].float().contiguous(), gt_box.float().contiguous(), anchors, hcfg['num_classes'],
                               hcfg['downsample'][i], cfg.yolo_loss['scale_x_y'], cfg.yolo_loss['ignore_thresh'], cfg.iou_loss['loss_weight'],
                               iou_aware, cfg.iou_aware_loss['loss_weight'] if iou_aware else 0.0, dout.view(), loss6, accumulate=i > 0,
-                              ws=self.ws, amax_dout=dout.amax)
+                              ws=self.ws, amax_dout=dout.amax, iou_loss_square=cfg.iou_loss.get('loss_square', True))
                 if inject_douts is not None:
                     dout.t[..., :out.C].copy_(inject_douts[i].to(self.dev).permute(0, 2, 3, 1))
                 out.g = dout

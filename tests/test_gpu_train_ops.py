@@ -209,14 +209,17 @@ def test_loss_and_dout_match_the_reference_step(golden, tag):
         assert abs(mine[nme] - float(val)) <= 2e-5 * abs(float(val)), (nme, mine[nme], float(val))
 
 
-def test_loss_plain_yolov3_branch_and_ignore_mask():
+@pytest.mark.parametrize('square', [True, False])
+def test_loss_plain_yolov3_branch_and_ignore_mask(square):
     """scale_x_y = 1 (cross-entropy on x / y), gts that overlap predictions above the ignore threshold, random targets:
-    against the training oracle's autograd."""
+    against the training oracle's autograd.  square: IouLoss(loss_square=) -- 1 - iou^2 (the configurations) / 1 - iou
+    (reference model/iou_losses.py:66-70)."""
     from config import PPYOLO_r18vd_Config
     from oracle import train_oracle as trn
     from ppyolo_hip import ops
     cfg = PPYOLO_r18vd_Config()
     cfg.yolo_loss = dict(cfg.yolo_loss, scale_x_y=1.0, ignore_thresh=0.3)
+    cfg.iou_loss = dict(cfg.iou_loss, loss_square=square)
     cfg.head = dict(cfg.head, anchor_masks=[[3, 4, 5]], downsample=[32])
     g = torch.Generator().manual_seed(8)
     N, S, an, C = 3, 6, 3, 80
@@ -236,7 +239,7 @@ def test_loss_plain_yolov3_branch_and_ignore_mask():
     sum(losses.values()).backward()
     ob, db, loss6 = nhwc(out.detach()).cuda(), torch.zeros(N, S, S, an * 85).cuda(), torch.zeros(6).cuda()
     ops.yolov3_loss(ops.View(ob), tgt.cuda(), gt.cuda(), [cfg.head['anchors'][m] for m in (3, 4, 5)], C, 32, 1.0, 0.3,
-                    cfg.iou_loss['loss_weight'], False, 0.0, ops.View(db), loss6)
+                    cfg.iou_loss['loss_weight'], False, 0.0, ops.View(db), loss6, iou_loss_square=square)
     torch.cuda.synchronize()
     assert rel(nchw(db), out.grad) <= 2e-5
     for j, nme in enumerate(['loss_xy', 'loss_wh', 'loss_obj', 'loss_cls', 'loss_iou']):

@@ -43,8 +43,7 @@ def test_freeze_follows_freeze_at():
 def test_unsupported_settings_are_refused():
     with pytest.raises(NotImplementedError):
         select_loss('IouLoss')(ciou_term=True)
-    with pytest.raises(NotImplementedError):
-        select_loss('IouLoss')(loss_square=False)
+    assert select_loss('IouLoss')(loss_square=False).loss_square is False        # 1 - iou: in the fused kernel since round 5
     with pytest.raises(NotImplementedError):
         select_loss('YOLOv3Loss')(iou_loss=None)
     il = select_loss('IouLoss')(loss_weight=2.5)
