@@ -20,6 +20,7 @@ struct ConvArgs {
     int N, H, W, C, Ho, Wo, K, R, S, stride, pad, act, ups;
     int M, Kred, cchunks, chunks_total, chunks_per_split;
     int nstages;                 // conv_x3 kernels: LDS stages (2..4 chunks resident; 2 in every other kernel)
+    int panel_n = 0;             // tile order: column panels of this many N-tiles (ppy_panel_n below); 0 = one panel (tile_m-major)
     unsigned long long *trace;   // debug: per-workgroup timeline (ppy_debug_set_trace), NULL in production
     // training forward (ppy_conv2d_train_fwd_f32): per-channel BatchNorm statistics of y from the epilogue, as (n, mean, M2)
     // triples [slice][K][3] with one slice per wave row-tile (tile_bn_stats below); the launcher reports the slice count to
@@ -68,6 +69,47 @@ int ppy_x3_num_configs();
 int ppy_x3_f16_base();        // first local id of the f16x2 scheme
 int ppy_x3_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
 // conv_stream.hip: persistent streaming kernel for 1x1 convolutions with C = 64 (f16x2 operands), optional 2x2 average output
+// Tile order (round 5).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2; every XCD takes one CONTIGUOUS range of
+// the tile order.  With the tile_m-major order (one panel) an XCD owns a few rows of tiles and ALL columns: the activation rows
+// cross the fabric once, the weights eight times -- right for the large-image layers, wrong for the 19x19 / 38x38 stages whose
+// weights outweigh their activations (3x3 512 -> 1024 at 19x19: 160 MB fetched for 25 MB of operands, profiles/r05_pmc_layers.txt).
+// With gn column panels an XCD owns tiles_m / (8 / gn) rows of ONE panel: fabric reads ~ gn x A + (8 / gn) x W.
+// ppy_panel_n picks gn in {1, 2, 4, 8} for the smaller sum (host); ppy_tile_of maps blockIdx.x (device, all conv tile kernels).
+static inline int ppy_panel_n(const ConvArgs &p, int BM, int BN, int splits) {
+    static const int mode = getenv("PPY_TILE_PANEL") ? atoi(getenv("PPY_TILE_PANEL")) : 1;      // 0 = off, 1 = by the estimate, 2/4/8 = that many panels
+    if (mode == 0 || splits > 1) return 0;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.K + BN - 1) / BN;
+    if (tiles_m * tiles_n < 16) return 0;
+    const double A = (double)p.N * p.H * p.W * p.C * 4.0, W = (double)p.K * p.Kred * 4.0;
+    int best = 1;
+    double best_cost = A + 8.0 * W;
+    for (int gn = 2; gn <= 8; gn *= 2) {
+        if (gn > tiles_n || 8 / gn > tiles_m) continue;
+        if (mode > 1 && gn != mode) continue;
+        const double cost = gn * A + (8.0 / gn) * W;
+        if (cost < 0.9 * best_cost || (mode > 1 && gn == mode)) { best = gn; best_cost = cost; }
+    }
+    return best == 1 ? 0 : (tiles_n + best - 1) / best;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void ppy_tile_of(const ConvArgs &p, int tiles_n, int &tile_m, int &tile_n) {
+    const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int tile_id = xcd * q + min(xcd, r) + idx;
+    const int pn = p.panel_n;
+    if (pn <= 0 || pn >= tiles_n) {
+        tile_m = tile_id / tiles_n;
+        tile_n = tile_id - tile_m * tiles_n;
+        return;
+    }
+    const int tiles_m = nb / tiles_n, per_panel = tiles_m * pn;
+    const int panel = tile_id / per_panel, within = tile_id - panel * per_panel;
+    const int pw = min(pn, tiles_n - panel * pn);              // (the last panel may be narrower)
+    tile_m = within / pw;
+    tile_n = panel * pn + (within - tile_m * pw);
+}
+#endif
+
 int ppy_stream_num_configs();
 int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_ld, hipStream_t stream);
 // conv_patch.hip: 3x3 / stride 1 / pad 1 with C = 32 (the stem layers), input patch staged once per output tile (f16x2 operands)

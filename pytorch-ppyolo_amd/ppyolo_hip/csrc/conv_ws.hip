@@ -43,13 +43,8 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.K + BN - 1) / BN;
-    int tile_id;
-    {   // XCD-contiguous tile order (conv_x3.hip)
-        const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7;
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        tile_id = xcd * q + min(xcd, r) + idx;
-    }
-    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    int tile_m, tile_n;          // XCD-contiguous ranges of the tile order (conv_shared.h, ppy_tile_of)
+    ppy_tile_of(p, tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int kc_begin = split * p.chunks_per_split;
@@ -420,6 +415,7 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     p.chunks_per_split = ceil_div(p.chunks_total, splits);
     splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
+    p.panel_n = ppy_panel_n(p, BM, BN, splits);
     const bool vec = vec_epilogue_ok(p);
     if (p.bn_part) {         // BatchNorm statistics from the epilogue: one split, plain conv + bias
         if (splits > 1 || p.res || p.posb || p.ups || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;

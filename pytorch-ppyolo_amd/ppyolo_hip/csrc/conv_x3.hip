@@ -115,19 +115,14 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.K + BN - 1) / BN;
 #if PPY_X3_XCD
-    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous range of the
-    // (tile_m-major) tile order, so that the N-tiles sharing A rows and the M-neighbours sharing 3x3 halo rows meet in
-    // ONE L2 instead of being fetched over the fabric by several.
-    int tile_id;
-    {
-        const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7;
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        tile_id = xcd * q + min(xcd, r) + idx;
-    }
+    // every XCD (own L2) takes one contiguous range of the tile order -- tile_m-major, or column panels where the weights outweigh
+    // the activations (conv_shared.h, ppy_panel_n / ppy_tile_of)
+    int tile_m, tile_n;
+    ppy_tile_of(p, tiles_n, tile_m, tile_n);
 #else
     const int tile_id = blockIdx.x;
-#endif
     const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+#endif
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int kc_begin = split * p.chunks_per_split;
@@ -703,6 +698,7 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     if (SLAB) p.chunks_per_split = ceil_div(p.chunks_per_split, 3) * 3;      // a split starts on a (channel chunk, r) boundary
     splits = ceil_div(p.chunks_total, p.chunks_per_split);
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.K, BN);
+    p.panel_n = ppy_panel_n(p, BM, BN, splits);
     const bool vec = vec_epilogue_ok(p);
     if (p.bn_part) {         // BatchNorm statistics from the epilogue: f16x2, one split, plain conv + bias
         if (!F16 || splits > 1 || p.res || p.posb || p.ups || p.act != PPY_ACT_NONE) return PPY_ERR_UNSUPPORTED;

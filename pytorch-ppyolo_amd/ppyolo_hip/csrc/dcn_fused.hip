@@ -58,15 +58,21 @@ __global__ void __launch_bounds__(NW * 64) dcn_fused_kernel(const DcnArgs q) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WCOLS, wn = wave - wm * WCOLS;
     const int tiles_n = (p.K + BN - 1) / BN;
-    int tile_id;       // XCD-contiguous tile order (conv_x3.hip): the N-tiles that gather the same rows meet in one L2
+    // XCD-contiguous order over (split, tile) (round 5): workgroups go round-robin to the 8 XCDs in launch order (x fastest, then
+    // the split in y), and every XCD takes one contiguous range of the split-major list -- about one split of ALL row tiles, so a
+    // split's weight slice crosses the fabric once or twice instead of eight times (with blockIdx.x alone the 23 row tiles of a
+    // 19x19 layer's split sat on all eight XCDs: 121 MB fetched for 16 MB of operands, profiles/r05_pmc_layers.txt)
+    int tile_id, split;
     {
-        const int nb = (int)gridDim.x, qd = nb >> 3, r = nb & 7;
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        tile_id = xcd * qd + min(xcd, r) + idx;
+        const int tiles = (int)gridDim.x, total = tiles * (int)gridDim.y, qd = total >> 3, r = total & 7;
+        const int lin = (int)blockIdx.y * tiles + (int)blockIdx.x;
+        const int xcd = lin & 7, idx = lin >> 3;
+        const int v = xcd * qd + min(xcd, r) + idx;
+        split = v / tiles;
+        tile_id = v - split * tiles;
     }
     const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
     const int kc_begin = split * p.chunks_per_split;
     const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
     const int nchunks = kc_end - kc_begin;

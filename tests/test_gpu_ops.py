@@ -1107,7 +1107,10 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
     ws = torch.empty(16 << 20).cuda()
     for N, H, W, C, K, R, stride, res, splitk in ((2, 19, 19, 64, 136, 3, 1, True, 1), (1, 1, 1, 32, 40, 3, 1, False, 1), (3, 1, 7, 64, 72, 1, 1, True, 2),
                                                   (5, 2, 2, 96, 64, 3, 1, False, 4), (1, 33, 31, 32, 258, 3, 2, False, 2), (4, 6, 5, 160, 27, 3, 1, False, 5),
-                                                  (2, 38, 38, 256, 256, 1, 1, True, 1), (2, 24, 24, 128, 256, 3, 1, False, 1), (2, 13, 11, 1024, 100, 1, 1, True, 3)):
+                                                  (2, 38, 38, 256, 256, 1, 1, True, 1), (2, 24, 24, 128, 256, 3, 1, False, 1), (2, 13, 11, 1024, 100, 1, 1, True, 3),
+                                                  # weights outweigh the activations: the tile order is cut into column panels (conv_shared.h ppy_panel_n), differently
+                                                  # per tile width -- every tile must still be computed exactly once
+                                                  (2, 19, 19, 512, 1024, 1, 1, True, 1), (3, 19, 19, 256, 520, 3, 1, False, 1)):
         pad = (R - 1) // 2
         x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
         w = torch.randn(K, C, R, R, generator=g) * (1.0 / (R * R * C) ** 0.5)
