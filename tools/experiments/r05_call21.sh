@@ -8,4 +8,3 @@ import json,sys
 d=json.loads([l for l in open('$f') if l.startswith('{')][-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline'].get('traffic'))"; done
 bash tools/prof_run.sh r05 > $O/prof_run.log 2>&1
 for n in trace pmc_sq pmc_fetch pmc_write pmc_lds; do cp gpurun_out/prof_r05/$n.txt $O/r05_$n.txt 2>/dev/null; done
-bash tools/experiments/r05_call20.sh
