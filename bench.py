@@ -969,6 +969,8 @@ def main():
     ap.add_argument('--tune-kinds', default='conv,dcn', help='with --autotune: plan op kinds to re-measure (conv,dcn)')
     ap.add_argument('--tune-match', default=None, help='with --autotune: only the layers whose table key contains all of these '
                     'comma-separated pieces (e.g. ":C64:,:R1:")')
+    ap.add_argument('--insitu-tune', action='store_true', help='with --autotune: re-rank the front-runners of every layer by their duration inside a '
+                    'whole eager pass of the plan (HipExecutor.insitu_tune)')
     ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
                     'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
     ap.add_argument('--verbose-tune', action='store_true')
@@ -1049,6 +1051,10 @@ def main():
             for alt in (a.tune_match.split('|') if a.tune_match else [None]):      # "a,b|c,d": layers matching (a and b) or (c and d)
                 ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
             torch.cuda.synchronize()
+        if a.insitu_tune:
+            changed = ex.insitu_tune(verbose=a.verbose_tune)
+            if rank == 0:
+                print('insitu_tune: %d layers changed their config' % changed, file=sys.stderr)
         if a.co_tune and depth > 1:
             lanes[1][0].use_graph = True
             changed = ex.co_tune(lanes[1][0], verbose=a.verbose_tune)
