@@ -971,6 +971,7 @@ def main():
                     'comma-separated pieces (e.g. ":C64:,:R1:")')
     ap.add_argument('--insitu-tune', action='store_true', help='with --autotune: re-rank the front-runners of every layer by their duration inside a '
                     'whole eager pass of the plan (HipExecutor.insitu_tune)')
+    ap.add_argument('--insitu-topk', type=int, default=6)
     ap.add_argument('--co-tune', action='store_true', help='with --autotune: choose among the front-runners of a layer '
                     'the best NEIGHBOUR of a second lane (HipExecutor.co_tune)')
     ap.add_argument('--verbose-tune', action='store_true')
@@ -1052,7 +1053,7 @@ def main():
                 ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
             torch.cuda.synchronize()
         if a.insitu_tune:
-            changed = ex.insitu_tune(verbose=a.verbose_tune)
+            changed = ex.insitu_tune(topk=a.insitu_topk, verbose=a.verbose_tune)
             if rank == 0:
                 print('insitu_tune: %d layers changed their config' % changed, file=sys.stderr)
         if a.co_tune and depth > 1:

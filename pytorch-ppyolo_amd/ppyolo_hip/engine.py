@@ -971,6 +971,7 @@ class HipExecutor(object):
                     if best is None or again < best[0]:
                         best = (again, c, s)
                 op['_front'] = sorted(front)           # kept for co_tune()
+                op['_cands'] = sorted(cands)[:24]      # (single look; insitu_tune(topk > 6) re-ranks more of them)
                 op.pop('x_split', None)
                 if best is None:
                     op['cfg'], op['splitk'] = base_cfg, base_split
@@ -1065,8 +1066,9 @@ class HipExecutor(object):
                 front = op.get('_front')
                 if op['op'] not in ('conv', 'dcn') or not front or len(front) < 2:
                     continue
+                pool = front if topk <= len(front) else front + [t for t in op.get('_cands', []) if (t[1], t[2]) not in {(c, s) for _, c, s in front}]
                 scored = []
-                for ms, c, s in front[:topk]:
+                for ms, c, s in pool[:topk]:
                     op['cfg'], op['splitk'] = c, s
                     best = None
                     for _ in range(reps):
