@@ -2,7 +2,8 @@
 # in-situ re-ranking for the other workloads of the refresh set; A/B per workload through PPYOLO_HIP_TUNE_CACHE
 O=gpurun_out/r05; mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-host-input --no-alt-math --no-pmc --no-worst-case --no-batch-scaling"
-for spec in "r18vd_320 1" "r50vd_608 1" "r18vd_416 8" "r18vd_320 8"; do
+IFS=";" read -ra LIST <<< "${SPECS:-r18vd_320 1;r50vd_608 1;r18vd_416 8;r18vd_320 8}"
+for spec in "${LIST[@]}"; do
  set -- $spec
  T=$O/tuned_insitu_$1_bs$2.json
  timeout 1200 $B --workload $1 --batch $2 --autotune --insitu-tune --save-tuning $T > /dev/null 2> $O/insitu_$1_bs$2.err; grep "layers changed" $O/insitu_$1_bs$2.err
