@@ -112,6 +112,11 @@ int ppy_conv2d_bn_act_f32(const float *x, int x_ld, const float *w_krsc, const v
  *     max|x_n| is taken from amax_in, rounded up to a power of two); amax_out still receives max|y|.
  *   x_split_scale != NULL: x holds such operands, written by a launch whose y_split_scale it is (C and x_ld multiples of 32).
  * PPY_ERR_BAD_ARG when the chosen cfg cannot read / write such tensors (never a silent reinterpretation of the bytes).
+ *   amax_in2 (round 6; may be NULL): a SECOND block of tracked per-image maxima, for an input whose channels were written by
+ *     producers that track into different blocks (the folded projection shortcut's wide buffer [conv2 output | pooled block
+ *     input], model/resnet_vd.py:27-33: the pooled part keeps the slots of the tensor it was pooled from, so that tensor's other
+ *     readers never see conv2's maximum); the f16x2 kernels scale an image by the larger of the two.  With both split pointers
+ *     NULL the call is ppy_conv2d_bn_act_f32 plus this one pointer (cfg -1 and split-K allowed).
  * Reference operator: the same Conv2dUnit.forward (model/custom_layers.py:243-253). */
 int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
                                 const void *w_f16x2, const float *scale, const float *scale_f16x2,
@@ -120,7 +125,7 @@ int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float *w_krsc, c
                                 int H, int W, int C, int K, int R, int S, int stride, int pad, int act,
                                 int upsample2x, int cfg, int splitk, const float *amax_in, float *amax_out,
                                 void *ws, size_t ws_bytes, void *stream, const float *x_split_scale,
-                                float *y_split_scale, float y_bound_mul, float y_bound_add);
+                                float *y_split_scale, float y_bound_mul, float y_bound_add, const float *amax_in2);
 size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int cfg, int splitk);
 int ppy_conv2d_num_configs(void);

@@ -33,7 +33,7 @@ _PROTOS = {
                               + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_bn_act_split_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 13
-                                    + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_float, c_float]),
+                                    + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p]),
     'ppy_conv2d_workspace_bytes': (c_size_t, [c_int] * 11),
     'ppy_conv2d_bn_partials_bytes': (c_size_t, [ctypes.c_longlong, c_int]),
     'ppy_conv2d_train_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 10

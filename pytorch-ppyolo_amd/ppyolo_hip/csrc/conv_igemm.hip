@@ -578,7 +578,7 @@ static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void
                        int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
                        int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
                        size_t ws_bytes, void *stream, const float *x_split_scale, float *y_split_scale, float y_bound_mul,
-                       float y_bound_add) {
+                       float y_bound_add, const float *amax_in2 = nullptr) {
     ppy_drop_stale_error();
     PPY_CHECK_ARG(x && w_krsc && scale && shift && y);
     Geometry g;
@@ -602,6 +602,7 @@ static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void
     ConvArgs p;
     p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.wf16 = (const unsigned short *)w_f16x2;
     p.scale_f16 = scale_f16x2; p.posb_f16 = posbias_f16x2; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
+    p.amax_in2 = amax_in ? amax_in2 : nullptr;
     p.y = y; p.part = (float *)ws;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;
@@ -645,13 +646,18 @@ extern "C" int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float
                                            int W, int C, int K, int R, int S, int stride, int pad, int act, int upsample2x,
                                            int cfg, int splitk, const float *amax_in, float *amax_out, void *ws,
                                            size_t ws_bytes, void *stream, const float *x_split_scale, float *y_split_scale,
-                                           float y_bound_mul, float y_bound_add) {
+                                           float y_bound_mul, float y_bound_add, const float *amax_in2) {
+    // (amax_in2 alone -- a plain fp32 launch whose input has two tracked blocks -- keeps the freedoms of ppy_conv2d_bn_act_f32)
+    if (!x_split_scale && !y_split_scale)
+        return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N,
+                           H, W, C, K, R, S, stride, pad, act, upsample2x, cfg, splitk, amax_in, amax_out, ws, ws_bytes, stream, nullptr,
+                           nullptr, 0.f, 0.f, amax_in2);
     PPY_CHECK_ARG(cfg >= 0 && splitk <= 1 && !(upsample2x && y_split_scale));
     PPY_CHECK_ARG(!y_split_scale || (y_bound_mul >= 0.f && y_bound_add >= 0.f && K % 32 == 0 && y_ld % 32 == 0 && ((uintptr_t)y & 127) == 0));
     PPY_CHECK_ARG(!x_split_scale || (C % 32 == 0 && x_ld % 32 == 0 && ((uintptr_t)x & 127) == 0));
     return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N, H,
                        W, C, K, R, S, stride, pad, act, upsample2x, cfg, splitk, amax_in, amax_out, ws, ws_bytes, stream, x_split_scale,
-                       y_split_scale, y_bound_mul, y_bound_add);
+                       y_split_scale, y_bound_mul, y_bound_add, amax_in2);
 }
 
 static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
         tile_of(live ? t : 0, n, y0, x0);
         if (live) {
         if (n != sc_n) {      // per-image activation scale (conv_x3.hip): the power of two that puts the tracked maximum into [2^13, 2^14)
-            const float mx = amax_read(p.amax_in, n);
+            const float mx = conv_amax_in(p, n);
             const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
             int f = 267 - e;
             f = f < 103 ? 103 : (f > 167 ? 167 : f);

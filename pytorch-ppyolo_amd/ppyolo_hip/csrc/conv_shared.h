@@ -14,6 +14,9 @@ struct ConvArgs {
     const float *scale_f16;      // `scale` with the inverse weight scale folded in (f16x2 kernels)
     const float *posb_f16;       // posb times the per-channel weight scale (f16x2 kernels), or NULL
     const float *amax_in;        // tracked per-image max|x| of the input tensor (N * AMAX_SLOTS slots), or NULL
+    const float *amax_in2 = nullptr;   // round 6: a SECOND block of tracked maxima covering part of the input's channels (the folded
+                                 // shortcut's wide buffer [conv2 output | pooled block input]: the pooled part keeps the slots of the
+                                 // tensor it was pooled from); the launch scales by the larger of the two.  conv_amax_in() below.
     float *amax_out;             // where this launch records per-image max|y| (N * AMAX_SLOTS slots), or NULL
     float *y, *part;
     int x_ld, res_ld, y_ld;
@@ -59,6 +62,15 @@ static __device__ __forceinline__ float pow2_above(float mx) {       // the powe
 static __device__ __forceinline__ float pow2_inverse(float s) {      // 1 / s for s = 2^k, exactly
     return __uint_as_float((254u - ((__float_as_uint(s) >> 23) & 0xffu)) << 23);
 }
+
+#if defined(__HIPCC__)
+// per-image max|x| of a launch's input: the maximum over its one or two tracked blocks (ConvArgs::amax_in, amax_in2)
+static __device__ __forceinline__ float conv_amax_in(const ConvArgs &p, int n) {
+    float mx = amax_read(p.amax_in, n);
+    if (p.amax_in2) mx = fmaxf(mx, amax_read(p.amax_in2, n));
+    return mx;
+}
+#endif
 
 struct Geometry {
     int Ho, Wo, M, Kred, chunks;

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
     int sc_n = -1;
     float sa0 = 1.f, sa1 = 1.f, inv0 = 1.f, inv1 = 1.f;
     auto scale_of = [&](int n, float &s, float &inv) {
-        const float mx = amax_read(p.amax_in, min(n, p.N - 1));
+        const float mx = conv_amax_in(p, min(n, p.N - 1));
         const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
         int f = 267 - e;
         f = f < 103 ? 103 : (f > 167 ? 167 : f);

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 #pragma unroll
             for (int j = 0; j < A_PASS; ++j) {
                 const int mrow = min(m0 + (j * NWP + pw) * 8 + (lane >> 3), p.M - 1);
-                const float mx = amax_read(p.amax_in, mrow / hw);
+                const float mx = conv_amax_in(p, mrow / hw);
                 const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
                 int f = 267 - e;
                 f = f < 103 ? 103 : (f > 167 ? 167 : f);
@@ -215,10 +215,10 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
         if constexpr (GP) {
             sa[i] = p.xscale[mrow / hw];
             inv_sa[i] = pow2_inverse(sa[i]);
-            if (p.yscale) xmax_up[i] = pow2_above(amax_read(p.amax_in, mrow / hw));      // (conv_x3.hip: chains bound from the tracked maximum)
+            if (p.yscale) xmax_up[i] = pow2_above(conv_amax_in(p, mrow / hw));      // (conv_x3.hip: chains bound from the tracked maximum)
             continue;
         }
-        const float mx = amax_read(p.amax_in, mrow / hw);
+        const float mx = conv_amax_in(p, mrow / hw);
         const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
         int f = 267 - e;
         f = f < 103 ? 103 : (f > 167 ? 167 : f);

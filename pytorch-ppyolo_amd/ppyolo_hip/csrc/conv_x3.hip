@@ -480,10 +480,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                     inv_sa[i] = pow2_inverse(sa[i]);
                     // (a link in a CHAIN of pre-split tensors bounds its own output from the input's TRACKED maximum, not from the
                     // input's bound: static bounds multiplied along a chain lose 2^6 per link and underflow the fp16 range)
-                    if (p.yscale) xmax_up[i] = pow2_above(amax_read(p.amax_in, mrow / hw));
+                    if (p.yscale) xmax_up[i] = pow2_above(conv_amax_in(p, mrow / hw));
                     continue;
                 }
-                const float mx = amax_read(p.amax_in, mrow / hw);
+                const float mx = conv_amax_in(p, mrow / hw);
                 const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // biased exponent: mx in [2^(e-127), 2^(e-126))
                 int f = 267 - e;                                                // biased exponent of 2^(13-(e-127))
                 f = f < 103 ? 103 : (f > 167 ? 167 : f);                       // scale in [2^-24, 2^40]: all-zero / absurd tensors stay finite

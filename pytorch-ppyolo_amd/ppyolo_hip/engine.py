@@ -265,6 +265,44 @@ class Builder(object):
         return y
 
 
+def assign_amax(ops):
+    """Blocks of tracked per-image maxima (HipExecutor._assign_amax): sets op['amax_out_id'] / ['amax_in_id'] / ['amax_in2_id'],
+    returns the number of blocks.  A conv / DCN launch merges max|y| into the block of its output BUFFER (the writers of a concat
+    buffer share one); a pooled tensor inherits the block of its input.  Round 6: when a convolution writes into a buffer that so
+    far only holds a pooled tensor -- the folded projection shortcut's wide buffer [conv2 output | pooled block input] -- the
+    buffer gets a block of its OWN for what convolutions write and keeps the inherited one as a second, read-only block
+    ('amax_in2_id' of its readers): the block input's other readers (the head's C3 / C4 convolutions) no longer see conv2's
+    maximum (round-5 advisor)."""
+    amax_of, aux_of, inherited, nblocks = {}, {}, set(), 0
+    for op in ops:
+        t = op['op']
+        if t in ('conv', 'dcn'):
+            b = op['y'].buf
+            if b in inherited:
+                inherited.discard(b)
+                aux_of[b] = amax_of.pop(b)
+            if b not in amax_of:
+                amax_of[b] = nblocks
+                nblocks += 1
+            op['amax_out_id'] = amax_of[b]
+            op['amax_in_id'] = amax_of.get(op['x'].buf)
+            op['amax_in2_id'] = aux_of.get(op['x'].buf)
+        elif t in ('maxpool', 'avgpool'):
+            src = amax_of.get(op['x'].buf)
+            if src is not None:
+                yb = op['y'].buf
+                if yb in amax_of and yb not in inherited:      # a convolution wrote into this buffer first: second block
+                    aux_of[yb] = src
+                else:
+                    amax_of[yb] = src
+                    inherited.add(yb)
+        elif t == 'stem':
+            amax_of[op['y'].buf] = nblocks
+            op['amax_out_id'] = nblocks
+            nblocks += 1
+    return nblocks
+
+
 def link_pools(ops, op_io, has_f16, two_streams=False):
     """Host logic of HipExecutor._link_pools, device-free (tests/test_plan_host_logic.py): gives every 'avgpool' op whose input
     slice is written by exactly one 1x1 / stride-1 convolution that ppy_conv1x1_expand_f32 accepts (C = 64 with K % 64 == 0, or
@@ -505,7 +543,9 @@ class HipExecutor(object):
             if op.get('posb') is not None:
                 used.add(op['posb'].buf)
         used.update(a.buf for a in list(p.feats) + list(p.head_outs))
-        used.update(op['y'].buf for op in p.ops if op['op'] == 'conv')          # (also behind a fused pair: the plan may fall back to two launches)
+        # (also behind a fused pair: the plan may fall back to two launches -- but NOT the full-resolution tensor in front of a
+        # linked max pool: its launch writes the pooled tensor only, and 189 MB per executor and lane stay unallocated)
+        used.update(op['y'].buf for op in p.ops if op['op'] == 'conv' and op.get('mpool') is None)
         self.bufs = []
         for i, (N, H, W, ld) in enumerate(p.buffers):
             if i in p.consts:
@@ -520,23 +560,7 @@ class HipExecutor(object):
         output buffer; pooled tensors inherit the slots of their input (max- and average-pooling never exceed it; SPP
         writes into its own input buffer; the DCN columns are bounded by the DCN input); the stem kernel tracks its
         output as well."""
-        amax_of, nblocks = {}, 0
-        for op in self.plan.ops:
-            t = op['op']
-            if t in ('conv', 'dcn'):
-                b = op['y'].buf
-                if b not in amax_of:
-                    amax_of[b] = nblocks
-                    nblocks += 1
-                op['amax_out_id'] = amax_of[b]
-                op['amax_in_id'] = amax_of.get(op['x'].buf)
-            elif t in ('maxpool', 'avgpool'):
-                if amax_of.get(op['x'].buf) is not None:
-                    amax_of[op['y'].buf] = amax_of[op['x'].buf]
-            elif t == 'stem':
-                amax_of[op['y'].buf] = nblocks
-                op['amax_out_id'] = nblocks
-                nblocks += 1
+        nblocks = assign_amax(self.plan.ops)
         self._amax_block = self.plan.N * K.AMAX_FLOATS_PER_IMAGE
         self.amax = torch.zeros(max(1, nblocks) * self._amax_block, dtype=torch.float32, device=self.device)
 
@@ -589,12 +613,14 @@ class HipExecutor(object):
             op.pop('x_split', None)
             op.pop('y_split', None)
 
-    def _link_splits(self):
+    def _link_splits(self, _retry=False):
         """"Global pre-split" (DESIGN.md 4.1g): where a convolution's output buffer is read by exactly ONE op, a convolution on
         an f16x2 tile kernel, the producer stores it as that consumer's finished MFMA operands (two fp16 terms of y * s_image,
         same bytes per pixel) and the consumer's main loop carries no scale / split work.  s_image comes from a static bound
         of |y| -- per output channel |scale| * sum|w| times the input's tracked maximum, plus |shift| and the CoordConv bias --
         so the producer needs no second pass.  Bottleneck conv1 -> conv2 (3x3) and the head's 1x1 -> 3x3 pairs qualify."""
+        if not _retry:
+            self._b2b_rejected = set()      # (op indices of fused pairs that fell back to two launches in this derivation)
         self._unlink_splits()
         self._mark_b2b()
         n = 0
@@ -619,22 +645,13 @@ class HipExecutor(object):
                 n += 1
         # a fused pair needs its input pre-split (csrc/conv_b2b.hip reads finished operands): without the link it is two launches again
         undone = False
-        for op in self.plan.ops:
+        for i, op in enumerate(self.plan.ops):
             if op.get('b2b') is not None and op.get('x_split') is None:
-                op['b2b'].pop('b2b_of', None)
-                op.pop('b2b', None)
+                self._b2b_rejected.add(i)
                 undone = True
-        if undone:      # (the links were derived with the pair fused: its stand-alone form may allow others)
-            return self._link_splits_plain()
+        if undone:      # (the links were derived with that pair fused: its stand-alone form may allow others; the other pairs stay fused)
+            return self._link_splits(_retry=True)
         return n
-
-    def _link_splits_plain(self):
-        """_link_splits without (re-)marking fused pairs: the fall-back when a marked pair did not get its pre-split input."""
-        keep, self._b2b_off = getattr(self, '_b2b_off', False), True
-        try:
-            return self._link_splits()
-        finally:
-            self._b2b_off = keep
 
     def _unlink_b2b(self):
         for op in self.plan.ops:
@@ -647,11 +664,15 @@ class HipExecutor(object):
         64-channel tensor between them is neither written nor read.  The static bound of the intermediate (per-image operand scale
         of the second contraction) is derived as for a pre-split link."""
         self._unlink_b2b()
-        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_B2B', '1') != '1' or getattr(self, '_b2b_off', False):
+        if self.math != 'f16x2' or os.environ.get('PPYOLO_HIP_B2B', '1') != '1':
             return 0
         pinned = {a.buf for a in list(self.plan.head_outs) + list(self.plan.feats)}
         pairs = b2b_pairs(self.plan.ops, self._op_io, self.plan.buffers, pinned,
                           lambda c: c.get('wf16') is not None and c.get('amax_in_id') is not None)
+        # pairs that did not get their pre-split input in an earlier pass of _link_splits stay two launches (round-5 advisor: only
+        # those, not every pair of the plan); the set is cleared whenever the links are rebuilt from scratch (a new tile table)
+        rejected = {id(self.plan.ops[i]) for i in getattr(self, '_b2b_rejected', ())}
+        pairs = [(a, b) for a, b in pairs if id(a) not in rejected]
         for a, b in pairs:
             if a.get('t_bound') is None:
                 w, sc, sh = a['w'], a['scale'], a['shift']
@@ -772,6 +793,9 @@ class HipExecutor(object):
         ws = self.ws if ws is None else ws
         if t == 'conv' and op.get('b2b_of') is not None:
             return                  # (computed by the launch of the convolution in front of it)
+        if op.get('amax_in2_id') is not None and (t != 'conv' or op.get('b2b') is not None or op.get('mpool') is not None or (
+                op.get('pool') is not None and self._stream_first() <= op['cfg'] < self._stream_first() + 2)):
+            raise PPYoloHipError('plan op %s reads a buffer with two tracked-maximum blocks through an entry point that takes one' % tune_key(op))
         if t == 'conv' and op.get('b2b') is not None:
             b = op['b2b']
             K.conv3x3_conv1x1(self.view(op['x']), op['x_split'], self._amax(op['amax_in_id']), op['wf16'], op['shift'], b['wf16'], b['shift'],
@@ -791,7 +815,8 @@ class HipExecutor(object):
                             op['pad'], op['act'], None if op['res'] is None else self.view(op['res']),
                             None if posb is None else self.bufs[posb.buf], op['ups'], op['cfg'], op['splitk'],
                             ws, op.get('w3'), op.get('wf16'), self._amax(op.get('amax_in_id')),
-                            self._amax(op.get('amax_out_id')), op.get('posb_f16'), op.get('x_split'), op.get('y_split'))
+                            self._amax(op.get('amax_out_id')), op.get('posb_f16'), op.get('x_split'), op.get('y_split'),
+                            self._amax(op.get('amax_in2_id')))
             if op.get('pool') is not None:
                 K.avgpool2x2(self.view(op['y']), self.view(op['pool']))
         elif t == 'stem':

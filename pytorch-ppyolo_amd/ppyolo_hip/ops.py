@@ -119,15 +119,16 @@ def amax_slots(t=None, device=None, N=None):
 
 def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residual=None, posbias=None,
                   upsample2x=False, cfg=-1, splitk=0, ws=None, w_x3=None, w_f16=None, amax_in=None, amax_out=None,
-                  posbias_f16=None, x_split=None, y_split=None):
+                  posbias_f16=None, x_split=None, y_split=None, amax_in2=None):
     """x, y, residual: View.  w_krsc: [K,R,S,C].  w_x3: split_weights_bf16x3(w_krsc) or None.
     w_f16: split_weights_f16x2(w_krsc, scale) or None; amax_in / amax_out: amax_slots blocks or None.
     x_split: [N] per-image scales of a pre-split input; y_split: ([N] scale tensor to fill, bound_mul, bound_add): write y
-    pre-split for its one consumer.  See ppy_conv2d_bn_act_f32 / ppy_conv2d_bn_act_split_f32."""
+    pre-split for its one consumer.  amax_in2: a second amax_slots block covering part of x's channels (the launch scales by the
+    larger maximum).  See ppy_conv2d_bn_act_f32 / ppy_conv2d_bn_act_split_f32."""
     _dev(x.t, w_krsc, scale, shift, y.t)
     K, R, S, C = w_krsc.shape
     assert C == x.C and K == y.C and w_krsc.is_contiguous()
-    if x_split is not None or y_split is not None:
+    if x_split is not None or y_split is not None or amax_in2 is not None:
         ys, ym, ya = y_split if y_split is not None else (None, 0.0, 0.0)
         rc = lib().ppy_conv2d_bn_act_split_f32(
             x.ptr, x.ld, w_krsc.data_ptr(), _p(w_x3), None if w_f16 is None else w_f16[0].data_ptr(), scale.data_ptr(),
@@ -135,7 +136,7 @@ def conv2d_bn_act(x, w_krsc, scale, shift, y, stride=1, pad=0, act=None, residua
             None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
             _p(posbias), _p(posbias_f16), y.ptr, y.ld, x.N, x.H, x.W, C, K, R, S, stride, pad, ACT[act], int(bool(upsample2x)),
             cfg, splitk, _p(amax_in), _p(amax_out), _p(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream(),
-            _p(x_split), _p(ys), float(ym), float(ya))
+            _p(x_split), _p(ys), float(ym), float(ya), _p(amax_in2))
         check(rc, 'ppy_conv2d_bn_act_split_f32')
         return
     rc = lib().ppy_conv2d_bn_act_f32(

@@ -19,6 +19,8 @@ The convolutions run on the exact bf16x3 split (no tracked maxima needed); torch
 import json
 import os
 
+import warnings
+
 import torch
 
 from . import ops as K
@@ -211,6 +213,7 @@ class TrainStep(object):
         self._prefetch_on = os.environ.get('PPYOLO_HIP_TRAIN_PREFETCH', '1') == '1'
         self._bstream = None
         self._pref = None
+        self._own_backbone_done = None
         self._b_res = None                  # [ws, bn_part, [arena0, arena1], which]
 
     @staticmethod
@@ -911,7 +914,8 @@ class TrainStep(object):
             if self.external:
                 self._pull_params()
             self._prepare_weights()
-            if pref is not None and pref['key'] == self._pref_key(x_nchw):
+            self._own_backbone_done = None
+            if pref is not None and pref['x'] is x_nchw and pref['key'] == self._pref_key(x_nchw):
                 # the backbone of this batch ran on the side stream during the previous step
                 main = torch.cuda.current_stream(self.dev)
                 main.wait_event(pref['event'])
@@ -921,7 +925,19 @@ class TrainStep(object):
                 self._nbt = list(pref['nbt']) + self._nbt
                 self.flops += pref['flops']
             else:
+                if pref is not None:
+                    # a prefetch that is not used (another tensor, or the same one modified since): its backbone has already
+                    # updated the BatchNorm running statistics once (no counter bump) -- the plain loop never would, so say so.
+                    # The main-stream backbone below also read-modify-writes them: order it behind the side stream's.
+                    warnings.warn('TrainStep: a prefetched backbone forward was discarded (the batch passed to step() is not the '
+                                  'tensor given as next_x, or it was modified in between); its BatchNorm running-statistics '
+                                  'update stays applied', RuntimeWarning)
+                    torch.cuda.current_stream(self.dev).wait_event(pref['event'])
                 feats = self.backbone(x_nchw.float().contiguous())
+                # this step ran its own backbone on the main stream: the NEXT batch's prefetched backbone must not start before it
+                # has finished (both update the same running statistics and, on step 0, the frozen-weight caches are made here)
+                self._own_backbone_done = torch.cuda.Event()
+                self._own_backbone_done.record(torch.cuda.current_stream(self.dev))
         return self.head_loss_backward(feats, gt_box, targets, inject_douts)
 
     @staticmethod
@@ -961,7 +977,9 @@ class TrainStep(object):
                 assert not self.tape, 'prefetch_backbone: a frozen backbone records no backward'
                 ev = torch.cuda.Event()
                 ev.record(self._bstream)
-                self._pref = dict(key=self._pref_key(x_next), feats=feats, event=ev, nbt=self._nbt, flops=self.flops)
+                x_next.record_stream(self._bstream)          # (the allocator must not hand its block out while the side stream reads it)
+                # the tensor itself is kept: identity + version decide whether the features are served (an address can be reused)
+                self._pref = dict(x=x_next, key=self._pref_key(x_next), feats=feats, event=ev, nbt=self._nbt, flops=self.flops)
                 res[1], res[2][res[3]] = self._bn_part, self._amax_arena
         finally:
             self.ws, self._bn_part, self._amax_arena, self._amax_next, self._nbt, self.flops, self.tape = saved
@@ -1149,7 +1167,9 @@ class TrainStep(object):
             ready.record(torch.cuda.current_stream(self.dev))      # next_x is ready here, before this step's kernels are issued
         loss6 = self.forward_backward(x_nchw, gt_box, targets, dropblock_masks)
         if next_x is not None:
-            self.prefetch_backbone(next_x, ready)
+            # the early event only when this step's backbone was served from the prefetch: otherwise the main stream has just run a
+            # backbone itself (step 0, or a key mismatch) and the side stream waits for THAT (round-5 advisor, medium)
+            self.prefetch_backbone(next_x, ready if self._own_backbone_done is None else self._own_backbone_done)
         self.all_reduce()
         self.sgd(lr)
         return loss6

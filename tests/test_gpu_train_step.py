@@ -246,7 +246,8 @@ def test_prefetched_backbone_changes_nothing(cfgc):
     xa, xb = xs[0].clone(), xs[1].clone()
     ts.step(xa, gts[0][0], gts[0][1], 0.002, next_x=xb)
     xb.mul_(0.5)
-    l_mod = ts.step(xb, gts[1][0], gts[1][1], 0.002).clone()
+    with pytest.warns(RuntimeWarning, match='prefetched backbone forward was discarded'):
+        l_mod = ts.step(xb, gts[1][0], gts[1][1], 0.002).clone()
     model2, _ = build_model(cfg, 0, 'cuda')
     ts2 = TrainStep(model2, cfg)
     ts2.step(xs[0], gts[0][0], gts[0][1], 0.002)
@@ -255,6 +256,34 @@ def test_prefetched_backbone_changes_nothing(cfgc):
     l_ref = ts2.step(xs[1] * 0.5, gts[1][0], gts[1][1], 0.002).clone()
     torch.cuda.synchronize()
     assert torch.equal(l_mod.cpu(), l_ref.cpu())
+
+
+def test_prefetched_backbone_is_ordered_behind_a_main_stream_backbone():
+    """Round-5 advisor (medium): on step 0 (and after any discarded prefetch) the step runs its own backbone on the main stream; the
+    next batch's prefetched backbone must wait for THAT one -- both read-modify-write the BatchNorm running statistics, and step 0
+    also makes the frozen-weight caches.  The small case above is host-bound and cannot see an overlap; this one is GPU-bound
+    (R50vd, 8 x 512 x 512: the backbone alone is several ms), so an unordered side stream would run beside step 0's backbone."""
+    from ppyolo_hip.train import TrainStep
+    cfg = PPYOLO_2x_Config()
+    N, S = 8, 512
+    xs = [synth.synth_images(N, S, seed=40 + i).cuda() for i in range(3)]
+    gts = [synth_targets(cfg, N, S, 9 + i) for i in range(3)]
+    gts = [(g.cuda(), [t.cuda() for t in tg]) for g, tg in gts]
+    got = {}
+    for mode in ('plain', 'pipe'):
+        model, _ = build_model(cfg, 0, 'cuda')
+        ts = TrainStep(model, cfg)
+        losses = []
+        for i in range(3):
+            nxt = xs[i + 1] if (mode == 'pipe' and i + 1 < 3) else None
+            losses.append(ts.step(xs[i], gts[i][0], gts[i][1], 0.002, next_x=nxt).clone())
+        torch.cuda.synchronize()
+        ts.sync_to_model()
+        sd = model.state_dict()
+        stats = torch.cat([sd[k].double().reshape(-1).cpu() for k in sorted(sd) if 'running_' in k or 'num_batches' in k])
+        got[mode] = (torch.stack(losses).cpu(), ts.pflat.clone().cpu(), stats)
+    for a, b in zip(got['plain'], got['pipe']):
+        assert torch.equal(a, b), 'the pipelined loop differs from the plain one at a GPU-bound size'
 
 
 def test_frozen_stage2_layers_without_raw_tensors_change_nothing(monkeypatch):

@@ -197,6 +197,44 @@ def test_b2b_pairs_of_the_r50_plan():
     assert b2b_pairs(p18.ops, HipExecutor._op_io, p18.buffers, set(), lambda c: True) == []
 
 
+def test_tracked_maximum_blocks_of_the_r50_plan():
+    """engine.assign_amax (device-free part of HipExecutor._assign_amax; round 6, the round-5 advisor's aliasing): the wide buffer
+    [conv2 output | pooled block input] of a stage's first block (the folded projection shortcut, model/resnet_vd.py:27-33) has a
+    block of its OWN for what conv2 / the DCNv2 launch writes and keeps the block of the tensor it was pooled from as a second,
+    read-only one: the fused 1x1 reads both, and NO other reader of the block input -- the head's C3 / C4 convolutions, conv1 of
+    the block itself -- sees a block that conv2 writes into."""
+    from ppyolo_hip.engine import HipExecutor, assign_amax
+    cfg = PPYOLO_2x_Config()
+    model, _ = build_model(cfg)
+    plan = build_plan(model, 2, 160, 160, 'cpu')
+    n = assign_amax(plan.ops)
+    convs = [o for o in plan.ops if o['op'] in ('conv', 'dcn')]
+    assert n > 0 and all(o['amax_out_id'] is not None and 0 <= o['amax_out_id'] < n for o in convs)
+    two = [o for o in convs if o.get('amax_in2_id') is not None]
+    # the four fused conv3 launches (C = 128, 384, 768, 1536), and stage 2's conv1, which reads the pooled half of the same buffer
+    fused = [o for o in two if o['x'].C == plan.buffers[o['x'].buf][3]]
+    assert sorted(o['x'].C for o in fused) == [128, 384, 768, 1536] and all(tuple(o['w'].shape)[1:3] == (1, 1) for o in fused)
+    writers = {}
+    for o in convs:
+        writers.setdefault(o['amax_out_id'], []).append(o)
+    for o in fused:
+        assert o['amax_in_id'] != o['amax_in2_id']
+        # the own block is written by conv2 (a 3x3 or the DCNv2 launch) only; the second block by the producers of the block INPUT only
+        assert all(w['y'].buf == o['x'].buf for w in writers[o['amax_in_id']])
+        assert all(w['y'].buf != o['x'].buf for w in writers.get(o['amax_in2_id'], []))
+    # the head's readers of C3 / C4 (feature maps; concat buffers with the upsampled routes) scale by their own producers' maxima
+    feat_bufs = {a.buf for a in plan.feats}
+    for o in convs:
+        if o['x'].buf in feat_bufs and o.get('amax_in2_id') is None:
+            assert all(w['y'].buf == o['x'].buf for w in writers[o['amax_in_id']]), 'a foreign writer merges into a feature map\'s block'
+    # pooled tensors still inherit: every reader of a buffer that holds ONLY a pooled tensor has its source's block
+    for o in plan.ops:
+        if o['op'] in ('avgpool', 'maxpool'):
+            for c in convs:
+                if c['x'].buf == o['y'].buf:
+                    assert c['amax_in_id'] is not None
+
+
 def test_dcn_configuration_ids_and_weight_prep_descriptor_layout():
     """Host-side bookkeeping of round 3 that needs no device: (1) the fused-DCNv2 ids -- [0, 18) = scheme * 6 + four-wave tile, from
     18 the eight-wave f16x2 tiles -- as ops.dcnv2_scheme / dcnv2_configs hand them to the plan and the tuner; every committed
