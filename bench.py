@@ -222,6 +222,118 @@ def pmc_traffic_leg(argv_tail, nconv, timeout=120, extra_kernels=()):
                                     seconds=round(time.perf_counter() - t0, 1), stale=False)
 
 
+def traced_pass(ex, steps=3, warm=2):
+    """The --trace-child loop: eager one-lane passes of the plan with a marker launch (ppy_debug_marker: grid = op index + 1
+    workgroups) in front of every op, one more in front of decode + Matrix-NMS and one behind them -- what kernel_trace_leg cuts a
+    `rocprofv3 --kernel-trace` into."""
+    import ctypes
+    from ppyolo_hip import _lib
+    from ppyolo_hip.ops import _stream
+    mark = _lib.lib().ppy_debug_marker
+    mark.restype, mark.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]
+    n = len(ex.plan.ops)
+    for _ in range(warm + steps):
+        ex.amax.zero_()
+        for i, op in enumerate(ex.plan.ops):
+            mark(i, _stream())
+            ex._run_op(op)
+        mark(n, _stream())
+        if ex.plan.decode is not None:
+            ex._run_decode()
+        mark(n + 1, _stream())
+        torch.cuda.synchronize()
+
+
+def kernel_trace_leg(argv_tail, ex, per_op_flops, steps=3, timeout=180, table_path=None):
+    """Solo kernel time of the plan's launches from a ONE-LANE, EAGER `rocprofv3 --kernel-trace` of this tree, taken by this run:
+    bench.py re-executes itself as a short child (--trace-child: traced_pass above) under the profiler and cuts the dispatch list
+    into plan ops at the marker launches.  A launch's time is End - Start of its kernels (split-K combine, a pooling launch that
+    follows its producer: all kernels between two markers belong to the op in front) -- no host gaps, no event packets.  Returns
+    (dict for the bench line, per-op rows) or (None, reason).  round-5 review, item 3."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from ppyolo_hip.engine import tune_key
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    d = tempfile.mkdtemp(prefix='ppy_ktrace_')
+    t0 = time.perf_counter()
+    try:
+        cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'kt', '--',
+               sys.executable, os.path.abspath(__file__), '--trace-child'] + argv_tail
+        subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout, check=True)
+        rows = []
+        for f in glob.glob(os.path.join(d, '**', '*kernel_trace*.csv'), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    g = r.get('Grid_Size_X') or r.get('Grid_Size') or '0'
+                    w = r.get('Workgroup_Size_X') or r.get('Workgroup_Size') or '64'
+                    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], int(float(g)), int(float(w))))
+        rows.sort()
+    except Exception as exc:
+        return None, 'kernel-trace pass failed: %s' % type(exc).__name__
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    nops = len(ex.plan.ops)
+    # cut at the markers: a step starts at marker 0 and ends at marker nops + 1
+    passes, cur, cur_id = [], None, None
+    for s, e, name, grid, wg in rows:
+        if 'ppy_marker_kernel' in name:
+            mid = grid // max(1, wg) - 1 if grid >= wg else grid - 1      # (grid in work-items; some versions report workgroups)
+            if mid == 0:
+                cur = dict(start=s, ops={}, end=None)
+            if cur is not None:
+                cur_id = mid
+                if mid == nops + 1:
+                    cur['end'] = s
+                    passes.append(cur)
+                    cur, cur_id = None, None
+            continue
+        if cur is not None and cur_id is not None:
+            ent = cur['ops'].setdefault(cur_id, [0.0, []])
+            ent[0] += (e - s) * 1e-3          # us
+            ent[1].append(name)
+    if len(passes) < steps:
+        return None, 'only %d complete passes in the trace' % len(passes)
+    passes = passes[-steps:]
+    convs = [i for i, op in enumerate(ex.plan.ops) if op['op'] in ('conv', 'dcn') and op.get('b2b_of') is None]
+    us = {i: sum(p['ops'].get(i, [0.0])[0] for p in passes) / len(passes) for i in list(range(nops + 1))}
+    conv_ms = sum(us[i] for i in convs) * 1e-3
+    other_ms = sum(us[i] for i in range(nops) if i not in convs) * 1e-3
+    span_ms = sum(p['end'] - p['start'] for p in passes) / len(passes) * 1e-6
+    table = []
+    for i, op in enumerate(ex.plan.ops):
+        key = tune_key(op) if op['op'] in ('conv', 'dcn') else op['op']
+        if op.get('b2b') is not None:
+            key += ' + ' + tune_key(op['b2b']) + ' (one launch)'
+        elif op.get('b2b_of') is not None:
+            key += ' (fused into the launch in front of it)'
+        names = passes[-1]['ops'].get(i, [0.0, []])[1]
+        table.append(dict(i=i, key=key, cfg=op.get('cfg'), splitk=op.get('splitk'), us=round(us[i], 2), kernels=len(names),
+                          gflop=round(per_op_flops[i] / 1e9, 3),
+                          tflops=round(per_op_flops[i] / (us[i] * 1e-6) / 1e12, 1) if us[i] > 0 and per_op_flops[i] else 0.0))
+    table.append(dict(i=nops, key='decode + matrix_nms', cfg=None, splitk=None, us=round(us[nops], 2),
+                      kernels=len(passes[-1]['ops'].get(nops, [0.0, []])[1]), gflop=0.0, tflops=0.0))
+    if table_path:
+        with open(table_path, 'w') as fh:
+            fh.write('# one lane, eager, rocprofv3 --kernel-trace of `bench.py --trace-child %s`: per plan op, mean over %d passes of the summed\n'
+                     '# End - Start of its kernels (us); markers (ppy_marker_kernel) cut the dispatch list.  conv / DCN launches: %.3f ms,\n'
+                     '# other plan ops %.3f ms, decode + Matrix-NMS %.3f ms; first marker -> last marker %.3f ms per pass (includes host gaps\n'
+                     '# of the eager loop).\n' % (' '.join(argv_tail), len(passes), conv_ms, other_ms, us[nops] * 1e-3, span_ms))
+            fh.write('%4s %-100s %5s %3s %9s %3s %8s %7s\n' % ('op', 'key', 'cfg', 'sk', 'us', 'n', 'GFLOP', 'TF/s'))
+            for r in table:
+                fh.write('%4d %-100s %5s %3s %9.2f %3d %8.3f %7.1f\n' % (r['i'], r['key'][:100], r['cfg'], r['splitk'], r['us'], r['kernels'],
+                                                                         r['gflop'], r['tflops']))
+    return dict(kernel_ms_per_step=round(conv_ms, 4), other_plan_ops_ms=round(other_ms, 4), decode_nms_ms=round(us[nops] * 1e-3, 4),
+                passes=len(passes), seconds=round(time.perf_counter() - t0, 1),
+                measured_by='this run: rocprofv3 --kernel-trace of an eager one-lane child (bench.py --trace-child), dispatches cut into '
+                            'plan ops at marker launches; sum of End - Start over the conv / DCN ops\' kernels, mean of %d passes' % len(passes)), table
+
+
 class _SmiSampler(object):
     """Socket power and shader clock from rocm-smi every ~0.25 s on a thread (diagnostic: --power-trace)."""
 
@@ -740,6 +852,60 @@ def preprocess_leg(cfg, size, batch, lanes, steps, with_cpu):
     return res
 
 
+def parity_note_leg(model, wl, batch, x):
+    """The headline parity figure in the bench line (round-5 review, item 7): this workload's batch against the rows the REFERENCE
+    ITSELF produced for it (tests/golden/g18_*.npz, made by tools/make_goldens.py importing the reference: im_size (480, 640), the
+    same images and weights as `value`) -- how many of the kept boxes lie beyond the north star's literal 1e-3 px, for this HIP
+    path and for the reference against itself (its own runs with another thread count / conv backend / one image at a time).
+    Data only: no oracle and no reference code runs here."""
+    import numpy as np
+    tag = {('PPYOLO_2x_Config', 608): 'r50vd_608', ('PPYOLO_r18vd_Config', 416): 'r18vd_416'}.get((wl['cfg'], wl['size']))
+    path = os.path.join(ROOT, 'tests', 'golden', 'g18_%s.npz' % tag) if tag else None
+    if not path or not os.path.exists(path) or batch != 8:
+        return None
+    g = np.load(path)
+    if int(g['meta'][0]) != wl['size'] or int(g['meta'][1]) != batch:
+        return None
+    runs = [str(r) for r in g['runs']]
+    alts = [r for r in runs if r not in ('t8', 'f64')]
+    ims = torch.from_numpy(g['im_size_a']).float()
+    dets, cnt, keep = model.forward_padded(x, ims.to(x.device))
+    torch.cuda.synchronize()
+    dets, cnt, keep = dets.cpu().double(), cnt.cpu(), keep.cpu().numpy()
+
+    def dist(rows_a, keep_a, rows_b, keep_b):       # rows matched by keep index (= candidate id: the same detection)
+        pos = {int(k): j for j, k in enumerate(keep_b)}
+        ia = [i for i, k in enumerate(keep_a) if int(k) in pos]
+        ib = [pos[int(keep_a[i])] for i in ia]
+        A, B = rows_a[ia], rows_b[ib]
+        return (A[:, 2:] - B[:, 2:]).abs().max(dim=1).values, (A[:, 1] - B[:, 1]).abs().max(), len(keep_b) - len(ia), ia == ib
+
+    hip_beyond = ref_beyond = boxes = unmatched = 0
+    hip_max = ref_max = score_max = 0.0
+    same_order = True
+    for i in range(batch):
+        ref, rkeep = torch.from_numpy(g['t8_a_pred%d' % i]).double(), g['t8_a_keep%d' % i]
+        kk = int(cnt[i])
+        d, es, un, so = dist(dets[i, :kk], keep[i, :kk], ref, rkeep)
+        hip_beyond += int((d > 1e-3).sum()); boxes += int(ref.shape[0]); unmatched += un + abs(kk - ref.shape[0])
+        hip_max, score_max, same_order = max(hip_max, float(d.max())), max(score_max, float(es)), same_order and so
+        worst = 0
+        for r in alts:
+            dr = dist(torch.from_numpy(g['%s_a_pred%d' % (r, i)]).double(), g['%s_a_keep%d' % (r, i)], ref, rkeep)[0]
+            worst = max(worst, int((dr > 1e-3).sum()))
+            ref_max = max(ref_max, float(dr.max()))
+        ref_beyond += worst
+    return dict(text='boxes beyond 1e-3 px: HIP %d / reference-vs-itself %d of %d (max %.2e / %.2e px); scores max %.1e; keep indices %s'
+                     % (hip_beyond, ref_beyond, boxes, hip_max, ref_max, score_max,
+                        'identical, same order' if (unmatched == 0 and same_order) else ('identical set' if unmatched == 0 else '%d differ' % unmatched)),
+                hip_boxes_beyond_1e_3_px=hip_beyond, reference_vs_itself_boxes_beyond_1e_3_px=ref_beyond, boxes=boxes,
+                hip_max_box_err_px=round(hip_max, 6), reference_vs_itself_max_px=round(ref_max, 6), max_score_err=float('%.2e' % score_max),
+                keep_indices_identical=unmatched == 0, same_order=bool(same_order),
+                against='tests/golden/g18_%s.npz: rows + keep indices made by the reference itself (8 threads), im_size (480, 640); '
+                        'reference-vs-itself = per image the worst of its other fp32 runs (%s), summed' % (tag, ', '.join(alts)),
+                north_star='box coords <= 1e-3, scores <= 1e-4, keep indices bit-exact')
+
+
 def cpu_baseline(sd, cfg, size, batch):
     """Oracle (PyTorch-CPU restatement of the reference forward) on the host cores."""
     from oracle import ppyolo_oracle as orc
@@ -989,6 +1155,9 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
                     '(then the committed summary under profiles/ is quoted, marked stale)')
     ap.add_argument('--pmc-child', action='store_true', help='(internal) the short eager one-lane run the PMC passes profile')
+    ap.add_argument('--trace-child', action='store_true', help='(internal) the eager one-lane run with op markers that kernel_trace_leg profiles')
+    ap.add_argument('--no-kernel-trace', action='store_true', help='skip the rocprofv3 --kernel-trace child pass (roofline.trace)')
+    ap.add_argument('--trace-layers', default=None, help='write the trace-derived per-op table (text) to this file')
     ap.add_argument('--tune-cu-mask', default=None, help='with --autotune: measure the layers on a stream restricted to these CUs (one term of '
                     'runtime.lane_cu_masks, e.g. m256:0-127 = half of every XCD) -- the table a CU-masked lane would want')
     ap.add_argument('--no-prefetch', action='store_true', help='--train: the plain loop (no backbone prefetch of the next batch)')
@@ -1032,7 +1201,7 @@ def main():
     from ppyolo_hip import synth
     x = synth.synth_images(a.batch, wl['size'], seed=1234 + rank + a.seed_offset).to(dev)
     ims = synth.synth_im_size(a.batch).to(dev)
-    depth = 1 if a.pmc_child else max(1, a.in_flight)
+    depth = 1 if (a.pmc_child or a.trace_child) else max(1, a.in_flight)
     lanes = model.in_flight(depth).lanes(x)            # [(executor, stream)]; depth 1 = the plain forward's executor
     ex = lanes[0][0]
     for k, (e, _) in enumerate(lanes):
@@ -1074,6 +1243,9 @@ def main():
         for _ in range(3):
             ex.run()
         torch.cuda.synchronize()
+        return
+    if a.trace_child:        # profiled by kernel_trace_leg: eager passes with a marker launch in front of every plan op
+        traced_pass(ex)
         return
     gats = [pd.DetectionGatherer(a.batch, ex.out_dets.shape[1], dev, world) for _ in lanes]
     for e, _ in lanes:
@@ -1212,8 +1384,22 @@ def main():
     if rank == 0:
         total_flops, per_op = conv_flops(ex.plan)
         conv_ms, covered, nconv, ideal_s, fam_flops = timed_conv_pass(ex, per_op)
-        achieved = covered / (conv_ms * 1e-3) / 1e12
         peak = covered / ideal_s / 1e12        # flop-weighted peak of the kernel mix of this step
+        # Round 6 (review item 3): the solo kernel time comes from PROFILER TIMESTAMPS of a one-lane eager child of this run where
+        # rocprofv3 is available (kernel_trace_leg); an event pair around a launch also times two event packets (~2.5 us per
+        # launch, 5 % over 75 launches: `hip_events_over_trace`), so the HIP-event sum is kept beside it as the cross-check.
+        conv_ms_events, timing = conv_ms, 'HIP events around every conv / DCN launch of an eager pass (best of 3)'
+        ktrace = None
+        if world == 1 and not a.no_kernel_trace:
+            ktrace, ktab = kernel_trace_leg(['--workload', a.workload, '--batch', str(a.batch)], ex, per_op, table_path=a.trace_layers)
+            if ktrace is None:
+                ktrace = dict(error=ktab)
+            else:
+                ktrace['hip_events_over_trace'] = round(conv_ms_events / ktrace['kernel_ms_per_step'], 4)
+                conv_ms = ktrace['kernel_ms_per_step']
+                timing = ('rocprofv3 --kernel-trace timestamps of an eager one-lane child of this run (sum of End - Start of the conv / DCN '
+                          'launches\' kernels, mean of %d passes)' % ktrace['passes'])
+        achieved = covered / (conv_ms * 1e-3) / 1e12
         # HBM-side bytes of the conv launches from rocprofv3 PMC passes (collected separately with
         # tools/prof_run.sh; summary committed under profiles/): average per launch, like `achieved`
         traffic, traffic_src = None, None
@@ -1239,7 +1425,7 @@ def main():
                     kernel='conv_igemm_x3_kernel<*> (fp32-in/fp32-out implicit GEMM on the 16-bit MFMA: f16x2 = 3 x '
                            'v_mfma_f32_32x32x16_f16 per product after a 2-term fp16 split, bf16x3 = 6 x ..._bf16 after a 3-term '
                            'bf16 split) / conv_igemm_glds_kernel<*> (v_mfma_f32_32x32x2_f32), %d launches/step' % nconv,
-                    peak_note='achieved = algorithmic fp32 FLOPs / HIP-event time of the conv launches; peak = the same '
+                    peak_note='achieved = algorithmic fp32 FLOPs / solo kernel time of the conv launches (kernel_ms_per_step; timing: ' + timing + '); peak = the same '
                               'FLOPs / MFMA-pipe time at peak, pricing a launch by its kernel family: f16x2 %.1f (= dense '
                               '16-bit MFMA %.1f / 3 products per multiply-add), bf16x3 %.1f (/ 6), exact fp32 %.1f TFLOP/s; '
                               'FLOP shares: %s.  Peaks are at the nominal 2.4 GHz; under dense 16-bit MFMA on real '
@@ -1247,7 +1433,8 @@ def main():
                                   F16X2_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, X3_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS,
                                   ', '.join('%s %.1f%%' % (k, 100.0 * v / max(1, covered)) for k, v in fam_flops.items())),
                     achieved_vs_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 3),
+                    flops_per_step=covered, kernel_ms_per_step=round(conv_ms, 4), kernel_ms_per_step_hip_events=round(conv_ms_events, 3),
+                    kernel_timing=timing, trace=ktrace,
                     whole_step_mfma_util=round(total_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4))
         if one_at_a_time is not None:
             ms_one = a.batch / one_at_a_time * 1e3
@@ -1315,6 +1502,13 @@ def main():
                                                                  not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg, wl['size'], a.batch)
+        if world == 1:
+            try:
+                pn = parity_note_leg(model, wl, a.batch, x)
+            except Exception as exc:          # (a diagnostic field must not take the benchmark line with it)
+                pn = dict(error='%s: %s' % (type(exc).__name__, exc))
+            if pn is not None:
+                out['parity_note'] = pn
         if world == 1 and not a.no_worst_case:
             out['worst_case_regime'] = worst_case_leg(wl, dev, x, ims, sd, cfg, depth, min(a.min_seconds, 1.0) or 0.2,
                                                       out['cpu_baseline']['cores'] if 'cpu_baseline' in out else 0)

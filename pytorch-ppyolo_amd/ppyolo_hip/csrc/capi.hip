@@ -52,3 +52,15 @@ extern "C" int ppy_lane_stream_destroy(void *stream) {
     }
     return PPY_OK;
 }
+
+// Debug hook (not part of the ABI in include/ppyolo_hip.h, like ppy_debug_set_trace): an empty kernel whose GRID SIZE carries an
+// id -- (id + 1) workgroups of 64 lanes -- so that a `rocprofv3 --kernel-trace` of an eager pass can be cut into the plan's ops by
+// the markers launched in front of them (bench.py --trace-child / kernel_trace_leg; tools/trace_layers.py).
+namespace {
+__global__ void __launch_bounds__(64) ppy_marker_kernel() {}
+}  // namespace
+extern "C" int ppy_debug_marker(int id, void *stream) {
+    if (id < 0 || id >= (1 << 20)) return PPY_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ppy_marker_kernel, dim3(id + 1), dim3(64), 0, (hipStream_t)stream);
+    return PPY_OK;
+}

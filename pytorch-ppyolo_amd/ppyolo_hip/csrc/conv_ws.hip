@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
             }
         }
         const int RS = p.R * p.S;
+        const bool a_nt = (p.nt & 2) != 0 || ((p.nt & 1) != 0 && RS == 1);      // (ConvArgs::nt)
         int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
         int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
         const char *xb = reinterpret_cast<const char *>(p.x) - bias;
@@ -111,7 +112,10 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 #pragma unroll
             for (int d = 0; d < A_PASS; ++d) {
                 const unsigned off = (a_ok[d] & tapbit) ? a_off[d] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 0);
+                if (a_nt)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 2);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < B_PASS; ++j) {

@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
     const char *xb = reinterpret_cast<const char *>(p.x) - bias;
     const char *wb = reinterpret_cast<const char *>(F16 ? p.wf16 : p.w3);
+    const bool a_nt = (p.nt & 2) != 0 || ((p.nt & 1) != 0 && RS == 1);      // (wave-uniform: ConvArgs::nt)
 
     // One chunk = G DMA pieces per wave.  begin/piece/end are separate so that the steady-state loop can
     // drop one piece into an MFMA slot at a time (a piece costs ~60+ issue cycles: M0 write + buffer_load);
@@ -259,7 +260,10 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                 return;
             }
             const unsigned off = (a_ok[d] & cur_tapbit) ? a_off[d] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
+            if (a_nt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
         } else {
             if (PPY_X3_ABL == 9) return;                    // (ablation: activation pieces only)
             const int j = d - A_PASS;

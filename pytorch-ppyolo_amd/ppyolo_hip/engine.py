@@ -508,6 +508,17 @@ class HipExecutor(object):
                     ent = tab.get(k0) or tab_x3.get(k0)
                 if ent:
                     op['cfg'], op['splitk'] = ent[:2]
+        if os.environ.get('PPYOLO_HIP_HEAD_TAIL_FP32', '0') == '1':
+            # experiment (round-5 review, item 7): the last two convolutions of every head level -- the tip 3x3 and the output 1x1 -- on
+            # the exact-fp32 MFMA kernels, everything in front of them as usual.  Measured: does not move the count of boxes beyond
+            # 1e-3 px at R50vd-608; off by default.
+            outs = {a.buf for a in p.head_outs}
+            tail = [op for op in p.ops if op['op'] == 'conv' and op['y'].buf in outs]
+            tips = [op for op in p.ops if op['op'] == 'conv' and any(op['y'].buf == t['x'].buf for t in tail)]
+            for op in tail + tips:
+                x = op['x']
+                Kout, R, S, C = op['w'].shape
+                op['cfg'], op['splitk'] = K.conv2d_pick(x.N, x.H, x.W, C, Kout, R, S, op['stride'], op['pad'])
         self.ws = None
         self.ws_side = None
         self._size_workspace()

@@ -24,9 +24,19 @@ tr = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
 L = _lib.lib()._handle
 lib = ctypes.CDLL(_lib.LIB_PATH)
 w3 = ops.split_weights_bf16x3(w); wf16 = ops.split_weights_f16x2(w, sc); amax0 = ops.amax_slots(x)
+xs = None
+if os.environ.get('PPY_TRACE_GP', '0') == '1':      # the input as a PRE-SPLIT tensor (what a linked producer stores): per pixel and 32-channel
+    # group 32 fp16 first terms then 32 fp16 second terms of x * s_image -- the ':g' layers of the plan
+    mx = x.abs().amax(dim=(1, 2, 3))
+    xs = torch.pow(2.0, 13 - torch.floor(torch.log2(mx)))
+    v = x * xs.view(-1, 1, 1, 1)
+    h0 = v.half()
+    h1 = (v - h0.float()).half()
+    packed = torch.stack([h0.view(N, H, W, C // 32, 32), h1.view(N, H, W, C // 32, 32)], dim=4).contiguous()      # [N,H,W,C/32,2,32] fp16
+    x = packed.view(torch.float32).view(N, H, W, C).contiguous()
 def run():
     ops.conv2d_bn_act(ops.View(x), w, sc, sh, ops.View(y), stride, pad, 'relu', residual=None if res is None else ops.View(res), cfg=cfg,
-                      splitk=splitk, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0)
+                      splitk=splitk, ws=ws, w_x3=w3, w_f16=wf16, amax_in=amax0, x_split=xs)
 for _ in range(int(os.environ.get('PPY_TRACE_WARM', '3'))): run()
 torch.cuda.synchronize()
 lib.ppy_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
