@@ -571,12 +571,6 @@ static unsigned long long *g_trace = nullptr;
 // (4 x u64 per workgroup); tools/conv_trace.py turns that into a per-CU timeline.
 extern "C" void ppy_debug_set_trace(unsigned long long *buf) { g_trace = buf; }
 
-// Cache policy of the streamed accesses of the f16x2 kernels (ConvArgs::nt): PPY_NT overrides the built-in choice (A/B runs).
-int ppy_nt_policy() {
-    static const int v = getenv("PPY_NT") ? atoi(getenv("PPY_NT")) : 0;
-    return v;
-}
-
 static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void *w_x3,
                        const void *w_f16x2, const float *scale, const float *scale_f16x2,
                        const float *shift, const float *residual, int res_ld,
@@ -609,7 +603,6 @@ static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void
     p.x = x; p.w = w_krsc; p.w3 = (const unsigned short *)w_x3; p.wf16 = (const unsigned short *)w_f16x2;
     p.scale_f16 = scale_f16x2; p.posb_f16 = posbias_f16x2; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale; p.shift = shift; p.res = residual; p.posb = posbias;
     p.amax_in2 = amax_in ? amax_in2 : nullptr;
-    p.nt = ppy_nt_policy();
     p.y = y; p.part = (float *)ws;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = g.Ho; p.Wo = g.Wo; p.K = K; p.R = R; p.S = S;
@@ -728,7 +721,7 @@ extern "C" int ppy_conv1x1_expand_f32(const float *x, int x_ld, const void *w_f1
     ConvArgs p;
     p.x = x; p.w = nullptr; p.w3 = nullptr; p.wf16 = (const unsigned short *)w_f16x2;
     p.scale_f16 = scale_f16x2; p.posb_f16 = nullptr; p.amax_in = amax_in; p.amax_out = amax_out; p.scale = scale_f16x2; p.shift = shift;
-    p.res = residual; p.posb = nullptr; p.y = y; p.part = nullptr; p.nt = ppy_nt_policy();
+    p.res = residual; p.posb = nullptr; p.y = y; p.part = nullptr;
     p.x_ld = x_ld; p.res_ld = res_ld; p.y_ld = y_ld;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = H; p.Wo = W; p.K = K; p.R = 1; p.S = 1;
     p.stride = 1; p.pad = 0; p.act = act; p.ups = 0;

@@ -45,10 +45,6 @@ struct ConvArgs {
     float *yscale = nullptr;        // producer: [N] per-image scales of the split output it writes (NULL: plain fp32 output)
     float ysplit_mul = 0.f, ysplit_add = 0.f;
     const float *xscale = nullptr;  // consumer: [N] per-image scales of its pre-split input (NULL: fp32 input, tracked maximum)
-    // round 6: cache policy of the streamed accesses (PPY_NT, conv_igemm.hip ppy_nt_policy(); results never depend on it).  Bits:
-    // 1 = "nt" on the activation LDS-DMA of 1x1 layers (every row is read by ONE workgroup per column tile: nothing to keep in
-    // the CU's L1), 2 = on every layer's, 4 = on the shortcut loads of the epilogue, 8 = on the output stores.
-    int nt = 0;
 };
 
 // scale of a pre-split tensor from a bound of its magnitude: the power of two that puts `bound` into [2^13, 2^14), as the
@@ -126,7 +122,6 @@ __device__ __forceinline__ void ppy_tile_of(const ConvArgs &p, int tiles_n, int 
 }
 #endif
 
-int ppy_nt_policy();          // conv_igemm.hip: ConvArgs::nt for this process (PPY_NT)
 int ppy_stream_num_configs();
 int ppy_stream_dispatch(const ConvArgs &p, int local_cfg, float *pool, int pool_ld, hipStream_t stream);
 // conv_patch.hip: 3x3 / stride 1 / pad 1 with C = 32 (the stem layers), input patch staged once per output tile (f16x2 operands)
@@ -229,10 +224,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                         const int col = n0 + wn * WN + j * 32 + ec4;
                         const int m = m0 + wm * WM + i * 32 + erow + 8 * t;
                         rv[i][j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
-                        if (col < p.K && m < p.M) {
-                            const floatx4 *rp = reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
-                            rv[i][j][t] = (p.nt & 4) ? __builtin_nontemporal_load(rp) : *rp;
-                        }
+                        if (col < p.K && m < p.M)
+                            rv[i][j][t] = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
                     }
         }
 #pragma unroll
@@ -293,11 +286,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                                 *reinterpret_cast<uintx2_ *>(o) = uintx2_{h0, h1};
                                 *reinterpret_cast<uintx2_ *>(o + 64) = uintx2_{l0, l1};
                             } else if (!p.ups) {
-                                floatx4 *yp = reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col);
-                                if (p.nt & 8)
-                                    __builtin_nontemporal_store(v, yp);
-                                else
-                                    *yp = v;
+                                *reinterpret_cast<floatx4 *>(p.y + (long long)m * p.y_ld + col) = v;
                             } else {
                                 const int n = m / hw, rem = m - n * hw;
                                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;

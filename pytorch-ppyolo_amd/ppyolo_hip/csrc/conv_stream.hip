@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const unsigned off = pix[u] >= 0 ? (unsigned)pix[u] * (unsigned)(p.res_ld * 4) + (unsigned)(n0 + j * 32 + ec4) * 4u : ST_OOB;
-                rv[j][u] = (p.nt & 4) ? __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off, 0, 0);
+                rv[j][u] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off, 0, 0);
             }
         }
     };
@@ -322,10 +322,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(const StreamArgs
                 run_mx = fmaxf(run_mx, lo ? rmx : 0.f);
                 hi_mx = fmaxf(hi_mx, lo ? 0.f : rmx);
                 const unsigned off = pix[u] >= 0 ? (unsigned)pix[u] * (unsigned)(p.y_ld * 4) + (unsigned)col * 4u : ST_OOB;
-                if (p.nt & 8)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v[u]), ry, (int)off, 0, 2);
-                else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v[u]), ry, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v[u]), ry, (int)off, 0, 0);
             }
             if constexpr (POOL) {
                 floatx4 r;

@@ -14,6 +14,11 @@
 
 #include <type_traits>
 
+#ifndef PPY_WS_PRIO
+#define PPY_WS_PRIO 0     // experiment (round 6): static wave priorities (s_setprio once, before the main loop; MI355X_MICROARCH.md "Two waves
+                          // per SIMD", item 4): 1 = consumers 1 / producers 0, 2 = producers 1 / consumers 0, 3 = the younger consumer half 1
+#endif
+
 namespace {
 
 // PRE = true: the producer waves also SPLIT the activations.  A producer wave that has seen its own pieces of a chunk land
@@ -54,6 +59,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 
     if (wave >= NC) {
         // ================= producers: every LDS-DMA piece of the tile, a quarter per wave =================
+        if (PPY_WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         const int pw = wave - NC;
         const unsigned OOB = 0xFFFFFFF0u;
         const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
@@ -97,7 +103,6 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
             }
         }
         const int RS = p.R * p.S;
-        const bool a_nt = (p.nt & 2) != 0 || ((p.nt & 1) != 0 && RS == 1);      // (ConvArgs::nt)
         int l_cc = kc_begin / RS, l_tap = kc_begin - l_cc * RS;
         int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
         const char *xb = reinterpret_cast<const char *>(p.x) - bias;
@@ -112,10 +117,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 #pragma unroll
             for (int d = 0; d < A_PASS; ++d) {
                 const unsigned off = (a_ok[d] & tapbit) ? a_off[d] : OOB;
-                if (a_nt)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 2);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NWP * 1024), 16, off, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < B_PASS; ++j) {
@@ -184,6 +186,7 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     }
 
     // ================= consumers: 2 x 2 waves over the tile; LDS reads, operand split, MFMAs =================
+    if (PPY_WS_PRIO == 1 || (PPY_WS_PRIO == 3 && wave >= NC / 2)) __builtin_amdgcn_s_setprio(1);
     const int wm = wave >> 1, wn = wave & 1;
     floatx16 acc[TM][TN];
 #pragma unroll

@@ -187,7 +187,6 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
     int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
     const char *xb = reinterpret_cast<const char *>(p.x) - bias;
     const char *wb = reinterpret_cast<const char *>(F16 ? p.wf16 : p.w3);
-    const bool a_nt = (p.nt & 2) != 0 || ((p.nt & 1) != 0 && RS == 1);      // (wave-uniform: ConvArgs::nt)
 
     // One chunk = G DMA pieces per wave.  begin/piece/end are separate so that the steady-state loop can
     // drop one piece into an MFMA slot at a time (a piece costs ~60+ issue cycles: M0 write + buffer_load);
@@ -260,10 +259,7 @@ __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN)) conv_igemm_x3_kern
                 return;
             }
             const unsigned off = (a_ok[d] & cur_tapbit) ? a_off[d] : OOB;
-            if (a_nt)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 2);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_ra, (lds_ptr)(smem + cur_lds + d * NW * 1024), 16, off, 0, 0, 0);
         } else {
             if (PPY_X3_ABL == 9) return;                    // (ablation: activation pieces only)
             const int j = d - A_PASS;
@@ -714,15 +710,28 @@ int launch_x3(ConvArgs p, int splits, hipStream_t stream, int nstages = 2) {
     if ((p.xscale || p.yscale) && (!F16 || SLAB || splits > 1 || !vec || p.bn_part)) return PPY_ERR_BAD_ARG;
     if (p.yscale && p.ups) return PPY_ERR_BAD_ARG;          // (a pre-split INPUT with an upsampled fp32 store is fine)
     if (p.yscale && (p.K % 32 != 0 || p.y_ld % 32 != 0)) return PPY_ERR_BAD_ARG;
+    // Round 6: the SCALAR epilogue (K % 4 != 0 or unaligned rows: rare, never a layer of the plan) exists for wave tiles of up to four
+    // 32x32 accumulator tiles only.  With six or eight the fully unrolled scalar store loop spills (416-576 bytes of scratch, no
+    // AGPRs), and hipcc (ROCm 7.2) then mixed up two of its row predicates: 192x256 / N3 C96 K258 6x25 left acc[1][1][10] of the last
+    // tile_m unstored, deterministically (tools/experiments/r06_case11.py).  Such a launch is refused; ppy_conv2d_bn_act_f32 then takes
+    // the exact-fp32 fall-back tile, as for any configuration that does not support a shape.
+    constexpr bool BIG_WAVE_TILE = (WM / 32) * (WN / 32) >= 6;
+    if (BIG_WAVE_TILE && !vec) return PPY_ERR_UNSUPPORTED;
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, F16, true, false, SLAB>(p, splits, lds, tiles, stream);
+        if constexpr (BIG_WAVE_TILE)
+            rc = launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream);
+        else
+            rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, true, true, SLAB>(p, splits, lds, tiles, stream)
+                     : launch_x3_one<BM, BN, WM, WN, F16, true, false, SLAB>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, false, true, SLAB>(p, splits, lds, tiles, stream)
-                 : launch_x3_one<BM, BN, WM, WN, F16, false, false, SLAB>(p, splits, lds, tiles, stream);
+        if constexpr (BIG_WAVE_TILE)
+            rc = launch_x3_one<BM, BN, WM, WN, F16, false, true, SLAB>(p, splits, lds, tiles, stream);
+        else
+            rc = vec ? launch_x3_one<BM, BN, WM, WN, F16, false, true, SLAB>(p, splits, lds, tiles, stream)
+                     : launch_x3_one<BM, BN, WM, WN, F16, false, false, SLAB>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
