@@ -1133,6 +1133,7 @@ def main():
     ap.add_argument('--freeze-at', type=int, default=None, help='--train: backbone stages 1..N frozen (default: the configuration\'s 5 = the '
                     'head trains; 1..4 add stages, incl. the DCNv2 backward of stage 5)')
     ap.add_argument('--tune-kinds', default='conv,dcn', help='with --autotune: plan op kinds to re-measure (conv,dcn)')
+    ap.add_argument('--tune-cfgs', default=None, help='with --autotune: measure only these comma-separated tile ids against every layer\'s current entry')
     ap.add_argument('--tune-match', default=None, help='with --autotune: only the layers whose table key contains all of these '
                     'comma-separated pieces (e.g. ":C64:,:R1:")')
     ap.add_argument('--insitu-tune', action='store_true', help='with --autotune: re-rank the front-runners of every layer by their duration inside a '
@@ -1219,7 +1220,8 @@ def main():
             tune_ctx = torch.cuda.stream(_tune_stream.stream)
         with tune_ctx:
             for alt in (a.tune_match.split('|') if a.tune_match else [None]):      # "a,b|c,d": layers matching (a and b) or (c and d)
-                ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None)
+                ex.autotune(iters=5, verbose=a.verbose_tune, kinds=tuple(a.tune_kinds.split(',')), match=alt.split(',') if alt else None,
+                            only_cfgs=[int(v) for v in a.tune_cfgs.split(',')] if a.tune_cfgs else None)
             torch.cuda.synchronize()
         if a.insitu_tune:
             changed = ex.insitu_tune(topk=a.insitu_topk, verbose=a.verbose_tune)

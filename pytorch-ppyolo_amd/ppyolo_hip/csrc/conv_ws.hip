@@ -14,11 +14,6 @@
 
 #include <type_traits>
 
-#ifndef PPY_WS_PRIO
-#define PPY_WS_PRIO 0     // experiment (round 6): static wave priorities (s_setprio once, before the main loop; MI355X_MICROARCH.md "Two waves
-                          // per SIMD", item 4): 1 = consumers 1 / producers 0, 2 = producers 1 / consumers 0, 3 = the younger consumer half 1
-#endif
-
 namespace {
 
 // PRE = true: the producer waves also SPLIT the activations.  A producer wave that has seen its own pieces of a chunk land
@@ -29,10 +24,19 @@ namespace {
 // layout), in the issue slots of the waves that feed the MFMA pipe.  Same values, same products: bit-identical results.
 // GP = true: the input arrives pre-split from its producer (conv_x3.hip, ConvArgs::xscale): same DMA, the consumers' fragment
 // reads are the operands.
-template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false>      // (BNS: conv_x3.hip)
-__global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
+// KP = true (round 6, "k-parity"; 128-row tiles): EIGHT consumer waves as two groups of 2 x 2 over the SAME 128 x BN tile; group g
+// multiplies k-step g (16 deep) of every 32-deep chunk.  A SIMD then holds two consumer waves that cover each other's LDS / barrier
+// latencies -- what made the 256-row twelve-wave form the fastest on the big layers -- without a 256-row tile, whose grid is too
+// coarse for the 19x19 / 38x38 maps (M = 2888 / 11552 rows at batch 8) and for batch 1.  Measured before (profiles/
+// r06_conv_trace_phases.txt): one consumer wave per SIMD runs the 128x128 main loop at 34-46 % of the matrix pipe, two at 77 %.
+// The groups' accumulators are added through the LDS when the reduction ends (group 0's + group 1's: one more fp32 rounding than
+// the other tiles, like a split-K of two; deterministic), each group then finishes ONE 32-column half of every wave tile -- eight
+// waves share the store-bound epilogue instead of four.
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false, bool KP = false>      // (BNS: conv_x3.hip)
+__global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2;              // consumer waves: CM x 2 over the tile (256-row tiles: eight)
+    static_assert(!KP || (BM == 128 && !PRE && !BNS), "k-parity consumers: 128-row tiles, plain / pre-split input, no BatchNorm statistics");
+    constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2 * (KP ? 2 : 1);      // consumer waves: CM x 2 over the tile (256-row tiles: eight; KP: two such groups)
     constexpr int WM = BM / CM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
     static_assert(BM % (8 * NWP) == 0 && B_ROWS % (16 * NWP) == 0, "whole DMA instructions per producer wave");
@@ -59,7 +63,6 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 
     if (wave >= NC) {
         // ================= producers: every LDS-DMA piece of the tile, a quarter per wave =================
-        if (PPY_WS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         const int pw = wave - NC;
         const unsigned OOB = 0xFFFFFFF0u;
         const long long bias = (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;   // keeps offsets >= 0
@@ -186,8 +189,9 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     }
 
     // ================= consumers: 2 x 2 waves over the tile; LDS reads, operand split, MFMAs =================
-    if (PPY_WS_PRIO == 1 || (PPY_WS_PRIO == 3 && wave >= NC / 2)) __builtin_amdgcn_s_setprio(1);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = KP ? wave >> 2 : 0;              // KP: the k-step of every chunk this wave multiplies
+    const int wq = KP ? wave & 3 : wave;
+    const int wm = wq >> 1, wn = wq & 1;
     floatx16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -247,8 +251,8 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
     constexpr int PER = (NSL + (NM - LEAD) - 1) / (NM - LEAD);
     // One k-step: NM slots { one MFMA of step g ; at most RPS LDS reads for step g+1 ; PER stages of the split of step g+1's A
     // fragments }, fenced so that hipcc keeps that order (conv_x3.hip's step() without the DMA pieces)
-    auto step = [&](const Frag &cur, Frag &nxt, int stage, auto s_tag) {
-        constexpr int s = decltype(s_tag)::value;      // k-step (0/1) of the chunk the NEXT operands come from
+    auto step = [&](const Frag &cur, Frag &nxt, int stage, const int ao0, const int ao1, const int bo, const int apo) {
+        // ao0 / ao1 / bo / apo: fragment offsets of the k-step (0/1) of the chunk the NEXT operands come from (a_foff[s][.], b_foff[s], ap_foff[s])
         constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0};      // a1*b0, a0*b1, a0*b0: smallest first
         const char *a_ptr = PRE ? smem + stage * STAGE + A_BYTES + wm * WM * 64 : smem + stage * STAGE + wm * WM * 128;
         const char *b_ptr = smem + stage * STAGE + A_BYTES + AP_BYTES + wn * WN * 64;
@@ -267,14 +271,14 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
                 if (r >= NR) {
                 } else if (r < NRA) {
                     if constexpr (PRE)      // (tile r>>1, plane r&1)
-                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r & 1) * BM * 64 + (r >> 1) * 32 * 64 + ap_foff[s]);
+                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r & 1) * BM * 64 + (r >> 1) * 32 * 64 + apo);
                     else if constexpr (GP)  // (tile r>>1, term r&1) of the pre-split rows
-                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                        nxt.a[r >> 1][r & 1] = *reinterpret_cast<const uintx4 *>(a_ptr + (r >> 1) * 32 * 128 + ((r & 1) ? ao1 : ao0));
                     else
-                        raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + a_foff[s][r & 1]);
+                        raw[r >> 1][r & 1] = *reinterpret_cast<const floatx4 *>(a_ptr + (r >> 1) * 32 * 128 + ((r & 1) ? ao1 : ao0));
                 } else {
                     const int pl = (r - NRA) / TN, j = (r - NRA) % TN;
-                    nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[s]);
+                    nxt.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + bo);
                 }
             }
             if (m >= LEAD) {
@@ -303,13 +307,14 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(nxt.a[i][pl]));
     };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
+    // this wave's first k-step: 0, or (KP) the one of its group
+    const int o_a0 = (KP && grp) ? a_foff[1][0] : a_foff[0][0], o_a1 = (KP && grp) ? a_foff[1][1] : a_foff[0][1];
+    const int o_b = (KP && grp) ? b_foff[1] : b_foff[0], o_ap = (KP && grp) ? ap_foff[1] : ap_foff[0];
 
     if (nchunks > 0) {
         Frag f0, f1;
         __builtin_amdgcn_s_barrier();            // chunk 0 is in the LDS
-        {   // operands of (chunk 0, k-step 0): not overlapped with anything
+        {   // operands of (chunk 0, first k-step): not overlapped with anything
             const char *a_ptr = smem + wm * WM * 128;
             const char *b_ptr = smem + A_BYTES + AP_BYTES + wn * WN * 64;
 #pragma unroll
@@ -317,16 +322,16 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
                 if constexpr (PRE) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
-                        f0.a[i][pl] = *reinterpret_cast<const uintx4 *>(smem + A_BYTES + pl * BM * 64 + (wm * WM + i * 32) * 64 + ap_foff[0]);
+                        f0.a[i][pl] = *reinterpret_cast<const uintx4 *>(smem + A_BYTES + pl * BM * 64 + (wm * WM + i * 32) * 64 + o_ap);
                     continue;
                 }
                 if constexpr (GP) {
-                    f0.a[i][0] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
-                    f0.a[i][1] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+                    f0.a[i][0] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + o_a0);
+                    f0.a[i][1] = *reinterpret_cast<const uintx4 *>(a_ptr + i * 32 * 128 + o_a1);
                     continue;
                 }
-                const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][0]);
-                const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + a_foff[0][1]);
+                const floatx4 lo = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + o_a0);
+                const floatx4 hi = *reinterpret_cast<const floatx4 *>(a_ptr + i * 32 * 128 + o_a1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float xa = q < 2 ? lo[2 * q] : hi[2 * q - 4], xb = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
@@ -339,15 +344,37 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + b_foff[0]);
+                    f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + o_b);
         }
         int st = 0;
-        for (int k = 0; k < nchunks; ++k) {
-            step(f0, f1, st, S1());                              // k-step 0 of chunk k  ||  fetch + split k-step 1
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of chunk k has returned
-            __builtin_amdgcn_s_barrier();
-            st = st + 1 == NS ? 0 : st + 1;
-            step(f1, f0, st, S0());                              // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1
+        if constexpr (KP) {
+            // one k-step per chunk and wave: behind the barrier of chunk k + 1 (it has landed; every wave has READ chunk k -- its stage
+            // is refilled by the producers from here on, the operands are in registers) the MFMAs of chunk k run beside the
+            // fragment reads of chunk k + 1.  Same barrier count as the producers' loop: one per chunk.
+            auto sync = [&]() {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                st = st + 1 == NS ? 0 : st + 1;
+            };
+            int k = 0;
+            for (; k + 2 <= nchunks; k += 2) {
+                sync();
+                step(f0, f1, st, o_a0, o_a1, o_b, o_ap);
+                sync();
+                step(f1, f0, st, o_a0, o_a1, o_b, o_ap);
+            }
+            if (k < nchunks) {
+                sync();
+                step(f0, f1, st, o_a0, o_a1, o_b, o_ap);         // (reads the dummy chunk behind the reduction: unused)
+            }
+        } else {
+            for (int k = 0; k < nchunks; ++k) {
+                step(f0, f1, st, a_foff[1][0], a_foff[1][1], b_foff[1], ap_foff[1]);      // k-step 0 of chunk k  ||  fetch + split k-step 1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of chunk k has returned
+                __builtin_amdgcn_s_barrier();
+                st = st + 1 == NS ? 0 : st + 1;
+                step(f1, f0, st, a_foff[0][0], a_foff[0][1], b_foff[0], ap_foff[0]);      // k-step 1 of chunk k  ||  fetch + split k-step 0 of chunk k+1
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -387,27 +414,52 @@ __global__ void __launch_bounds__(BM == 256 ? 768 : 512) conv_igemm_ws_kernel(co
                 for (int j = 0; j < TN; ++j) acc[i][j][e] *= inv;
             }
     }
-    tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
-                                              VEC ? rowscale : nullptr, (VEC && !SPLIT) ? rowsplit : nullptr, split_out);
+    if constexpr (KP) {
+        // the two groups' sums meet: every wave hands the 32-column half it does NOT finish to its partner (wave ^ 4: same rows and
+        // columns, the other k-steps) through the LDS -- [wave][register][lane] floats behind the eight transposition patches -- and
+        // finishes the other half: group 0's sum + group 1's, in that order on both sides (the addition commutes)
+        static_assert(!KP || TN == 2, "one column half per group");
+        constexpr int XCH_OFF = 40960, XCH_WAVE = TM * 16 * 64;          // (8 patches of 32 x LDS_LD floats = 36864 bytes)
+        float *xch = reinterpret_cast<float *>(smem + XCH_OFF);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[wave * XCH_WAVE + (i * 16 + e) * 64 + lane] = grp ? acc[i][0][e] : acc[i][1][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // (the producers have left: the barrier counts the eight consumers)
+        floatx16 half[TM][1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float theirs = xch[(wave ^ 4) * XCH_WAVE + (i * 16 + e) * 64 + lane];
+                half[i][0][e] = grp ? theirs + acc[i][1][e] : acc[i][0][e] + theirs;
+            }
+        tile_epilogue<TM, 1, WM, 32, SPLIT, VEC>(p, half, reinterpret_cast<float *>(smem), m0, n0, wm, 2 * wn + grp, lane, wave, split,
+                                                 VEC ? rowscale : nullptr, (VEC && !SPLIT) ? rowsplit : nullptr, split_out);
+    } else {
+        tile_epilogue<TM, TN, WM, WN, SPLIT, VEC>(p, acc, reinterpret_cast<float *>(smem), m0, n0, wm, wn, lane, wave, split,
+                                                  VEC ? rowscale : nullptr, (VEC && !SPLIT) ? rowsplit : nullptr, split_out);
+    }
 #endif
 }
 
-template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false, bool GP = false>
+template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false, bool GP = false, bool KP = false>
 int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
-    if constexpr (!SPLIT && !BNS && !GP) {
+    if constexpr (!SPLIT && !BNS && !GP && !KP) {
         if (p.bn_part) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
     }
     if constexpr (!SPLIT && VEC && !BNS && !PRE && !GP) {
-        if (p.xscale) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, false, true>(p, splits, lds, tiles, stream);
+        if (p.xscale) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, false, true, KP>(p, splits, lds, tiles, stream);
     }
-    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE, GP>;
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE, GP, KP>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
-    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(BM == 256 ? 768 : 512), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(tiles, splits), dim3((BM == 256 || KP) ? 768 : 512), lds, stream, p);
     return PPY_OK;
 }
 
-template <int BM, int BN, int NS, bool PRE = false>
+template <int BM, int BN, int NS, bool PRE = false, bool KP = false>
 int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
     const long long wbytes = (long long)p.K * p.Kred * 2 * 2;
@@ -415,8 +467,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     constexpr int STAGE_BYTES = BM * 128 * (PRE ? 2 : 1) + 2 * BN * 64;
     static_assert(NS * STAGE_BYTES <= 160 * 1024, "LDS");
     size_t lds = (size_t)NS * STAGE_BYTES;
-    const size_t epi = (size_t)(BM == 256 ? 8 : 4) * 32 * LDS_LD * sizeof(float);
+    const size_t epi = KP ? (size_t)40960 + 8 * (BM / 64) * 16 * 64 * sizeof(float)        // eight patches + the groups' exchange area
+                          : (size_t)(BM == 256 ? 8 : 4) * 32 * LDS_LD * sizeof(float);
     if (lds < epi) lds = epi;
+    if (KP && p.bn_part) return PPY_ERR_UNSUPPORTED;
     p.nstages = NS;
     p.chunks_total = p.R * p.S * (p.C / 32);
     p.chunks_per_split = ceil_div(p.chunks_total, splits);
@@ -435,13 +489,13 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     if (p.yscale && (p.K % 32 != 0 || p.y_ld % 32 != 0)) return PPY_ERR_BAD_ARG;
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, PRE, true, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true, false, false, KP>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, true, false, false, false, KP>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_ws_one<BM, BN, NS, PRE, false, true>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, PRE, false, false>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, false, true, false, false, KP>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, false, false, false, false, KP>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
@@ -451,9 +505,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 
 // local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6; with the activations
 // split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4; eight consumer waves (4 x 2)
-// + four producers on a 256x128 tile: 7 = two stages, 8 = three
+// + four producers on a 256x128 tile: 7 = two stages, 8 = three; round 6, eight consumer waves as two k-parity groups (KP) on a
+// 128x128 tile: 9 = three stages, 10 = four
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 9; }
+int ppy_ws_num_configs() { return 11; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -470,6 +525,8 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 6: return launch_ws<128, 64, 4, true>(q, s, st);
         case 7: return launch_ws<256, 128, 2>(q, s, st);
         case 8: return launch_ws<256, 128, 3>(q, s, st);
+        case 9: return launch_ws<128, 128, 3, false, true>(q, s, st);
+        case 10: return launch_ws<128, 128, 4, false, true>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

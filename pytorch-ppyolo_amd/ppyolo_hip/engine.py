@@ -601,7 +601,7 @@ class HipExecutor(object):
         if f0 <= cfg < f0 + 27 or f0 + 45 <= cfg < f0 + 54:          # 9 tiles x {2, 3, 4} stages; the 96 / 192-row tiles
             return True
         w0 = K.ws_first_cfg()
-        return cfg - w0 in ((0, 1, 2, 3, 7, 8) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8))
+        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10) if consumer else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10))      # (9, 10: the k-parity tiles, round 6)
 
     def _split_pairs(self):
         """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (split_pairs below)."""
@@ -923,9 +923,10 @@ class HipExecutor(object):
         self._graph_stream = None
 
     # ---- autotune --------------------------------------------------------------------------
-    def autotune(self, iters=3, verbose=False, kinds=('conv', 'dcn'), match=None):
+    def autotune(self, iters=3, verbose=False, kinds=('conv', 'dcn'), match=None, only_cfgs=None):
         """Per-layer (tile config, split-K) search measured on the device: 'measure, don't
-        guess'.  Results are written into the plan ops; the graph is re-captured lazily."""
+        guess'.  Results are written into the plan ops; the graph is re-captured lazily.  only_cfgs (convolutions): measure just these
+        tile ids (new candidate kernels) against the layer's current entry instead of the whole table of configurations."""
         from ._lib import lib
         ncfg_conv = {'fp32': NUM_FP32_CFGS, 'bf16x3': NUM_FP32_CFGS + NUM_X3_CFGS}.get(self.math, lib().ppy_conv2d_num_configs())
         cfgs_dcn = K.dcnv2_configs(self.math)      # schemes up to this mode's (+ the eight-wave f16x2 tiles)
@@ -991,9 +992,16 @@ class HipExecutor(object):
                     return ms
 
                 cands = []
-                for c in (cfgs_dcn if op['op'] == 'dcn' else range(ncfg_conv)):
+                pool = cfgs_dcn if op['op'] == 'dcn' else (range(ncfg_conv) if only_cfgs is None else sorted(set(only_cfgs)))
+                if only_cfgs is not None and op['op'] == 'conv' and base_cfg >= 0:
+                    ms = measure(base_cfg, base_split, iters)             # the current entry defends its place
+                    if ms is not None:
+                        cands.append((ms, base_cfg, base_split))
+                for c in pool:
                     for s in splits:
                         if s > 1 and chunks // s < 4:
+                            continue
+                        if only_cfgs is not None and op['op'] == 'conv' and (c, s) == (base_cfg, base_split):
                             continue
                         ms = measure(c, s, iters)
                         if ms is not None:

@@ -1094,6 +1094,9 @@ def test_patch_3x3_refuses_what_it_cannot_run():
                               w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
 
 
+KP_IDS = (9, 10)      # local ids of the k-parity tiles of csrc/conv_ws.hip
+
+
 def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
     """csrc/conv_ws.hip (four waves deliver operands, four multiply) against the f16x2 tiles of conv_x3.hip: same operand
     layouts, same products in the same order, same epilogue -- EQUAL outputs over 3x3 / 1x1, strides, tiny maps, tiles that
@@ -1134,7 +1137,11 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
         what = 'N%d %dx%d C%d K%d R%d s%d res %s split %d' % (N, H, W, C, K, R, stride, res, splitk)
         close(nchw(outs[0]), ref, what=what)
         for i, y in enumerate(outs[1:]):
-            assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
+            if i in KP_IDS:        # k-parity tiles (round 6): two k-groups summed at the end -- one more fp32 rounding, like a split-K of two
+                close(nchw(y), ref, what=what + ' (k-parity tile %d)' % i)
+                assert torch.equal(y, outs[1 + KP_IDS[0]]), '%s: the k-parity tiles differ from each other (stage count only)' % what
+            else:
+                assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
 
 
 def test_stem_conv_with_maxpool_from_the_epilogue_is_the_two_launches():
