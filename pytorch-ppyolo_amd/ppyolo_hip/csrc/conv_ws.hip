@@ -35,7 +35,7 @@ namespace {
 template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false, bool KP = false>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(!KP || (BM == 128 && !PRE && !BNS), "k-parity consumers: 128-row tiles, plain / pre-split input, no BatchNorm statistics");
+    static_assert(!KP || (BM <= 128 && !PRE && !BNS), "k-parity consumers: 64- / 128-row tiles, plain / pre-split input, no BatchNorm statistics");
     constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2 * (KP ? 2 : 1);      // consumer waves: CM x 2 over the tile (256-row tiles: eight; KP: two such groups)
     constexpr int WM = BM / CM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
@@ -506,9 +506,9 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 // local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6; with the activations
 // split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4; eight consumer waves (4 x 2)
 // + four producers on a 256x128 tile: 7 = two stages, 8 = three; round 6, eight consumer waves as two k-parity groups (KP) on a
-// 128x128 tile: 9 = three stages, 10 = four
+// 128x128 tile: 9 = three stages, 10 = four; on a 64x128 tile (32x64 wave tiles): 11 = four stages, 12 = six
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 11; }
+int ppy_ws_num_configs() { return 13; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -527,6 +527,8 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 8: return launch_ws<256, 128, 3>(q, s, st);
         case 9: return launch_ws<128, 128, 3, false, true>(q, s, st);
         case 10: return launch_ws<128, 128, 4, false, true>(q, s, st);
+        case 11: return launch_ws<64, 128, 4, false, true>(q, s, st);
+        case 12: return launch_ws<64, 128, 6, false, true>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

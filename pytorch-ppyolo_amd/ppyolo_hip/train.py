@@ -214,6 +214,7 @@ class TrainStep(object):
         self._bstream = None
         self._pref = None
         self._own_backbone_done = None
+        self._coord_slot = 2                # which of a layer's coordinate-ready buffers new_coord hands out (0 / 1: prefetched backbones)
         self._b_res = None                  # [ws, bn_part, [arena0, arena1], which]
 
     @staticmethod
@@ -240,7 +241,9 @@ class TrainStep(object):
         backward finish inside one call (loss_dict snapshots the gradients), so a layer's buffer is free again at the next
         step."""
         Cp = _r32(C + 2)
-        key = (tag, N, H, W, C)
+        # (a prefetched backbone writes the NEXT batch's tensor while this batch's head still reads its own: two alternating buffers
+        # on that path, a third for the plain loop -- self._coord_slot, set by prefetch_backbone)
+        key = (tag, N, H, W, C, self._coord_slot)
         t = self._coord_bufs.get(key)
         if t is None:
             t = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=self.dev)
@@ -745,15 +748,15 @@ class TrainStep(object):
             self.tape.append(bwd)
         return o
 
-    def _bottleneck(self, p, x, stride, has_proj, is_first):
-        # reference model/resnet_vd.py:48-57, :81-87
+    def _bottleneck(self, p, x, stride, has_proj, is_first, coord_out=False):
+        # reference model/resnet_vd.py:48-57, :81-87   (coord_out: the block's output feeds a CoordConv -- the head's first layer)
         y = self.conv_unit(p + '.conv1', x, 1, 'relu')
         y = self.conv_unit(p + '.conv2', y, stride, 'relu')
         if has_proj:
             s = self.conv_unit(p + '.conv4', x, stride, None) if is_first else self.conv_unit(p + '.conv4', self._avgpool(x), 1, None)
         else:
             s = x
-        return self.conv_unit(p + '.conv3', y, 1, 'relu', res=s)             # relu(bn(conv3) + shortcut)
+        return self.conv_unit(p + '.conv3', y, 1, 'relu', res=s, coord_out=coord_out)             # relu(bn(conv3) + shortcut)
 
     def _basic(self, p, x, stride, is_first):
         # reference model/resnet_vd.py:256-267
@@ -772,7 +775,10 @@ class TrainStep(object):
             for stage, nblk in ((2, 3), (3, 4), (4, 6), (5, 3)):
                 for b in range(nblk):
                     p = 'backbone.stage%d_%d' % (stage, b)
-                    x = self._bottleneck(p, x, 1 if (stage == 2 or b > 0) else 2, b == 0, stage == 2)
+                    # round 6: the deepest feature map is read by ONE layer, the head's first CoordConv (reference model/head.py:178-182):
+                    # it is produced into that layer's coordinate-ready buffer, so no step concatenates [C5 | x_range, y_range] any more
+                    c5 = stage == 5 and b == nblk - 1 and bool(cfg.head.get('coord_conv', True)) and 5 in cfg.backbone['feature_maps']
+                    x = self._bottleneck(p, x, 1 if (stage == 2 or b > 0) else 2, b == 0, stage == 2, coord_out=c5)
                 feats[stage] = x
         else:
             for stage in (2, 3, 4, 5):
@@ -965,6 +971,7 @@ class TrainStep(object):
         res = self._b_res
         res[3] ^= 1
         saved = (self.ws, self._bn_part, self._amax_arena, self._amax_next, self._nbt, self.flops, self.tape)
+        self._coord_slot = res[3]
         self._bstream.wait_event(ready)
         try:
             with torch.cuda.stream(self._bstream), torch.no_grad():
@@ -983,6 +990,7 @@ class TrainStep(object):
                 res[1], res[2][res[3]] = self._bn_part, self._amax_arena
         finally:
             self.ws, self._bn_part, self._amax_arena, self._amax_next, self._nbt, self.flops, self.tape = saved
+            self._coord_slot = 2
         return True
 
     def head_loss_backward(self, feats, gt_box, targets, inject_douts=None):
