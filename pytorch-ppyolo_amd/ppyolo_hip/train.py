@@ -385,7 +385,8 @@ class TrainStep(object):
             ids = list(range(NUM_FP32_CFGS, NUM_FP32_CFGS + 9))                 # the nine bf16x3 tiles
             if f16:
                 ids = list(range(NUM_X3_F16_FIRST, NUM_X3_F16_LAST + 1))        # the nine f16x2 tiles x {2, 3, 4} LDS stages
-                ids += list(range(K.ws_first_cfg(), K.ws_first_cfg() + K.ws_num_cfgs()))      # ... and with specialised waves (csrc/conv_ws.hip)
+                ids += list(range(K.ws_first_cfg(), K.ws_first_cfg() + min(9, K.ws_num_cfgs())))      # ... and with specialised waves (csrc/conv_ws.hip;
+                # not the k-parity tiles ws + 9..12 of round 6: they do not emit the BatchNorm statistics the training forward takes from the epilogue)
             best = None
             for cfg_id in ids:
                 for splitk in (1, 2, 3, 4, 6, 8):
