@@ -1406,15 +1406,30 @@ def test_presplit_links_in_the_plan_and_same_detections(monkeypatch):
     assert len(links) >= 12 and len(links) >= len(prods) >= 12          # (a route has two readers)
     assert all(any(op['x_split'] is pr['y_split'][0] for pr in prods) for op in links)
     assert sum(op['w'].shape[1] == 3 for op in links) >= 12
+    def padded(m, xx):
+        d, c, k = m.forward_padded(xx, ims)
+        torch.cuda.synchronize()
+        return d.cpu(), c.cpu(), k.cpu()
     got = [p.cpu() for p in model(x, ims)]
+    gd, gc, gk = padded(model, x)
     monkeypatch.setenv('PPYOLO_HIP_PRESPLIT', '0')
     model2, _ = build_model(cfg, 0, 'cuda')
     assert not any(op.get('x_split') is not None for op in model2._plans.executor(x).plan.ops)
-    want = [p.cpu() for p in model2(x, ims)]
+    wd, wc, wk = padded(model2, x)
     monkeypatch.delenv('PPYOLO_HIP_PRESPLIT')
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and torch.equal(a[:, 0], b[:, 0])
+    for i in range(8):
+        # the same detections (matched by keep index = candidate id); two rows may trade places only between scores closer than the
+        # score tolerance (round 6: the k-parity tiles add one rounding per sum, and two near-tied rows of one class did swap)
+        n = int(gc[i])
+        assert n == int(wc[i]) and n > 1
+        pos = {int(k): j for j, k in enumerate(wk[i, :n])}
+        assert sorted(pos) == sorted(int(k) for k in gk[i, :n]), 'image %d: another set of detections' % i
+        order = [pos[int(k)] for k in gk[i, :n]]
+        a, b = gd[i, :n], wd[i, order]
+        assert torch.equal(a[:, 0], b[:, 0])
         assert (a[:, 1] - b[:, 1]).abs().max() <= 2e-6 and (a[:, 2:] - b[:, 2:]).abs().max() <= 2e-3
+        for j, o in enumerate(order):
+            assert j == o or abs(float(gd[i, j, 1]) - float(wd[i, j, 1])) <= 2e-6, 'image %d: rows %d / %d out of place' % (i, j, o)
     big = x.clone()
     big[1] *= 50.0
     again = [p.cpu() for p in model(big, ims)]

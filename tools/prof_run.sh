@@ -8,7 +8,7 @@ SCR=/tmp/prof_$TAG
 rm -rf $SCR; mkdir -p $OUT $SCR
 export TMPDIR=/tmp
 STEPS=5
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-math --no-host-input --no-pmc --no-worst-case --no-graph --in-flight 1 --min-seconds 0 $*"   # (one lane: the per-kernel durations bench.py reports are solo durations)
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-alt-math --no-host-input --no-pmc --no-kernel-trace --no-batch-scaling --no-worst-case --no-graph --in-flight 1 --min-seconds 0 $*"   # (one lane: the per-kernel durations bench.py reports are solo durations)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 # (counter passes profile the clean --pmc-child run -- plan passes only -- so that per-pass sums are not inflated by the side legs'

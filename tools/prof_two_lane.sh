@@ -8,6 +8,6 @@ rm -rf $SCR; mkdir -p $SCR $REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $SCR -o t -- python $REPO/bench.py --steps 240 --warmup 10 --min-seconds 0 \
-    --no-cpu-baseline --no-alt-math --no-host-input --no-pmc --no-worst-case > $REPO/gpurun_out/two_lane_$TAG.log 2>&1
+    --no-cpu-baseline --no-alt-math --no-host-input --no-pmc --no-kernel-trace --no-worst-case > $REPO/gpurun_out/two_lane_$TAG.log 2>&1
 cd $REPO
 python tools/two_lane_timeline.py $SCR gpurun_out/${TAG}_two_lane_timeline.txt --skip 40 --count 160
