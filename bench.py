@@ -880,7 +880,8 @@ def parity_note_leg(model, wl, batch, x):
         A, B = rows_a[ia], rows_b[ib]
         return (A[:, 2:] - B[:, 2:]).abs().max(dim=1).values, (A[:, 1] - B[:, 1]).abs().max(), len(keep_b) - len(ia), ia == ib
 
-    hip_beyond = ref_beyond = boxes = unmatched = 0
+    hip_beyond = ref_beyond = boxes = unmatched = hip_moved = 0
+    ref_moved = {r: 0 for r in alts}
     hip_max = ref_max = score_max = 0.0
     same_order = True
     for i in range(batch):
@@ -889,18 +890,26 @@ def parity_note_leg(model, wl, batch, x):
         d, es, un, so = dist(dets[i, :kk], keep[i, :kk], ref, rkeep)
         hip_beyond += int((d > 1e-3).sum()); boxes += int(ref.shape[0]); unmatched += un + abs(kk - ref.shape[0])
         hip_max, score_max, same_order = max(hip_max, float(d.max())), max(score_max, float(es)), same_order and so
+        if kk == ref.shape[0]:
+            hip_moved += int((keep[i, :kk] != rkeep).sum())
         worst = 0
         for r in alts:
-            dr = dist(torch.from_numpy(g['%s_a_pred%d' % (r, i)]).double(), g['%s_a_keep%d' % (r, i)], ref, rkeep)[0]
+            ak = g['%s_a_keep%d' % (r, i)]
+            dr = dist(torch.from_numpy(g['%s_a_pred%d' % (r, i)]).double(), ak, ref, rkeep)[0]
             worst = max(worst, int((dr > 1e-3).sum()))
             ref_max = max(ref_max, float(dr.max()))
+            if ak.shape == rkeep.shape:
+                ref_moved[r] += int((ak != rkeep).sum())
         ref_beyond += worst
     return dict(text='boxes beyond 1e-3 px: HIP %d / reference-vs-itself %d of %d (max %.2e / %.2e px); scores max %.1e; keep indices %s'
                      % (hip_beyond, ref_beyond, boxes, hip_max, ref_max, score_max,
-                        'identical, same order' if (unmatched == 0 and same_order) else ('identical set' if unmatched == 0 else '%d differ' % unmatched)),
+                        'identical, same order' if (unmatched == 0 and same_order) else (
+                            'identical set, %d of %d rows trade places between near-tied scores (the reference against itself: up to %d)'
+                            % (hip_moved, boxes, max(ref_moved.values())) if unmatched == 0 else '%d differ' % unmatched)),
                 hip_boxes_beyond_1e_3_px=hip_beyond, reference_vs_itself_boxes_beyond_1e_3_px=ref_beyond, boxes=boxes,
                 hip_max_box_err_px=round(hip_max, 6), reference_vs_itself_max_px=round(ref_max, 6), max_score_err=float('%.2e' % score_max),
-                keep_indices_identical=unmatched == 0, same_order=bool(same_order),
+                keep_indices_identical=unmatched == 0, same_order=bool(same_order), rows_out_of_place=hip_moved,
+                reference_vs_itself_rows_out_of_place=ref_moved,
                 against='tests/golden/g18_%s.npz: rows + keep indices made by the reference itself (8 threads), im_size (480, 640); '
                         'reference-vs-itself = per image the worst of its other fp32 runs (%s), summed' % (tag, ', '.join(alts)),
                 north_star='box coords <= 1e-3, scores <= 1e-4, keep indices bit-exact')
