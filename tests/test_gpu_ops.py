@@ -1306,6 +1306,54 @@ def test_conv3x3_conv1x1_is_bit_repeatable_at_full_size(pool):
             assert torch.equal(got[2].view(N, -1).amax(dim=1), first[2].view(N, -1).amax(dim=1))
 
 
+@pytest.mark.parametrize('shape', [(8, 38, 38, 1024, 256, 1, 1, True), (8, 38, 38, 256, 256, 3, 1, False), (8, 19, 19, 512, 1024, 3, 1, False),
+                                   (8, 76, 76, 256, 256, 3, 2, False)])
+def test_k_parity_tiles_are_bit_repeatable_at_full_size(shape):
+    """Round 6, the k-parity tiles of csrc/conv_ws.hip (ids ws_first + 9..12) at the R50vd-608 batch-8 shapes their table entries
+    run: 16 launches on the same inputs, traffic on a second stream every other run -- every output and every tracked maximum
+    bit-equal to the first (the two consumer groups meet at ONE barrier per chunk and once more for the exchange of their sums: a
+    race would show here, as conv_b2b's did), equal between the 3- / 4-stage variants, and as close to a float64 convolution as
+    the one-group tile of the same shape."""
+    from ppyolo_hip import ops
+    N, H, W, C, K, R, stride, res = shape
+    g = torch.Generator().manual_seed(77)
+    pad = (R - 1) // 2
+    x = torch.relu(torch.randn(N, H, W, C, generator=g)) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+    w = torch.randn(K, R, R, C, generator=g) * (2.0 / (R * R * C)) ** 0.5
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, stride, pad).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    r = torch.randn(N, Ho, Wo, K, generator=g) if res else None
+    ref = F.relu(ref + r.double() if res else ref)
+    mag = ref.abs().max().item()
+    x, w = x.cuda(), w.cuda()
+    one, zero = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    wf, a_in = ops.split_weights_f16x2(w, one), ops.amax_slots(x)
+    rd = r.cuda() if res else None
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, device='cuda')
+    first = ops.ws_first_cfg()
+
+    def run(cfg):
+        y = torch.full((N, Ho, Wo, K), float('nan')).cuda()
+        am = ops.amax_slots(N=N, device='cuda')
+        ops.conv2d_bn_act(ops.View(x), w, one, zero, ops.View(y), stride, pad, 'relu', residual=None if rd is None else ops.View(rd),
+                          cfg=cfg, splitk=1, w_f16=wf, amax_in=a_in, amax_out=am)
+        torch.cuda.synchronize()
+        return y, am.view(N, -1).amax(dim=1)
+    base, base_am = run(first + 10)
+    assert torch.isfinite(base).all()
+    for rep in range(16):
+        if rep % 2:
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)
+        y, am = run(first + 9 + rep % 2)
+        assert torch.equal(y, base), 'run %d (cfg ws+%d) differs by %.3e' % (rep, 9 + rep % 2, float((y - base).abs().max()))
+        assert torch.equal(am, base_am)
+    plain, _ = run(first + 1)                  # the same tile with one consumer group
+    e_kp = float((base.cpu().double() - ref).abs().max()) / mag
+    e_plain = float((plain.cpu().double() - ref).abs().max()) / mag
+    assert e_kp <= 1.5 * e_plain + 1e-7, (e_kp, e_plain)
+
+
 # ------------------------------------------------------------------------------------------
 # "global pre-split": a producer convolution stores its output as its one consumer's finished MFMA operands
 def test_presplit_pair_matches_fp64_as_well_as_the_plain_pair():
