@@ -32,17 +32,21 @@ namespace {
 // The groups' accumulators are added through the LDS when the reduction ends (group 0's + group 1's: one more fp32 rounding than
 // the other tiles, like a split-K of two; deterministic), each group then finishes ONE 32-column half of every wave tile -- eight
 // waves share the store-bound epilogue instead of four.
-template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false, bool KP = false>      // (BNS: conv_x3.hip)
+// CPS = 2 (k-parity tiles only): a stage holds TWO 32-deep chunks and the workgroup meets at ONE barrier per 64 -- group g multiplies
+// k-step g of both.  The small-grid layers these tiles serve are bound by the per-barrier round trip (wait for the fragment reads, meet,
+// read, multiply: ~1000 cycles around 200-400 cycles of MFMAs), not by the matrix pipe: twice the work per round trip.
+template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false, bool KP = false, int CPS = 1>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!KP || (BM <= 128 && !PRE && !BNS), "k-parity consumers: 64- / 128-row tiles, plain / pre-split input, no BatchNorm statistics");
+    static_assert(CPS == 1 || (CPS == 2 && KP), "two chunks per stage: the k-parity tiles");
     constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2 * (KP ? 2 : 1);      // consumer waves: CM x 2 over the tile (256-row tiles: eight; KP: two such groups)
     constexpr int WM = BM / CM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int NP = 2, B_ROWS = NP * BN, NWP = 4;                 // weight planes, producer waves
     static_assert(BM % (8 * NWP) == 0 && B_ROWS % (16 * NWP) == 0, "whole DMA instructions per producer wave");
-    constexpr int A_PASS = BM / (8 * NWP), B_PASS = B_ROWS / (16 * NWP), G = A_PASS + B_PASS;
+    constexpr int A_PASS = BM / (8 * NWP), B_PASS = B_ROWS / (16 * NWP), G = CPS * (A_PASS + B_PASS);
     constexpr int A_BYTES = BM * 128, AP_BYTES = PRE ? 2 * BM * 64 : 0, B_BYTES = B_ROWS * 64;      // fp32 landing area, A planes, B planes
-    constexpr int STAGE = A_BYTES + AP_BYTES + B_BYTES;
+    constexpr int SUB = A_BYTES + AP_BYTES + B_BYTES, STAGE = CPS * SUB;                            // one 32-deep chunk; a stage
     static_assert((NS - 1) * G <= 63, "6-bit vmcnt");
     static_assert(!GP || (!PRE && !SPLIT && VEC && !BNS), "pre-split input: plain consumers, one split, vector epilogue");
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -59,6 +63,7 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
     const int kc_begin = split * p.chunks_per_split;
     const int kc_end = min(kc_begin + p.chunks_per_split, p.chunks_total);
     const int nchunks = kc_end - kc_begin;
+    const int nsuper = (nchunks + CPS - 1) / CPS;      // stages to walk (CPS chunks each; the tail of an odd reduction is zero-filled)
     const int hw = p.Ho * p.Wo;
 
     if (wave >= NC) {
@@ -110,13 +115,13 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
         int l_r = l_tap / p.S, l_s = l_tap - l_r * p.S;
         const char *xb = reinterpret_cast<const char *>(p.x) - bias;
         const char *wb = reinterpret_cast<const char *>(p.wf16);
-        auto issue = [&](int stage, bool have) {
+        auto issue_sub = [&](int lds_base, bool have) {
             const long long a_uni = ((long long)(l_r * p.W + l_s) * p.x_ld + l_cc * 32) * 4;
             const long long b_uni = ((long long)l_tap * (p.C / 32) + l_cc) * p.K * 64;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + (have ? a_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + (have ? b_uni : 0)), 0, 0xFFFFFF00u, 0x00020000);
             const unsigned tapbit = have ? (1u << l_tap) : 0u;
-            const unsigned lds = (unsigned)(stage * STAGE + pw * 1024);
+            const unsigned lds = (unsigned)(lds_base + pw * 1024);
 #pragma unroll
             for (int d = 0; d < A_PASS; ++d) {
                 const unsigned off = (a_ok[d] & tapbit) ? a_off[d] : OOB;
@@ -131,6 +136,10 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
             ++l_s;
             if (l_s == p.S) { l_s = 0; ++l_r; }
             if (l_tap == RS) { l_tap = 0; l_r = 0; l_s = 0; ++l_cc; }
+        };
+        auto issue = [&](int stage, int sup) {          // the CPS chunks of stage index `sup` of this split (beyond the reduction: dummies)
+#pragma unroll
+            for (int u = 0; u < CPS; ++u) issue_sub(stage * STAGE + u * SUB, sup * CPS + u < nchunks);
         };
         // PRE: the scale of the image of each of this lane's piece rows, and the split of this wave's pieces of a stage
         float sa_p[A_PASS];
@@ -170,16 +179,16 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
             // NS stage slots are requested up front, slots past the end of the reduction as out-of-range dummies, so that the
             // number of outstanding pieces is the same at every wait below
 #pragma unroll
-            for (int sidx = 0; sidx < NS; ++sidx) issue(sidx, sidx < nchunks);
+            for (int sidx = 0; sidx < NS; ++sidx) issue(sidx, sidx);
             wait_vmcnt<(NS - 1) * G>();                  // chunk 0 has landed
             split_stage(0);
             __builtin_amdgcn_s_barrier();
             int st = 0;
-            for (int k = 0; k < nchunks; ++k) {
+            for (int k = 0; k < nsuper; ++k) {
                 wait_vmcnt<(NS - 2) * G>();              // chunk k+1 has landed (this wave's pieces; the barrier makes it all of them)
                 split_stage(st + 1 == NS ? 0 : st + 1);
                 __builtin_amdgcn_s_barrier();            // ... and the consumers have read all of chunk k
-                issue(st, k + NS < nchunks);
+                issue(st, k + NS);
                 st = st + 1 == NS ? 0 : st + 1;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -347,7 +356,18 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
                     f0.b[pl][j] = *reinterpret_cast<const uintx4 *>(b_ptr + (pl * BN + j * 32) * 64 + o_b);
         }
         int st = 0;
-        if constexpr (KP) {
+        if constexpr (KP && CPS == 2) {
+            // a stage = two chunks: the loop of the one-group tiles with the two CHUNKS of a stage in the place of the two k-steps of a
+            // chunk -- MFMAs of (stage k, chunk 0) beside the reads of (k, chunk 1), the barrier, MFMAs of (k, chunk 1) beside the reads of
+            // (k + 1, chunk 0); this wave's k-step (its group's) in both
+            for (int k = 0; k < nsuper; ++k) {
+                step(f0, f1, st, o_a0 + SUB, o_a1 + SUB, o_b + SUB, o_ap);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of stage k has returned
+                __builtin_amdgcn_s_barrier();
+                st = st + 1 == NS ? 0 : st + 1;
+                step(f1, f0, st, o_a0, o_a1, o_b, o_ap);
+            }
+        } else if constexpr (KP) {
             // one k-step per chunk and wave: behind the barrier of chunk k + 1 (it has landed; every wave has READ chunk k -- its stage
             // is refilled by the producers from here on, the operands are in registers) the MFMAs of chunk k run beside the
             // fragment reads of chunk k + 1.  Same barrier count as the producers' loop: one per chunk.
@@ -444,27 +464,27 @@ __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_k
 #endif
 }
 
-template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false, bool GP = false, bool KP = false>
+template <int BM, int BN, int NS, bool PRE, bool SPLIT, bool VEC, bool BNS = false, bool GP = false, bool KP = false, int CPS = 1>
 int launch_ws_one(const ConvArgs &p, int splits, size_t lds, int tiles, hipStream_t stream) {
     if constexpr (!SPLIT && !BNS && !GP && !KP) {
         if (p.bn_part) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, true>(p, splits, lds, tiles, stream);
     }
     if constexpr (!SPLIT && VEC && !BNS && !PRE && !GP) {
-        if (p.xscale) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, false, true, KP>(p, splits, lds, tiles, stream);
+        if (p.xscale) return launch_ws_one<BM, BN, NS, PRE, SPLIT, VEC, false, true, KP, CPS>(p, splits, lds, tiles, stream);
     }
-    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE, GP, KP>;
+    auto k = conv_igemm_ws_kernel<BM, BN, NS, SPLIT, VEC, BNS, PRE, GP, KP, CPS>;
     static PpyLdsAttr attr;
     if (ppy_lds_attr(attr, reinterpret_cast<const void *>(k), 160 * 1024) != PPY_OK) return PPY_ERR_LAUNCH;
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3((BM == 256 || KP) ? 768 : 512), lds, stream, p);
     return PPY_OK;
 }
 
-template <int BM, int BN, int NS, bool PRE = false, bool KP = false>
+template <int BM, int BN, int NS, bool PRE = false, bool KP = false, int CPS = 1>
 int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     const long long xbytes = (long long)p.N * p.H * p.W * p.x_ld * 4 + (long long)(p.pad * p.W + p.pad) * p.x_ld * 4;
     const long long wbytes = (long long)p.K * p.Kred * 2 * 2;
     if (xbytes >= 0xFFFFF000LL || wbytes >= 0xFFFFF000LL || p.R * p.S > 32) return PPY_ERR_UNSUPPORTED;
-    constexpr int STAGE_BYTES = BM * 128 * (PRE ? 2 : 1) + 2 * BN * 64;
+    constexpr int STAGE_BYTES = CPS * (BM * 128 * (PRE ? 2 : 1) + 2 * BN * 64);
     static_assert(NS * STAGE_BYTES <= 160 * 1024, "LDS");
     size_t lds = (size_t)NS * STAGE_BYTES;
     const size_t epi = KP ? (size_t)40960 + 8 * (BM / 64) * 16 * 64 * sizeof(float)        // eight patches + the groups' exchange area
@@ -489,13 +509,13 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
     if (p.yscale && (p.K % 32 != 0 || p.y_ld % 32 != 0)) return PPY_ERR_BAD_ARG;
     int rc;
     if (splits > 1) {
-        rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true, false, false, KP>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, PRE, true, false, false, false, KP>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, true, true, false, false, KP, CPS>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, true, false, false, false, KP, CPS>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
         launch_splitk_reduce(p, splits, vec, stream);
     } else {
-        rc = vec ? launch_ws_one<BM, BN, NS, PRE, false, true, false, false, KP>(p, splits, lds, tiles, stream)
-                 : launch_ws_one<BM, BN, NS, PRE, false, false, false, false, KP>(p, splits, lds, tiles, stream);
+        rc = vec ? launch_ws_one<BM, BN, NS, PRE, false, true, false, false, KP, CPS>(p, splits, lds, tiles, stream)
+                 : launch_ws_one<BM, BN, NS, PRE, false, false, false, false, KP, CPS>(p, splits, lds, tiles, stream);
         if (rc != PPY_OK) return rc;
     }
     return ppy_launch_status();
@@ -506,9 +526,10 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 // local ids: 0 = 128x128 tile with 3 stages, 1 = the same with 4, 2 = 64x128 with 4, 3 = 64x128 with 6; with the activations
 // split by the producer waves (PRE): 4 = 128x128 with 3 stages, 5 = 64x128 with 4, 6 = 128x64 with 4; eight consumer waves (4 x 2)
 // + four producers on a 256x128 tile: 7 = two stages, 8 = three; round 6, eight consumer waves as two k-parity groups (KP) on a
-// 128x128 tile: 9 = three stages, 10 = four; on a 64x128 tile (32x64 wave tiles): 11 = four stages, 12 = six
+// 128x128 tile: 9 = three stages, 10 = four; on a 64x128 tile (32x64 wave tiles): 11 = four stages, 12 = six; with TWO chunks per stage
+// (one barrier per 64-deep step): 13 = 128x128 with two stages, 14 / 15 = 64x128 with two / three
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 13; }
+int ppy_ws_num_configs() { return 16; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -529,6 +550,9 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 10: return launch_ws<128, 128, 4, false, true>(q, s, st);
         case 11: return launch_ws<64, 128, 4, false, true>(q, s, st);
         case 12: return launch_ws<64, 128, 6, false, true>(q, s, st);
+        case 13: return launch_ws<128, 128, 2, false, true, 2>(q, s, st);
+        case 14: return launch_ws<64, 128, 2, false, true, 2>(q, s, st);
+        case 15: return launch_ws<64, 128, 3, false, true, 2>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

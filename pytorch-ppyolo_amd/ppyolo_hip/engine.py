@@ -601,7 +601,7 @@ class HipExecutor(object):
         if f0 <= cfg < f0 + 27 or f0 + 45 <= cfg < f0 + 54:          # 9 tiles x {2, 3, 4} stages; the 96 / 192-row tiles
             return True
         w0 = K.ws_first_cfg()
-        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10, 11, 12) if consumer else tuple(range(13)))      # (9-12: the k-parity tiles, round 6)
+        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15) if consumer else tuple(range(16)))      # (9-15: the k-parity tiles, round 6)
 
     def _split_pairs(self):
         """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (split_pairs below)."""
