@@ -348,21 +348,27 @@ def test_full_size_batch_properties(cfgc, S):
     x = synth.synth_images(N, S)
     ims = torch.tensor(_FULL_IMS)
     preds = [p.cpu() for p in model(x.cuda(), ims.cuda())]
+    keep0 = model.forward_padded(x.cuda(), ims.cuda())[2].cpu()
+    ref_keep = [keep0[i][:preds[i].shape[0]].numpy().astype(np.int64) for i in range(N)]
     perm = torch.tensor([5, 2, 7, 0, 3, 6, 1, 4])
     pp = [p.cpu() for p in model(x[perm].cuda(), ims[perm].cuda())]
+    keep_p = model.forward_padded(x[perm].cuda(), ims[perm].cuda())[2].cpu()
     has_dcn = bool(cfg.backbone.get('dcn_v2_stages'))
     for j, i in enumerate(perm.tolist()):
         if has_dcn:
             # the reference's DCNv2 folds the batch index into the fp32 row coordinate before floor()
             # (custom_layers.py:626-633), so ITS results depend on the batch position at the 1e-5
-            # level; this build reproduces that arithmetic, hence a tolerance instead of equality
-            _check_preds([pp[j]], [preds[i]], box_tol=5e-3 * max(1.0, float(ims[i].max()) / 640.0))
+            # level; this build reproduces that arithmetic, hence a tolerance instead of equality -- and rows whose scores
+            # are within 2e-6 of each other may trade places (round 6, profiles/r06_perm_rows.txt: image 1, rows 64 / 65, scores
+            # 0.016375758 / 0.016375743): matched by keep index, as the golden comparisons do
+            _check_preds([pp[j]], [preds[i]], keep=[keep_p[j]], ref_keep=[ref_keep[i]], box_tol=5e-3 * max(1.0, float(ims[i].max()) / 640.0))
         else:
             assert torch.equal(pp[j], preds[i]), 'image %d depends on its position in the batch' % i
     for i in (3, 7):
         solo = model(x[i:i + 1].cuda(), ims[i:i + 1].cuda())[0].cpu()
+        keep_s = model.forward_padded(x[i:i + 1].cuda(), ims[i:i + 1].cuda())[2].cpu()
         scale = float(ims[i].max()) / 640.0
-        _check_preds([solo], [preds[i]], box_tol=5e-3 * max(1.0, scale))
+        _check_preds([solo], [preds[i]], keep=[keep_s[0]], ref_keep=[ref_keep[i]], box_tol=5e-3 * max(1.0, scale))
     again = [p.cpu() for p in model(x.cuda(), ims.cuda())]
     for a, b in zip(preds, again):
         assert torch.equal(a, b)
