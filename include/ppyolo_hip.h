@@ -151,6 +151,14 @@ int ppy_conv2d_patch_first_config(void);
 /* First cfg id of the f16x2 tiles with specialised waves (csrc/conv_ws.hip: four waves deliver operands, four multiply; any
  * geometry the f16x2 tiles take, split-K included; bit-identical results). */
 int ppy_conv2d_ws_first_config(void);
+/* First cfg id of the wave-private tiles for SMALL outputs (round 6, csrc/conv_small.hip; f16x2 only; four ids: 32x32 / 32x64 output
+ * tiles per wave, four / eight waves per workgroup) -- batch 1 (the reference's demo loop, demo.py:121-160) and narrow layers.  A wave
+ * owns its tile and one k-part of the reduction, operands go from the L2 straight into MFMA fragment registers.  For these ids
+ * `splitk` counts k-parts INSIDE the workgroup (rounded down to a power of two <= the workgroup's waves): the parts are added in the LDS
+ * in the order 0, 1, 2, ..., no workspace is needed (ppy_conv2d_workspace_bytes = 0), no combine launch follows, pre-split tensors
+ * (ppy_conv2d_bn_act_split_f32) are accepted on both sides with splitk > 1 as well; with splitk in {1, 2, 4, 8} results are
+ * bit-identical to the f16x2 tiles' split-K of the same count. */
+int ppy_conv2d_small_first_config(void);
 /* Writes the tile configuration / split the heuristic would pick. */
 int ppy_conv2d_pick(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int *cfg_out, int *splitk_out);

@@ -48,6 +48,7 @@ _PROTOS = {
     'ppy_conv2d_stream_first_config': (c_int, []),
     'ppy_conv2d_patch_first_config': (c_int, []),
     'ppy_conv2d_ws_first_config': (c_int, []),
+    'ppy_conv2d_small_first_config': (c_int, []),
     'ppy_conv2d_pick': (c_int, [c_int] * 9 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'ppy_conv2d_dgrad_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_int] * 11 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'ppy_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int] * 11),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libppyolo_hip.so')
-SOURCES = ['capi.hip', 'conv_igemm.hip', 'conv_x3.hip', 'conv_stream.hip', 'conv_patch.hip', 'conv_ws.hip', 'conv_b2b.hip', 'conv_bwd.hip', 'train.hip', 'yolo_loss.hip', 'stem_pool.hip', 'dcn.hip', 'dcn_fused.hip', 'decode_nms.hip', 'preprocess.hip']
+SOURCES = ['capi.hip', 'conv_igemm.hip', 'conv_x3.hip', 'conv_stream.hip', 'conv_patch.hip', 'conv_ws.hip', 'conv_small.hip', 'conv_b2b.hip', 'conv_bwd.hip', 'train.hip', 'yolo_loss.hip', 'stem_pool.hip', 'dcn.hip', 'dcn_fused.hip', 'decode_nms.hip', 'preprocess.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-function']
 # No packed-fp32 VALU ops (v_pk_add/mul/fma_f32) in any kernel of this library.  Measured on MI355X (ROCm 7.2): while
 # waves of the 16-bit-MFMA convolution kernels are resident on a CU, v_pk_*_f32 instructions of ANOTHER kernel's waves on

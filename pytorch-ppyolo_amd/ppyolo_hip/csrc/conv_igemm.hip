@@ -526,8 +526,10 @@ void pick_config(const Geometry &g, int K, int *cfg_out, int *split_out) {
 static int stream_first() { return kNumCfgs + ppy_x3_num_configs(); }
 static int patch_first() { return stream_first() + ppy_stream_num_configs(); }
 static int ws_first() { return patch_first() + ppy_patch_num_configs(); }
-extern "C" int ppy_conv2d_num_configs(void) { return ws_first() + ppy_ws_num_configs(); }
+static int small_first() { return ws_first() + ppy_ws_num_configs(); }      // (round 6: csrc/conv_small.hip, behind every older id)
+extern "C" int ppy_conv2d_num_configs(void) { return small_first() + ppy_small_num_configs(); }
 extern "C" int ppy_conv2d_ws_first_config(void) { return ws_first(); }
+extern "C" int ppy_conv2d_small_first_config(void) { return small_first(); }
 extern "C" int ppy_conv2d_stream_first_config(void) { return stream_first(); }
 extern "C" int ppy_conv2d_patch_first_config(void) { return patch_first(); }
 
@@ -561,6 +563,7 @@ extern "C" size_t ppy_conv2d_workspace_bytes(int N, int H, int W, int C, int K, 
     if (!conv_geometry(N, H, W, C, K, R, S, stride, pad, &g)) return 0;
     int c, s;
     if (resolve(g, K, cfg, splitk, &c, &s) != PPY_OK) return 0;
+    if (c >= small_first()) return 0;      // (conv_small.hip splits the reduction inside the workgroup)
     return s > 1 ? (size_t)s * g.M * K * sizeof(float) : 0;
 }
 
@@ -595,7 +598,7 @@ static int conv2d_impl(const float *x, int x_ld, const float *w_krsc, const void
     if (cfg < 0 && w_x3 && K >= 48 && g.chunks >= 4) c = kNumCfgs + 4;
     if (cfg < 0 && w_f16x2 && scale_f16x2 && amax_in && (!posbias || posbias_f16x2) && K >= 48 && g.chunks >= 4)
         c = kNumCfgs + ppy_x3_f16_base() + 4;      // the same tile on the f16x2 kernel
-    if (s > 1) {
+    if (s > 1 && c < small_first()) {
         const size_t need = (size_t)s * g.M * K * sizeof(float);
         if (!ws || ws_bytes < need) return PPY_ERR_WORKSPACE;
     }
@@ -652,7 +655,7 @@ extern "C" int ppy_conv2d_bn_act_split_f32(const float *x, int x_ld, const float
         return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N,
                            H, W, C, K, R, S, stride, pad, act, upsample2x, cfg, splitk, amax_in, amax_out, ws, ws_bytes, stream, nullptr,
                            nullptr, 0.f, 0.f, amax_in2);
-    PPY_CHECK_ARG(cfg >= 0 && splitk <= 1 && !(upsample2x && y_split_scale));
+    PPY_CHECK_ARG(cfg >= 0 && (splitk <= 1 || cfg >= small_first()) && !(upsample2x && y_split_scale));      // (conv_small.hip: the k-parts never leave the launch)
     PPY_CHECK_ARG(!y_split_scale || (y_bound_mul >= 0.f && y_bound_add >= 0.f && K % 32 == 0 && y_ld % 32 == 0 && ((uintptr_t)y & 127) == 0));
     PPY_CHECK_ARG(!x_split_scale || (C % 32 == 0 && x_ld % 32 == 0 && ((uintptr_t)x & 127) == 0));
     return conv2d_impl(x, x_ld, w_krsc, w_x3, w_f16x2, scale, scale_f16x2, shift, residual, res_ld, posbias, posbias_f16x2, y, y_ld, N, H,
@@ -665,6 +668,7 @@ static int dispatch_cfg(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (p.bn_part && c < kNumCfgs + ppy_x3_f16_base()) return PPY_ERR_UNSUPPORTED;
     // pre-split tensors exist on the f16x2 tiles (conv_x3.hip, conv_ws.hip) only: anything else would misread the bytes
     if ((p.xscale || p.yscale) && (c < kNumCfgs + ppy_x3_f16_base() || (c >= stream_first() && c < ws_first()))) return PPY_ERR_BAD_ARG;
+    if (c >= small_first()) return ppy_small_dispatch(p, c - small_first(), s, st);
     if (c >= ws_first()) return ppy_ws_dispatch(p, c - ws_first(), s, st);
     if (c >= patch_first()) return s == 1 ? ppy_patch_dispatch(p, c - patch_first(), st) : PPY_ERR_BAD_ARG;
     if (c >= stream_first()) return s == 1 ? ppy_stream_dispatch(p, c - stream_first(), nullptr, 0, st) : PPY_ERR_BAD_ARG;

@@ -131,6 +131,10 @@ int ppy_patch_maxpool_dispatch(const ConvArgs &p, int Hp, int Wp, hipStream_t st
 // conv_ws.hip: the f16x2 tiles with specialised waves (four deliver operands, four multiply)
 int ppy_ws_num_configs();
 int ppy_ws_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
+// conv_small.hip (round 6): wave-private 32 x 32 / 32 x 64 output tiles for small outputs (batch 1, narrow layers); `splits` = k-parts
+// INSIDE the workgroup (a power of two <= its waves, anything else is rounded down): no workspace, no combine launch
+int ppy_small_num_configs();
+int ppy_small_dispatch(const ConvArgs &p, int local_cfg, int splits, hipStream_t stream);
 
 namespace {
 
@@ -227,15 +231,69 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                         if (col < p.K && m < p.M)
                             rv[i][j][t] = *reinterpret_cast<const floatx4 *>(p.res + (long long)m * p.res_ld + col);
                     }
+        } else if (!SPLIT && p.posb) {
+            // round 6: the CoordConv position bias (a layer without shortcut: the head's convolutions) takes the same registers and is
+            // requested up front as well -- loaded inside the store loop it stood between every tile's transposition and its stores, one
+            // L2 round trip per 32 x 32 tile and wave (3x3 512 -> 1024 at 19x19: 96 us with the bias map, 82 us without)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int col = n0 + wn * WN + j * 32 + ec4;
+                        const int m = m0 + wm * WM + i * 32 + erow + 8 * t;
+                        rv[i][j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+                        if (col < p.K && m < p.M)
+                            rv[i][j][t] = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % hw) * p.K + col);
+                    }
+        }
+        // Round 6: NOTHING is loaded inside the store loop of a column tile.  The stores sit in divergent branches (row / column tails), so
+        // the compiler cannot count them, and every first use of a loaded register behind one became `s_waitcnt vmcnt(0)` -- which on gfx950
+        // also waits for the wave's outstanding STORES: one store in flight per wave, the whole epilogue a chain of write round trips (ISA
+        // of the 192x256 tile: a vmcnt(0) in front of every 32-row group's arithmetic).  Every loaded register therefore passes through an
+        // empty asm in front of the stores: the shortcut / bias rows once, the per-channel scale / shift of ALL column tiles with them where
+        // the registers allow it (wave tiles of up to three 32 x 32 blocks), else at the head of their column tile (one wait per column tile).
+        constexpr bool HOIST_SC = TM * TN < 4;
+        floatx4 scv[HOIST_SC ? TN : 1], shv[HOIST_SC ? TN : 1];
+        if constexpr (HOIST_SC) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 32 + ec4;
+                scv[j] = floatx4{1.f, 1.f, 1.f, 1.f};
+                shv[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (!SPLIT && col < p.K) {
+                    scv[j] = *reinterpret_cast<const floatx4 *>(p.scale + col);
+                    shv[j] = *reinterpret_cast<const floatx4 *>(p.shift + col);
+                }
+            }
+            if (!SPLIT) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(scv[j]), "+v"(shv[j]));
+            }
+        }
+        if (!SPLIT && (p.res || p.posb)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(rv[i][j][t]));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + ec4;
             const bool colok = col < p.K;
             floatx4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (!SPLIT && colok) {
-                sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
-                sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
+            if constexpr (HOIST_SC) {
+                sc = scv[j];
+                sh = shv[j];
+            } else if (!SPLIT) {
+                if (colok) {
+                    sc = *reinterpret_cast<const floatx4 *>(p.scale + col);
+                    sh = *reinterpret_cast<const floatx4 *>(p.shift + col);
+                }
+                asm volatile("" : "+v"(sc), "+v"(sh));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -259,7 +317,11 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &p, floatx16 (&acc)
                             *reinterpret_cast<floatx4 *>(p.part + ((long long)split * p.M + m) * p.K + col) = v;
                         } else {
                             if (p.posb) {
-                                const floatx4 pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % hw) * p.K + col);
+                                floatx4 pb = rv[i][j][t];          // (requested in front of the loop; a layer with BOTH a bias map and a shortcut: here)
+                                if (p.res) {                      // (its wait stays inside this branch: the empty asm is the first use)
+                                    pb = *reinterpret_cast<const floatx4 *>(p.posb + (long long)(m % hw) * p.K + col);
+                                    asm volatile("" : "+v"(pb));
+                                }
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) v[u] += pb[u];
                             }

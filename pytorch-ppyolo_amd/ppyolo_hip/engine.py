@@ -600,8 +600,16 @@ class HipExecutor(object):
         f0 = NUM_FP32_CFGS + NUM_X3_CFGS
         if f0 <= cfg < f0 + 27 or f0 + 45 <= cfg < f0 + 54:          # 9 tiles x {2, 3, 4} stages; the 96 / 192-row tiles
             return True
+        if cfg >= K.small_first_cfg():          # the wave-private tiles for small outputs (csrc/conv_small.hip, round 6): both sides
+            return True
         w0 = K.ws_first_cfg()
         return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15) if consumer else tuple(range(16)))      # (9-15: the k-parity tiles, round 6)
+
+    @staticmethod
+    def _split_leaves_launch(op):
+        """Does this op's split-K go through partial sums in memory (a second launch combines them)?  Such a launch neither reads nor
+        writes pre-split tensors.  The small-output tiles (csrc/conv_small.hip) add their k-parts inside the workgroup."""
+        return op.get('splitk', 0) > 1 and not (op['op'] == 'conv' and op.get('cfg', -1) >= K.small_first_cfg())
 
     def _split_pairs(self):
         """[(producer, [consumers])] that qualify STRUCTURALLY for a pre-split tensor between them (split_pairs below)."""
@@ -638,8 +646,8 @@ class HipExecutor(object):
         for pr, cons in self._split_pairs():
             if pr.get('b2b') is not None or pr.get('b2b_of') is not None:
                 continue          # (the fused pair's output is plain fp32: it is a shortcut as well)
-            if pr.get('splitk', 0) > 1 or not self._split_capable(pr['cfg'], False) \
-                    or any(c.get('b2b') is None and (c.get('splitk', 0) > 1 or not self._split_capable(c['cfg'], True)) for c in cons):
+            if self._split_leaves_launch(pr) or not self._split_capable(pr['cfg'], False) \
+                    or any(c.get('b2b') is None and (self._split_leaves_launch(c) or not self._split_capable(c['cfg'], True)) for c in cons):
                 continue          # (every reader must take the tensor in that form, or none does)
             w, sc, sh = pr['w'], pr['scale'], pr['shift']
             l1 = w.abs().double().sum(dim=(1, 2, 3))
@@ -959,7 +967,7 @@ class HipExecutor(object):
                     # a layer whose input will arrive pre-split is measured in that form on the tiles that can read it (the
                     # bytes it reads are whatever the buffer holds: the timing does not depend on the values)
                     op.pop('x_split', None)
-                    if gp_scales is not None and s <= 1 and self._split_capable(c, True):
+                    if gp_scales is not None and (s <= 1 or c >= K.small_first_cfg()) and self._split_capable(c, True):
                         op['x_split'] = gp_scales
                     try:
                         self._run_op(op)

