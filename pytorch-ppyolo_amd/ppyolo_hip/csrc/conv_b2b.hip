@@ -171,7 +171,17 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         yoff[t] = ((unsigned)max(pix[t], 0) * (unsigned)p.y_ld + (unsigned)ec4) * 4u;
     }
     const char *res_b = reinterpret_cast<const char *>(p.res);
-    char *y_b = reinterpret_cast<char *>(p.y);
+    // round 6: y and the pooled tensor are stored through buffer resources -- a row beyond the tensor gets an out-of-range offset (the store
+    // is dropped) instead of a branch around the store.  Straight-line code is what lets the compiler COUNT its memory operations: behind a
+    // divergent branch every later wait became `s_waitcnt vmcnt(0)`, which on gfx950 also waits for the wave's own stores -- one store in
+    // flight per wave, eight waves per CU: ~2 TB/s of writes for a launch that writes 189 MB.
+    constexpr unsigned B2B_OOB = 0x80000000u;          // = num_records (the entry point keeps the tensors below 2 GB)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, B2B_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(POOL ? p.pool : p.y), 0, B2B_OOB, 0x00020000);
+    const bool no_stores = (p.skip & 4) != 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (pix[t] < 0 || no_stores) yoff[t] = B2B_OOB;
     floatx4 rv[TNH][4];
     auto load_res = [&](int col0, floatx4 (&dst)[4]) {
 #pragma unroll
@@ -303,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         bnd = (n_lo + 1) * hw;
     }
     float amx = 0.f, amx_hi = 0.f;
+    floatx4 sc_next = *reinterpret_cast<const floatx4 *>(p.scaleB + ec4), sh_next = *reinterpret_cast<const floatx4 *>(p.shiftB + ec4);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         // this half's weights have landed: the first half's are the only loads in flight; behind the second half's DMA come the 16
@@ -345,7 +356,14 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
 #pragma unroll
         for (int jj = 0; jj < TNH; ++jj) {
             const int col = half * HB + jj * 32 + ec4;
-            const floatx4 sc = *reinterpret_cast<const floatx4 *>(p.scaleB + col), sh = *reinterpret_cast<const floatx4 *>(p.shiftB + col);
+            // this column tile's scale / shift were requested one tile ago, IN FRONT of that tile's stores (a wait for a load also waits
+            // for everything older than it, never for what was issued behind it); the next tile's are requested here
+            const floatx4 sc = sc_next, sh = sh_next;
+            if (jj + 1 < TNH || half == 0) {
+                const int coln = (jj + 1 < TNH ? half * HB + (jj + 1) * 32 : HB) + ec4;
+                sc_next = *reinterpret_cast<const floatx4 *>(p.scaleB + coln);
+                sh_next = *reinterpret_cast<const floatx4 *>(p.shiftB + coln);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -362,21 +380,19 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
                     const float o = fmaf(v[t][u] * rs[t], sc[u], sh[u]) + rv[jj][t][u];
                     v[t][u] = o > 0.f ? o : 0.f;
                 }
-                if (pix[t] >= 0 && !(p.skip & 4)) {
-                    const float rmx = fmaxf(fmaxf(fabsf(v[t][0]), fabsf(v[t][1])), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
-                    amx = fmaxf(amx, pix[t] < bnd ? rmx : 0.0f);
-                    amx_hi = fmaxf(amx_hi, pix[t] < bnd ? 0.0f : rmx);
-                    *reinterpret_cast<floatx4 *>(y_b + (size_t)yoff[t] + (half * HB + jj * 32) * 4) = v[t];
-                }
+                const float rmx = fmaxf(fmaxf(fabsf(v[t][0]), fabsf(v[t][1])), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
+                const bool live = pix[t] >= 0 && !no_stores;
+                amx = fmaxf(amx, (live && pix[t] < bnd) ? rmx : 0.0f);
+                amx_hi = fmaxf(amx_hi, (live && pix[t] >= bnd) ? rmx : 0.0f);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v[t]), ry, (int)(yoff[t] + (unsigned)((half * HB + jj * 32) * 4)), 0, 0);
             }
             if constexpr (POOL) {
-                if (pix[0] >= 0) {
-                    floatx4 r;
+                floatx4 r;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) r[u] = (((v[0][u] + v[1][u]) + v[2][u]) + v[3][u]) * 0.25f;
-                    const int blk = tile_id * 32 + wave * 8 + erow;
-                    *reinterpret_cast<floatx4 *>(p.pool + (long long)blk * p.pool_ld + col) = r;
-                }
+                for (int u = 0; u < 4; ++u) r[u] = (((v[0][u] + v[1][u]) + v[2][u]) + v[3][u]) * 0.25f;
+                const int blk = tile_id * 32 + wave * 8 + erow;
+                const unsigned poff = pix[0] >= 0 ? (unsigned)blk * (unsigned)(p.pool_ld * 4) + (unsigned)col * 4u : B2B_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, r), rp, (int)poff, 0, 0);
             }
             if (half == 0) load_res(HB + jj * 32, rv[jj]);           // the second half's shortcut rows take this tile's place
             __builtin_amdgcn_wave_barrier();
@@ -403,7 +419,8 @@ extern "C" int ppy_conv3x3_conv1x1_f32(const float *x_split, int x_ld, const flo
     PPY_CHECK_ARG(al(x_split) && al(wA_f16x2) && al(wB_f16x2) && al(scaleA_f16x2) && al(shiftA) && al(scaleB_f16x2) && al(shiftB) && al(residual) && al(y));
     if (pool) PPY_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && pool_ld >= KB && pool_ld % 4 == 0 && al(pool));
     const long long M = (long long)N * H * W;
-    if (M > 0x7fffffffLL / 4 || (M + W + 1) * x_ld * 4 >= 0xFFFFF000LL || M * res_ld * 4 >= 0xFFFFF000LL || M * y_ld * 4 >= 0xFFFFF000LL) return PPY_ERR_UNSUPPORTED;
+    if (M > 0x7fffffffLL / 4 || (M + W + 1) * x_ld * 4 >= 0xFFFFF000LL || M * res_ld * 4 >= 0xFFFFF000LL || M * y_ld * 4 >= 0x7FFFF000LL ||
+        (pool && (M / 4) * pool_ld * 4 >= 0x7FFFF000LL)) return PPY_ERR_UNSUPPORTED;      // (y / pool: buffer stores with a 2 GB range)
     B2bArgs a;
     a.x = x_split; a.wA = (const unsigned short *)wA_f16x2; a.wB = (const unsigned short *)wB_f16x2;
     a.scaleA = scaleA_f16x2; a.shiftA = shiftA; a.scaleB = scaleB_f16x2; a.shiftB = shiftB;

@@ -397,18 +397,49 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 4) yolo_decode_stream_kernel(co
         const int ncl = have ? min(DS_GC, cells_img - cell_base) : 0;
         const bool cell_ok = c < ncl;
         const float *row = p.head + ((long long)n * cells_img + cell_base + c) * p.head_ld;
+        // round 6: the row is requested through a buffer resource -- a lane without a cell (or beyond the row's last 16-byte group) gets an
+        // out-of-range offset and reads zeros.  The predicated form (`v = 0; if (ok) v = load`) put a branch and a zero fill in front of
+        // every load, and hipcc placed `s_waitcnt vmcnt(1)` / `vmcnt(0)` in front of the 13th and 14th: twelve loads in flight, then a
+        // round trip, then the last five (ISA of the round-5 kernel) -- not the seventeen this loop was written for.
         floatx4 v[NJ];
+        {
+            constexpr unsigned DS_OOB = 0x80000000u;      // = num_records (a level's head output is far below 2 GB; checked by the entry point)
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)p.head, 0, DS_OOB, 0x00020000);
+            const unsigned rbase = cell_ok ? (unsigned)(((long long)n * cells_img + cell_base + c) * p.head_ld * 4) + (unsigned)r * 16u : DS_OOB;
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (cell_ok && 4 * i + r < N4ROW) v[i] = *reinterpret_cast<const floatx4 *>(row + 4 * (4 * i + r));
+            for (int i = 0; i < NJ; ++i) {
+                const unsigned off = (4 * i + r < N4ROW) ? rbase + (unsigned)i * 64u : DS_OOB;
+                v[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rh, (int)off, 0, 0));
+            }
         }
-        // pair lanes (r < A): header values, decode_pair, box store
+        // pair lanes (r < A): header values, decode_pair, box store.  Round 6: the six header values of anchor r (IoU logit, t0 .. t4) are
+        // taken from the quad's registers -- channel ch of the row sits in element ch % 4 of v[ch / 16] of quad lane (ch / 4) % 4 -- instead
+        // of being loaded again: the reload was a second memory round trip in every wave's chain (and, short of registers, hipcc waited
+        // for ALL seventeen row loads before it could form the reload's address)
+        auto header = [&](int ch_q0, int step_q) -> float {      // channel ch_q0 + q * step_q for pair lane q
+            float val = 0.0f;
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                const int ch = ch_q0 + q * step_q;
+                const float src = v[ch >> 4][ch & 3];
+                float b;
+                switch ((ch >> 2) & 3) {
+                    case 0: b = quad_bcast<0>(src); break;
+                    case 1: b = quad_bcast<1>(src); break;
+                    case 2: b = quad_bcast<2>(src); break;
+                    default: b = quad_bcast<3>(src); break;
+                }
+                val = r == q ? b : val;
+            }
+            return val;
+        };
+        const float h_iou = IOU ? header(0, 1) : 0.0f;
+        const float h_t0 = header(OFF0 + 0, PER), h_t1 = header(OFF0 + 1, PER), h_t2 = header(OFF0 + 2, PER);
+        const float h_t3 = header(OFF0 + 3, PER), h_t4 = header(OFF0 + 4, PER);
         float conf = 0.0f, bound = INFINITY;
         if (cell_ok && r < A && !(m.abl & 2)) {
-            const float *t = row + OFF0 + r * PER;
-            const float iou_logit = IOU ? row[r] : 0.0f;
-            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+            const float iou_logit = h_iou;
+            const float t0 = h_t0, t1 = h_t1, t2 = h_t2, t3 = h_t3, t4 = h_t4;
             const int cell = cell_base + c;
             const int h = cell / p.S, w = cell - h * p.S;
             floatx4 bb;
@@ -1188,7 +1219,8 @@ extern "C" int ppy_yolo_decode_levels_f32(int nlevels, const float *const *head_
     bool stream_ok = !env_staged && A == 3 && num_classes == 80;
     for (int l = 0; l < nlevels && stream_ok; ++l)
         stream_ok = (head_ld[l] & 3) == 0 && head_ld[l] >= (A * (5 + num_classes) + (iou_aware ? A : 0) + 3) / 4 * 4 &&
-                    (((uintptr_t)head_out[l]) & 15) == 0;      // (whole 16-byte groups of a row are read, pad channels included)
+                    (((uintptr_t)head_out[l]) & 15) == 0 &&      // (whole 16-byte groups of a row are read, pad channels included)
+                    (long long)N * S[l] * S[l] * head_ld[l] * 4 < 0x7FFFF000LL;      // (32-bit buffer offsets with an out-of-range sentinel)
     if (stream_ok) {
         DecodeStream ds;
         ds.nlevels = nlevels;
