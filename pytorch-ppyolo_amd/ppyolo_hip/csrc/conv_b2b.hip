@@ -41,16 +41,23 @@ template <int CA, int KA, int KB, bool POOL>
 __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, NW = 4;
+    // round 6: the output tile is 8 x 16 pixels of ONE image and conv A reads its input from a WINDOW of (8 + 2) x (16 + 2) pixels that is
+    // brought into the LDS once -- the nine taps are shifted reads of it -- instead of one 128-row operand tile per tap: with K = 64 the
+    // main loop was bound by its L2 -> LDS traffic (18 chunks x 24 KB per tile; 9 TB/s chip-wide); now 45 KB of window + 18 x 8 KB of weights
+    constexpr int TY = 8, TX = 16, WX = TX + 2, WPIX = (TY + 2) * WX;      // (152 = 8 x 19: one dimension of a 128-pixel tile is ragged either way)
     constexpr int TNA = KA / 32, HB = KB / 2, TNH = HB / 32;         // conv B in two column halves of HB channels
     constexpr int CCH = CA / 32, NCH = 9 * CCH, KCH = KA / 32;       // chunks of conv A / of conv B's reduction
-    constexpr int A_PASS = BM / (8 * NW), B_PASS = (2 * KA) / (16 * NW), G = A_PASS + B_PASS;
-    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + 2 * KA * 64;
+    constexpr int WIN_CC = WPIX * 128, WIN_BYTES = CCH * WIN_CC;      // window: per 32-channel group a pixel's 128 bytes (first terms | second terms)
+    constexpr int WIN_UNITS = CCH * WPIX * 8, WIN_PASS = (WIN_UNITS + 64 * NW - 1) / (64 * NW);      // 16-byte pieces; DMA instructions per wave
+    constexpr int B_PASS = (2 * KA) / (16 * NW), G = B_PASS;          // conv A's weights of a chunk: DMA instructions per wave
+    constexpr int BST = 2 * KA * 64, BS_OFF = WIN_PASS * NW * 1024;   // a stage of them; three stages behind the window
     constexpr int A2_BYTES = KCH * BM * 128;                         // the intermediate as GEMM B's A operand
     constexpr int W_OFF = A2_BYTES, W_BYTES = KCH * 2 * HB * 64;     // one column half of conv B's planes: [chunk][plane][HB][32]
     constexpr int E_OFF = W_OFF + W_BYTES;                           // transposition patches: 32 x 32 floats per wave, XOR-swizzled
     constexpr int B2_PASS = W_BYTES / (1024 * NW);
+    static_assert(TY * TX == BM && TY == 2 * NW && TX == 16, "a wave owns two tile rows as eight 2x2 blocks");
     static_assert(KA % 32 == 0 && KB % 64 == 0 && CA % 32 == 0 && (2 * KA) % (16 * NW) == 0 && W_BYTES % (1024 * NW) == 0 && HB % 16 == 0, "shapes");
-    static_assert(3 * STAGE <= E_OFF + NW * 4096, "the main loop's stages fit the allocation");
+    static_assert(BS_OFF >= WIN_BYTES && BS_OFF + 3 * BST <= E_OFF + NW * 4096, "window + weight stages fit the allocation");
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) char smem_b2b[];
     char *smem = smem_b2b;
@@ -64,48 +71,36 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         tile_id = xcd * q + min(xcd, r) + idx;
     }
     const int hw = p.H * p.W;
-    const int Wq = p.W >> 1, qhw = hw >> 2;
-    // pixel (row of y / res / x) of tile row R (0..127), or -1 beyond the tensor.  Linear: consecutive pixels.  POOL: wave R >> 5 owns
-    // the blocks tile * 32 + 8 (R >> 5) + (R & 7), row (R & 31) >> 3 is the position inside the 2x2 block
+    // tile -> (image, tile row, tile column); tile row R (0..127) -> pixel: wave R >> 5 owns the tile's rows 2w, 2w + 1 as eight 2x2 blocks,
+    // row r = R & 31 of the wave is block r & 7, position r >> 3 inside it (the four rows r, r + 8, r + 16, r + 24 a lane finishes after the
+    // transposition are ONE block: what the pooled output needs)
+    const int tiles_x = (p.W + TX - 1) / TX, tiles_y = (p.H + TY - 1) / TY;
+    const int t_n = tile_id / (tiles_x * tiles_y), t_rem = tile_id - t_n * (tiles_x * tiles_y);
+    const int t_y = t_rem / tiles_x, t_x = t_rem - t_y * tiles_x;
+    const int y0 = t_y * TY, x0 = t_x * TX;
     auto pixel_of = [&](int R) -> int {
-        if constexpr (!POOL) {
-            const int m = tile_id * BM + R;
-            return m < p.M ? m : -1;
-        } else {
-            const int blk = tile_id * 32 + (R >> 5) * 8 + (R & 7), pos = (R & 31) >> 3;
-            if (blk >= (p.M >> 2)) return -1;
-            const int n = blk / qhw, rem = blk - n * qhw;
-            const int ph = rem / Wq, pw = rem - ph * Wq;
-            return n * hw + (2 * ph + (pos >> 1)) * p.W + 2 * pw + (pos & 1);
-        }
+        const int w = R >> 5, r = R & 31;
+        const int y = y0 + 2 * w + (r >> 4), x = x0 + 2 * (r & 7) + ((r >> 3) & 1);
+        return (y < p.H && x < p.W) ? t_n * hw + y * p.W + x : -1;
     };
     const unsigned OOB = 0xFFFFFFF0u;
-    const long long bias = (long long)(p.W + 1) * p.x_ld * 4;               // pad = 1: keeps offsets >= 0
-
-    // ---- per-lane DMA source offsets of conv A (conv_x3.hip) ----
-    unsigned a_off[A_PASS], a_ok[A_PASS], b_off[B_PASS];
+    // ---- the window: piece q = ((pass * NW + wave) * 64 + lane) is 16-byte slot q & 7 of window pixel (q >> 3) % WPIX of channel group
+    // (q >> 3) / WPIX, and lands at byte 16 q; the slot is swizzled on the SOURCE side (content slot c of pixel wp sits at c ^ ((wp >> 1) & 7):
+    // the sixteen lanes of a fragment read -- consecutive window pixels -- hit sixteen different bank groups).  Pixels outside the image: zeros.
     {
-        const int drow = lane >> 3, dslot = lane & 7;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, 0xFFFFFF00u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < A_PASS; ++j) {
-            const int row = (j * NW + wave) * 8 + drow;
-            const int scol = dslot ^ ((row >> 1) & 7);
-            const int m = pixel_of(row);
-            const int mc = max(m, 0);
-            const int n = mc / hw, rem = mc - n * hw;
-            const int ho = rem / p.W, wo = rem - ho * p.W;
-            const int hi0 = ho - 1, wi0 = wo - 1;
-            a_off[j] = (unsigned)((((long long)n * p.H + hi0) * p.W + wi0) * p.x_ld * 4 + bias + scol * 16);
-            unsigned colmask = 0, okb = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2)
-                if ((unsigned)(wi0 + s2) < (unsigned)p.W) colmask |= 1u << s2;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-                if ((unsigned)(hi0 + r) < (unsigned)p.H) okb |= colmask << (r * 3);
-            a_ok[j] = m >= 0 ? okb : 0u;
+        for (int d = 0; d < WIN_PASS; ++d) {
+            const int q = (d * NW + wave) * 64 + lane;
+            const int pq = q >> 3, cc = pq / WPIX, wp = pq - cc * WPIX;
+            const int wy = wp / WX, wx = wp - wy * WX;
+            const int y = y0 - 1 + wy, x = x0 - 1 + wx;
+            const bool ok = q < WIN_UNITS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(((t_n * p.H + y) * p.W + x) * (p.x_ld * 4) + cc * 128 + (((q & 7) ^ ((wp >> 1) & 7)) << 4)) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (d * NW + wave) * 1024), 16, off, 0, 0, 0);
         }
     }
+    unsigned b_off[B_PASS];
     {
         const int drow = lane >> 2, dslot = lane & 3;
         const long long plane_bytes = (long long)KA * (9 * CA) * 2;
@@ -117,31 +112,23 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
             b_off[j] = (unsigned)(plane * plane_bytes + (long long)nrow * 64 + scol * 16);
         }
     }
-    const char *xb = reinterpret_cast<const char *>(p.x) - bias;
     const char *wb = reinterpret_cast<const char *>(p.wA);
-    auto issue = [&](int stage, int kc) {           // chunk kc = (channel chunk cc, tap): cc outer, tap inner
+    auto issue = [&](int stage, int kc) {           // conv A's weights of chunk kc = (channel chunk cc, tap): cc outer, tap inner
         const int cc = kc / 9, tap = kc - cc * 9;
-        const int r = tap / 3, s = tap - r * 3;
-        const long long a_uni = ((long long)(r * p.W + s) * p.x_ld + cc * 32) * 4;
         const long long b_uni = ((long long)tap * CCH + cc) * KA * 64;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(xb + a_uni), 0, 0xFFFFFF00u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(wb + b_uni), 0, 0xFFFFFF00u, 0x00020000);
-        const unsigned tapbit = 1u << tap;
-        const unsigned lds = (unsigned)(stage * STAGE + wave * 1024);
-#pragma unroll
-        for (int d = 0; d < A_PASS; ++d) {
-            const unsigned off = (a_ok[d] & tapbit) ? a_off[d] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + lds + d * NW * 1024), 16, off, 0, 0, 0);
-        }
 #pragma unroll
         for (int j = 0; j < B_PASS; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + lds + A_BYTES + j * NW * 1024), 16, b_off[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + BS_OFF + stage * BST + (j * NW + wave) * 1024), 16, b_off[j], 0, 0, 0);
     };
 
-    // fragment read offsets (conv_x3.hip, GP form): MFMA k-step s, lane half h: first terms in slot 2s + h, second terms in 4 + 2s + h
+    // fragment reads.  A: this lane's MFMA row is the wave's row frow = its pixel (2 wave + (frow >> 4), 2 (frow & 7) + ((frow >> 3) & 1)) of the
+    // tile = window pixel wp0 at tap (0, 0); tap (r, s) reads window pixel wp0 + r WX + s.  k-step ks, lane half h: first terms in content
+    // slot 2 ks + h, second terms in 4 + 2 ks + h.  B (conv_x3.hip): row frow of the plane, slot 2 ks + h swizzled by (frow >> 2) & 3.
     const int frow = lane & 31, fkh = lane >> 5;
+    const int wp0 = (2 * wave + (frow >> 4)) * WX + 2 * (frow & 7) + ((frow >> 3) & 1);
     const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 2) & 3;
-    int a_foff[2][2], b_foff[2];
+    int a_foff[2][2], b_foff[2];          // (a_foff: GEMM B's A operand, the intermediate, by tile row -- conv_x3.hip's GP form)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         a_foff[s][0] = frow * 128 + (((2 * s + fkh) ^ a_sw) << 4);
@@ -152,8 +139,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
     // per-image scales of this lane's tile row (row lane & 31 of the wave's 32)
     float inv_sa, s2, inv_s2;
     {
-        const int m = max(pixel_of(wave * 32 + (lane & 31)), 0);
-        const int n = min(m / hw, p.N - 1);
+        const int n = min(t_n, p.N - 1);          // (a tile lies inside one image)
         inv_sa = pow2_inverse(p.xscale[n]);
         s2 = split_scale_of(fmaf(p.t_mul, pow2_above(amax_read(p.amax_in, n)), p.t_add));
         inv_s2 = pow2_inverse(s2);
@@ -214,12 +200,15 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
         __builtin_amdgcn_s_barrier();        // chunk k is visible, and every wave has finished chunk k - 1: its stage takes chunk k + 2
         if (k + 2 < NCH) issue((k + 2) % 3, k + 2);
         const int st = k % 3;
-        const char *a_ptr = smem + st * STAGE + wave * 32 * 128;
-        const char *b_ptr = smem + st * STAGE + A_BYTES;
+        const int cc = k / 9, tap = k - cc * 9, tr = tap / 3;
+        const int wp = wp0 + tr * WX + (tap - tr * 3);          // this lane's window pixel under the tap
+        const char *a_ptr = smem + cc * WIN_CC + wp * 128;
+        const int wsw = (wp >> 1) & 7;
+        const char *b_ptr = smem + BS_OFF + st * BST;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const uintx4 a0 = *reinterpret_cast<const uintx4 *>(a_ptr + a_foff[s][0]);
-            const uintx4 a1 = *reinterpret_cast<const uintx4 *>(a_ptr + a_foff[s][1]);
+            const uintx4 a0 = *reinterpret_cast<const uintx4 *>(a_ptr + (((2 * s + fkh) ^ wsw) << 4));
+            const uintx4 a1 = *reinterpret_cast<const uintx4 *>(a_ptr + (((4 + 2 * s + fkh) ^ wsw) << 4));
             uintx4 b[2][TNA];
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
@@ -304,14 +293,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
     float rs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) rs[t] = __shfl(inv_s2, (lane >> 3) + 8 * t);
-    int n_lo, n_hi, bnd;
-    {
-        const int f = pixel_of(wave * 32), l = POOL ? pixel_of(wave * 32 + 7) : pixel_of(wave * 32 + 31);
-        const int first = max(f, 0), last = l >= 0 ? l : p.M - 1;
-        n_lo = __builtin_amdgcn_readfirstlane(first / hw);
-        n_hi = __builtin_amdgcn_readfirstlane(last / hw);
-        bnd = (n_lo + 1) * hw;
-    }
+    const int n_lo = t_n, n_hi = t_n, bnd = (t_n + 1) * hw;          // (the tile lies inside image t_n: `amx_hi` stays 0)
     float amx = 0.f, amx_hi = 0.f;
     floatx4 sc_next = *reinterpret_cast<const floatx4 *>(p.scaleB + ec4), sh_next = *reinterpret_cast<const floatx4 *>(p.shiftB + ec4);
 #pragma unroll
@@ -390,7 +372,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(const B2bArgs p) {
                 floatx4 r;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) r[u] = (((v[0][u] + v[1][u]) + v[2][u]) + v[3][u]) * 0.25f;
-                const int blk = tile_id * 32 + wave * 8 + erow;
+                const int blk = (t_n * (p.H >> 1) + (y0 >> 1) + wave) * (p.W >> 1) + (x0 >> 1) + erow;      // pooled pixel of the lane's 2x2 block
                 const unsigned poff = pix[0] >= 0 ? (unsigned)blk * (unsigned)(p.pool_ld * 4) + (unsigned)col * 4u : B2B_OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, r), rp, (int)poff, 0, 0);
             }
@@ -429,7 +411,7 @@ extern "C" int ppy_conv3x3_conv1x1_f32(const float *x_split, int x_ld, const flo
     { static const int sk = getenv("PPY_B2B_SKIP") ? atoi(getenv("PPY_B2B_SKIP")) : 0; a.skip = sk; }
     a.x_ld = x_ld; a.res_ld = res_ld; a.y_ld = y_ld; a.pool_ld = pool_ld; a.N = N; a.H = H; a.W = W; a.M = (int)M;
     constexpr size_t lds = 2 * 128 * 128 + 2 * 2 * 128 * 64 + 4 * 4096;       // A2 + one column half of conv B's planes + patches = 80 KB: two workgroups per CU
-    const unsigned grid = (unsigned)((M + 127) / 128);
+    const unsigned grid = (unsigned)(N * ((H + 7) / 8) * ((W + 15) / 16));          // 8 x 16-pixel tiles, each inside one image
     if (pool) {
         auto k = conv_b2b_kernel<64, 64, 256, true>;
         static PpyLdsAttr attr;

@@ -65,11 +65,23 @@ __global__ void __launch_bounds__(512, 1) conv3x3_patch_kernel(const PatchArgs q
     {
         const char *wb = reinterpret_cast<const char *>(p.wf16);
         const long long plane_bytes = (long long)K * 9 * 32 * 2;
-        for (int u = tid; u < 9 * 2 * K * 4; u += 512) {
+        // (round 6: all of a thread's pieces are requested before the first is written -- as a plain loop hipcc waited for every load
+        // before it issued the next one: nine memory round trips at the head of every workgroup)
+        constexpr int WUNITS = 9 * 2 * K * 4, NWL = (WUNITS + 511) / 512;
+        uintx4 wv[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int u = min(tid + 512 * i, WUNITS - 1);
             const int slot = u & 3, row = u >> 2;
             const int k = row % K, tp = row / K, plane = tp & 1, tap = tp >> 1;
-            const uintx4 v = *reinterpret_cast<const uintx4 *>(wb + plane * plane_bytes + ((long long)(tap * K + k) * 32) * 2 + slot * 16);
-            *reinterpret_cast<uintx4 *>(wl + row * 64 + ((slot ^ ((k >> 2) & 3)) << 4)) = v;
+            wv[i] = *reinterpret_cast<const uintx4 *>(wb + plane * plane_bytes + ((long long)(tap * K + k) * 32) * 2 + slot * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int u = tid + 512 * i;
+            const int slot = u & 3, row = u >> 2;
+            const int k = row % K;
+            if (u < WUNITS) *reinterpret_cast<uintx4 *>(wl + row * 64 + ((slot ^ ((k >> 2) & 3)) << 4)) = wv[i];
         }
     }
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;

@@ -345,8 +345,17 @@ __global__ void __launch_bounds__(SPP_THREADS) spp_kernel(const float *__restric
     const int tid = threadIdx.x;
     const long long img = (long long)n * H * W;
     const floatx4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int u = tid; u < units; u += SPP_THREADS)
-        t0[u] = *reinterpret_cast<const floatx4 *>(x + (img + u / G) * x_ld + c0 + (u % G) * 4);
+    for (int u0 = tid; u0 < units; u0 += 4 * SPP_THREADS) {      // (four requests in flight per thread: a 19x19 map is ONE round trip, not three)
+        floatx4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = min(u0 + k * SPP_THREADS, units - 1);
+            v[k] = *reinterpret_cast<const floatx4 *>(x + (img + u / G) * x_ld + c0 + (u % G) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (u0 + k * SPP_THREADS < units) t0[u0 + k * SPP_THREADS] = v[k];
+    }
     __syncthreads();
     float *outs[3] = {y5, y9, y13};
     floatx4 *src = t0, *dst = t2;
