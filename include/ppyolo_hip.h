@@ -134,13 +134,12 @@ int ppy_conv2d_num_configs(void);
  *   40-66  f16x2 tiles, 9 shapes x {2, 3, 4} LDS stages           67-84  the same with slab reuse (3x3 / stride 1 / pad 1 only)
  *   85-93  f16x2 tiles of 96 / 192 rows x {2, 3, 4} stages        then, from the functions below:
  *   stream_first + {0, 1}   streaming 1x1 kernel (C = 64 / 128)   patch_first   patch kernel of the 3x3 stem layers (C = 32)
- *   ws_first + {0..17}      f16x2 tiles with specialised waves: 128x128 (3 / 4 stages), 64x128 (4 / 6), the three PRE variants,
+ *   ws_first + {0..15}      f16x2 tiles with specialised waves: 128x128 (3 / 4 stages), 64x128 (4 / 6), the three PRE variants,
  *                           256x128 with eight consumer waves (2 / 3 stages); round 6: + 9 / + 10 = 128x128 (3 / 4 stages), + 11 / + 12 = 64x128 (4 / 6 stages), + 13 = 128x128 and + 14 / + 15 = 64x128 with two
  *                           32-deep chunks per stage (one barrier per 64), all with eight
  *                           consumer waves as two "k-parity" groups (group g multiplies k-step g of every 32-deep chunk; the two
- *                           sums are added at the end -- one more fp32 rounding, so these are bit-identical to each other, not
- *                           to the other f16x2 tiles); + 16 / + 17 = the k-parity 128x128 (3 stages) / 64x128 (4 stages) tiles over
- *                           activations split by the PRODUCER waves (for inputs that cannot arrive pre-split)
+ *                           sums are added at the end -- one more fp32 rounding, so these seven are bit-identical to each other, not
+ *                           to the other f16x2 tiles)
  *   small_first + {0..3}    wave-private tiles for small outputs (ppy_conv2d_small_first_config below)
  * An explicit id on a geometry its kernel does not cover returns PPY_ERR_BAD_ARG (never a silent other kernel); the one exception:
  * the scalar epilogue (K % 4 != 0 or unaligned rows) does not exist for the wave tiles of six / eight 32x32 blocks (40, 46, 85-93

@@ -38,7 +38,7 @@ namespace {
 template <int BM, int BN, int NS, bool SPLIT, bool VEC, bool BNS = false, bool PRE = false, bool GP = false, bool KP = false, int CPS = 1>      // (BNS: conv_x3.hip)
 __global__ void __launch_bounds__((BM == 256 || KP) ? 768 : 512) conv_igemm_ws_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(!KP || (BM <= 128 && !BNS), "k-parity consumers: 64- / 128-row tiles, no BatchNorm statistics");
+    static_assert(!KP || (BM <= 128 && !PRE && !BNS), "k-parity consumers: 64- / 128-row tiles, plain / pre-split input, no BatchNorm statistics");
     static_assert(CPS == 1 || (CPS == 2 && KP), "two chunks per stage: the k-parity tiles");
     constexpr int CM = BM == 256 ? 4 : 2, NC = CM * 2 * (KP ? 2 : 1);      // consumer waves: CM x 2 over the tile (256-row tiles: eight; KP: two such groups)
     constexpr int WM = BM / CM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -528,10 +528,8 @@ int launch_ws(ConvArgs p, int splits, hipStream_t stream) {
 // + four producers on a 256x128 tile: 7 = two stages, 8 = three; round 6, eight consumer waves as two k-parity groups (KP) on a
 // 128x128 tile: 9 = three stages, 10 = four; on a 64x128 tile (32x64 wave tiles): 11 = four stages, 12 = six; with TWO chunks per stage
 // (one barrier per 64-deep step): 13 = 128x128 with two stages, 14 / 15 = 64x128 with two / three
-// round 6, second half: k-parity consumers over activations the PRODUCER waves split (PRE + KP -- for layers whose input cannot arrive
-// pre-split, a block input with several readers: no operand VALU work in the consumer waves): 16 = 128x128 with three stages, 17 = 64x128 with four
 // (256x128 / 128x256 with 2 x 2 consumer waves: 128 accumulator + 128 shortcut-prefetch registers spill)
-int ppy_ws_num_configs() { return 18; }
+int ppy_ws_num_configs() { return 16; }
 
 int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
     if (!p.wf16 || ((uintptr_t)p.wf16 & 15) != 0 || !p.scale_f16 || !p.amax_in || (p.posb && !p.posb_f16)) return PPY_ERR_BAD_ARG;
@@ -555,8 +553,6 @@ int ppy_ws_dispatch(const ConvArgs &p, int c, int s, hipStream_t st) {
         case 13: return launch_ws<128, 128, 2, false, true, 2>(q, s, st);
         case 14: return launch_ws<64, 128, 2, false, true, 2>(q, s, st);
         case 15: return launch_ws<64, 128, 3, false, true, 2>(q, s, st);
-        case 16: return launch_ws<128, 128, 3, true, true>(q, s, st);
-        case 17: return launch_ws<64, 128, 4, true, true>(q, s, st);
     }
     return PPY_ERR_BAD_ARG;
 }

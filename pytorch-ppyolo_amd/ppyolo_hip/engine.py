@@ -603,7 +603,7 @@ class HipExecutor(object):
         if cfg >= K.small_first_cfg():          # the wave-private tiles for small outputs (csrc/conv_small.hip, round 6): both sides
             return True
         w0 = K.ws_first_cfg()
-        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15) if consumer else tuple(range(18)))      # (9-17: the k-parity tiles, round 6; 16 / 17 split in their producer waves)
+        return cfg - w0 in ((0, 1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 14, 15) if consumer else tuple(range(16)))      # (9-15: the k-parity tiles, round 6)
 
     @staticmethod
     def _split_leaves_launch(op):

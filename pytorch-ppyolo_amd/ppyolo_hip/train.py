@@ -463,10 +463,10 @@ class TrainStep(object):
         key = 'conv:N%d:H%d:W%d:C%d:K%d:R%d:s%d' % (xin.N, xin.H, xin.W, Cp, Kout, R, stride)
         cfg_id, splitk = (-1, 0) if self.fp32 else self._choose(key, run, R * S * Cp // 32, use_f16)
         kp0 = K.ws_first_cfg() + 9
-        if kp0 <= cfg_id < kp0 + 9:
+        if kp0 <= cfg_id < kp0 + 7:
             # a k-parity tile (round 6; the inference table's entry for this geometry -- the training tables fall back on it): those
             # kernels do not emit the BatchNorm statistics this forward takes from the epilogue; the same tile with one consumer group
-            cfg_id = K.ws_first_cfg() + (0, 1, 2, 3, 1, 2, 3, 4, 5)[cfg_id - kp0]
+            cfg_id = K.ws_first_cfg() + (0, 1, 2, 3, 1, 2, 3)[cfg_id - kp0]
         # BatchNorm statistics from the convolution's epilogue (the f16x2 kernels, one split): saves the
         # statistics kernel's pass over the raw output
         slices = 0

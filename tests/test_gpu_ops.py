@@ -1094,7 +1094,7 @@ def test_patch_3x3_refuses_what_it_cannot_run():
                               w_f16=ops.split_weights_f16x2(wk, one), amax_in=ops.amax_slots(x))
 
 
-KP_IDS = (9, 10, 11, 12, 13, 14, 15, 16, 17)      # local ids of the k-parity tiles of csrc/conv_ws.hip (128x128 with 3 / 4 stages, 64x128 with 4 / 6; two chunks per stage: 128x128, 64x128 x 2; activations split by the producer waves: 128x128, 64x128)
+KP_IDS = (9, 10, 11, 12, 13, 14, 15)      # local ids of the k-parity tiles of csrc/conv_ws.hip (128x128 with 3 / 4 stages, 64x128 with 4 / 6; two chunks per stage: 128x128, 64x128 x 2)
 
 
 def test_specialised_wave_tiles_are_bit_identical_to_the_f16x2_tiles():
