@@ -145,7 +145,12 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs 
     if (dy0 >= S) return;
     const int dy1 = min(dy0 + R, S) - 1;                      // last output row of the tile
     const int dx0 = blockIdx.x * PRE_TW;
-    for (int i = threadIdx.x; i < 3 * 256; i += 256) s_lut[i] = p.a.lut[i];
+    {   // (the three table rows requested together)
+        const float l0 = p.a.lut[threadIdx.x], l1 = p.a.lut[256 + threadIdx.x], l2 = p.a.lut[512 + threadIdx.x];
+        s_lut[threadIdx.x] = l0;
+        s_lut[256 + threadIdx.x] = l1;
+        s_lut[512 + threadIdx.x] = l2;
+    }
     float ftmp;
     const int r_lo = first_tap(dy0, im.scale_y, ftmp) - 1;
     const int nrows = first_tap(dy1, im.scale_y, ftmp) + 2 - r_lo + 1;      // <= PRE_MAXROWS (host: rows_for)
@@ -162,19 +167,35 @@ __global__ __launch_bounds__(256) void preprocess_tile_kernel(const PreTileArgs 
 #pragma unroll
             for (int j = 0; j < 4; ++j) cj[j] = min(max(sx - 1 + j, 0), im.w - 1) * 3;
             // PRE_U rows per pass, all their loads in flight together (one row at a time left every thread in a chain of dependent
-            // ~1 us loads: the phase was latency-bound)
+            // ~1 us loads: the phase was latency-bound).  Round 6: the four source pixels of a row (12 bytes at an arbitrary byte address) are
+            // ONE aligned 16-byte buffer load and three v_alignbyte -- as three unaligned dwords hipcc emitted nine 1- / 2-byte loads per row, and
+            // because they sat inside the `inside` branch it could not count them: every row's loads were waited for before the next row's
+            // were issued (ISA of the round-5 kernel), not PRE_U rows in flight.  The resource starts at the image pointer rounded DOWN to a
+            // dword; a thread at the image border requests a clamped (valid) address here and gathers its bytes one by one below.
+            const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(im.src) & 3);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(im.src - mis), 0, (mis + (unsigned)im.h * (unsigned)im.stride + 3u) & ~3u, 0x00020000);
+            const unsigned bo = mis + (unsigned)min(max(sx - 1, 0), max(im.w - 4, 0)) * 3u;
             for (int rb = lane; rb < nrows; rb += 2 * PRE_U) {
                 unsigned px[PRE_U][3];
+                uintx4 dw[PRE_U];
 #pragma unroll
                 for (int u = 0; u < PRE_U; ++u) {
                     const int r = min(rb + 2 * u, nrows - 1);       // (a repeated last row: same bytes, result not stored)
-                    const unsigned char *row = im.src + (long long)min(max(r_lo + r, 0), im.h - 1) * im.stride;
-                    if (inside) {
-                        const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(row + (sx - 1) * 3);
-                        px[u][0] = q[0];
-                        px[u][1] = q[1];
-                        px[u][2] = q[2];
-                    } else {
+                    const unsigned a = (unsigned)min(max(r_lo + r, 0), im.h - 1) * (unsigned)im.stride + bo;
+                    dw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a & ~3u), 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < PRE_U; ++u) {
+                    const int r = min(rb + 2 * u, nrows - 1);
+                    const unsigned sh = ((unsigned)min(max(r_lo + r, 0), im.h - 1) * (unsigned)im.stride + bo) & 3u;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) px[u][d] = __builtin_amdgcn_alignbyte(dw[u][d + 1], dw[u][d], sh);
+                }
+                if (!inside) {          // the image's first / last columns: clamped taps, byte by byte
+#pragma unroll
+                    for (int u = 0; u < PRE_U; ++u) {
+                        const int r = min(rb + 2 * u, nrows - 1);
+                        const unsigned char *row = im.src + (long long)min(max(r_lo + r, 0), im.h - 1) * im.stride;
                         unsigned char b[12];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
