@@ -1,6 +1,6 @@
 """Round 6: the wave-private small-output tiles (csrc/conv_small.hip) against the table's entry, layer by layer, timed as nodes of a
 captured graph (16 launches per replay) -- fp32 input, no shortcut.
-usage: python tools/experiments/r06_small_bench.py [N]"""
+usage: python tools/experiments/r06_small_bench.py [N [abs_id,abs_id,...]]"""
 import json
 import os
 import re
@@ -38,7 +38,7 @@ def main():
     table = json.load(open(os.path.join(ROOT, 'pytorch-ppyolo_amd', 'ppyolo_hip', 'tuned_gfx950_f16x2.json')))
     first = ops.small_first_cfg()
     ws = torch.empty(64 << 20, device='cuda')
-    keys = [k for k in table if k.startswith('conv:N%d:' % N) and k.endswith(':f') and re.search(r':H(19|38|76):', k)]
+    keys = [k for k in table if k.startswith('conv:N%d:' % N) and k.endswith(':f') and re.search(r':H(19|38|76|152):' if len(sys.argv) > 2 else r':H(19|38|76):', k)]
     for key in sorted(keys, key=lambda k: (-int(re.search(r':H(\d+)', k).group(1)), k)):
         m = re.match(r'conv:N(\d+):H(\d+):W(\d+):C(\d+):K(\d+):R(\d+):s(\d+)', key)
         n, H, W, C, K, R, stride = [int(v) for v in m.groups()]
@@ -58,11 +58,18 @@ def main():
         t0 = timed(mk(ent[0], ent[1]))
         row = []
         chunks = R * R * C // 32
-        for i in range(4):
-            for s in (1, 2, 4, 8):
-                if s > (4 if i < 2 else 8) or s > chunks:
-                    continue
-                row.append((timed(mk(first + i, s)), i, s))
+        if len(sys.argv) > 2:          # explicit absolute ids (e.g. the persistent tiles of csrc/conv_wsp.hip), one split
+            for c in [int(v) for v in sys.argv[2].split(',')]:
+                try:
+                    row.append((timed(mk(c, 1)), c, 1))
+                except Exception:
+                    pass
+        else:
+            for i in range(4):
+                for s in (1, 2, 4, 8):
+                    if s > (4 if i < 2 else 8) or s > chunks:
+                        continue
+                    row.append((timed(mk(first + i, s)), i, s))
         row.sort()
         print('%-44s table [%3d, %2d] %6.2f us | small: %s' % (key, ent[0], ent[1], t0, '  '.join('%d/%d %.2f' % (i, s, t) for t, i, s in row[:5])), flush=True)
 
